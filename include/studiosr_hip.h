@@ -1,0 +1,139 @@
+/* studiosr_hip.h -- C ABI of libstudiosr_hip.so (MI355X / gfx950 hot path of veritross/studiosr).
+ *
+ * The reference (pure Python) has no FFI; its hot path is the closed set of ATen ops reached from
+ * studiosr/models/{common,swinir,hat,edsr,rcan}.py.  Each entry point below
+ * replaces one group of those ops and cites the reference lines it stands in for.  All pointers are
+ * DEVICE pointers on the current HIP device; `stream` is a hipStream_t passed as void*; functions
+ * enqueue work only (no allocation, no synchronisation, graph-capture safe) and return 0 on success
+ * or a negative SR_E* code (sr_last_error() gives the text).  Layout everywhere: NHWC with the
+ * channel count padded to a multiple of 32 (pad lanes hold zeros), "T" = bf16 or fp32.
+ *
+ * Packed weights ("Wp"): fragment order [n_tile][k_chunk][lane 0..63][8] of T, element
+ *   (n = 16*n_tile + (lane & 15), k = 32*k_chunk + 8*(lane >> 4) + j); for 3x3 convs
+ *   k = (ky*3 + kx) * Cin_p + c.  studiosr_amd/packing.py builds them from a state_dict.
+ */
+#ifndef STUDIOSR_HIP_H
+#define STUDIOSR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_ABI_VERSION 1
+
+enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
+enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
+enum { SR_ACT_NONE_ = 0, SR_ACT_RELU_ = 1, SR_ACT_LRELU_ = 2, SR_ACT_GELU_ = 3 };
+enum { SR_PAD_NONE = 0, SR_PAD_EVAL_MIRROR = 1, SR_PAD_REFLECT = 2 };
+enum { SR_MAP_IDENTITY = 0, SR_MAP_WINDOW = 1 };
+enum { SR_EPI_STD = 0, SR_EPI_QKV = 1 };
+enum { SR_OUT_NHWC = 0, SR_OUT_PIXEL_SHUFFLE = 1, SR_OUT_FINAL_NCHW = 2 };
+
+int sr_abi_version(void);
+const char* sr_last_error(void);
+
+/* Model.inference ingest + SwinIR/HAT padding + Normalizer.normalize / MeanShift(sub)
+ * (studiosr/models/common.py:42-43,108-121,228-230,277-282; swinir.py:249-255).
+ * x: fp32 NCHW [B,C,H,W] -> out: NHWC [B,Hp,Wp,Cp] of out_dtype, out = x*scale[c] + bias[c],
+ * rows/cols >= H/W filled by pad_mode, channels >= C zero. */
+int sr_ingest_nchw(const float* x, void* out, int out_dtype, int B, int C, int H, int W, int Hp, int Wp,
+                   int Cp, int pad_mode, const float* scale, const float* bias, void* stream);
+
+/* nn.LayerNorm over the channel axis (swinir.py:26,313; hat.py:460): fp32 rows [M, Cp] -> [M, Cp]. */
+int sr_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, int Cp,
+                 float eps, void* stream);
+
+typedef struct SrGemm {
+    /* y = epilogue( prologue(A) @ W^T ): nn.Linear qkv/proj/fc1/fc2 with fused LayerNorm prologue,
+     * bias, GELU, residual and the window partition/reverse + cyclic shift folded into row addressing
+     * (swinir.py:69-71,80,103,151-172; common.py:184-195,236-247; hat.py:76-78,165-193,216,233). */
+    const void* A;        /* [rows, lda] a_dtype */
+    const void* Wp;       /* packed weights, compute dtype */
+    const float* bias;    /* [N] or NULL */
+    const float* ln_gamma;/* [K] fp32 or NULL: LayerNorm prologue over the first k_real channels (a_dtype must be f32) */
+    const float* ln_beta;
+    void* out;            /* STD: [rows, ldo] out_dtype.  QKV: q buffer */
+    void* out_k;          /* QKV only */
+    void* out_vt;         /* QKV only */
+    const float* skip;    /* fp32 residual [rows, ldskip] added after act/scale, or NULL */
+    int M, K, N;          /* K, N padded (K % 32 == 0, N % 64 == 0) */
+    int k_real;           /* LayerNorm width */
+    int lda, ldo, ldskip;
+    int a_dtype, out_dtype, compute_dtype;
+    int act;
+    float out_scale;
+    int a_map, o_map;     /* SR_MAP_*: rows are in window order on that side */
+    int H, W, ws, shift;  /* geometry of the window map */
+    int epi;              /* SR_EPI_* */
+    int heads, hd_p, ntok;/* QKV epilogue: q,k -> [bwin][head][tok][hd_p], v -> [bwin][head][hd_p][ntok] */
+    float ln_eps;
+} SrGemm;
+int sr_gemm(const SrGemm* a, void* stream);
+
+typedef struct SrConv3x3 {
+    /* nn.Conv2d(k=3, s=1, p=1) as an im2col-free implicit GEMM on an LDS halo tile, fused bias /
+     * ReLU / LeakyReLU / GELU / res_scale / residual and optionally nn.PixelShuffle or the final
+     * unnormalise+crop+NCHW store (common.py:104-105,124-153,232-233; swinir.py:241,290,316-326,371-372;
+     * edsr.py:34-48; rcan.py:11-36; hat.py:45-47,380,462-467). */
+    const void* x;        /* NHWC [B,H,W,Cin_p] x_dtype */
+    const void* Wp;       /* packed, compute dtype, K = 9*Cin_p */
+    const float* bias;    /* [Cout_p] or NULL */
+    void* out;
+    const void* skip;     /* residual, same geometry as the NHWC output, skip_dtype, or NULL */
+    float* pool_partial;  /* optional [B, n_tiles, Cout_p] per-tile channel sums (channel attention), or NULL */
+    const float* fin_scale; /* FINAL_NCHW: out = (acc + bias) * fin_scale[c] + fin_bias[c] */
+    const float* fin_bias;
+    int B, H, W, Cin_p, Cout_p;
+    int x_dtype, out_dtype, skip_dtype, compute_dtype;
+    int act;
+    float out_scale;
+    int out_mode;         /* SR_OUT_* */
+    int ps_r;             /* PIXEL_SHUFFLE factor r: packed channel n = (i*r + j)*Cps_p + c */
+    int cps_p;            /* PIXEL_SHUFFLE: padded channel count of the shuffled output */
+    int fin_c, fin_h, fin_w; /* FINAL_NCHW: real channels and cropped size */
+} SrConv3x3;
+int sr_conv3x3(const SrConv3x3* a, void* stream);
+int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype); /* n_tiles of pool_partial for this geometry */
+
+typedef struct SrWindowAttn {
+    /* softmax(q k^T + bias[head] + shift mask) v per (window, head)
+     * (swinir.py:83-102; common.py:250-274; hat.py:90-107).  q is pre-scaled (scale folded into Wq). */
+    const void* q;        /* [bwin][head][ntok][hd_p] T */
+    const void* k;        /* [bwin][head][ntok][hd_p] T */
+    const void* vt;       /* [bwin][head][hd_p][ntok] T */
+    const float* bias;    /* [heads][ntok][ntok] fp32 (table[rpi] gathered once per model) */
+    void* out;            /* [bwin*ntok][heads*hd_p] T (window-order rows) */
+    int n_bwin, heads, hd_p, ntok;
+    int H, W, ws, shift;  /* mask geometry (shift == 0 -> no mask) */
+    int dtype;
+} SrWindowAttn;
+int sr_window_attention(const SrWindowAttn* a, void* stream);
+
+/* nn.PixelShuffle (common.py:129,133,136) standalone: out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w].
+ * elem_size 2 or 4 bytes; tensors are plain NCHW. Bit-exact copy. */
+int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, int B, int C_out, int H, int W, int r,
+                          void* stream);
+
+/* ChannelAttention (common.py:156-170, hat.py:25-38) second half: given per-tile channel sums of y,
+ * s = sigmoid(W2 relu(W1 mean + b1) + b2); out = y * s * y_scale + skip.  y/out/skip NHWC fp32 or bf16. */
+typedef struct SrChannelAttn {
+    const void* y;
+    const float* pool_partial; /* [B, n_tiles, C_p] */
+    const float* w1;      /* [Cr, C] */
+    const float* b1;      /* [Cr] */
+    const float* w2;      /* [C, Cr] */
+    const float* b2;      /* [C] */
+    const void* skip;     /* or NULL */
+    void* out;
+    int B, H, W, C, C_p, Cr, n_tiles;
+    int y_dtype, skip_dtype, out_dtype;
+    float y_scale;
+    const void* skip2;    /* optional second residual (HAT: shortcut + attn + conv_scale*cab) or NULL */
+    int skip2_dtype;
+} SrChannelAttn;
+int sr_channel_attention(const SrChannelAttn* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""studiosr_amd -- MI355X (gfx950) native hot path of veritross/studiosr.
+
+`studiosr_amd.models` mirrors `studiosr.models` (same classes, kwargs, state_dict keys, inference API);
+the math runs in hand-written HIP kernels behind the C ABI of include/studiosr_hip.h.  GPU only: there
+is no CPU fallback (use the reference for CPU runs).
+"""
+from . import _lib, models, ops, packing, runtime  # noqa: F401
+from .models import EDSR, RCAN, SwinIR  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,127 @@
+"""ctypes binding of libstudiosr_hip.so (the C ABI declared in include/studiosr_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails the error is
+raised.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstudiosr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SR_F32, SR_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
+PAD_NONE, PAD_EVAL_MIRROR, PAD_REFLECT = 0, 1, 2
+MAP_IDENTITY, MAP_WINDOW = 0, 1
+EPI_STD, EPI_QKV = 0, 1
+OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+
+class SrGemm(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("Wp", _vp), ("bias", _vp), ("ln_gamma", _vp), ("ln_beta", _vp),
+        ("out", _vp), ("out_k", _vp), ("out_vt", _vp), ("skip", _vp),
+        ("M", _i), ("K", _i), ("N", _i), ("k_real", _i),
+        ("lda", _i), ("ldo", _i), ("ldskip", _i),
+        ("a_dtype", _i), ("out_dtype", _i), ("compute_dtype", _i),
+        ("act", _i), ("out_scale", _f),
+        ("a_map", _i), ("o_map", _i),
+        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
+        ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
+        ("ln_eps", _f),
+    ]
+
+
+class SrConv3x3(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("Wp", _vp), ("bias", _vp), ("out", _vp), ("skip", _vp),
+        ("pool_partial", _vp), ("fin_scale", _vp), ("fin_bias", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cout_p", _i),
+        ("x_dtype", _i), ("out_dtype", _i), ("skip_dtype", _i), ("compute_dtype", _i),
+        ("act", _i), ("out_scale", _f), ("out_mode", _i), ("ps_r", _i), ("cps_p", _i),
+        ("fin_c", _i), ("fin_h", _i), ("fin_w", _i),
+    ]
+
+
+class SrWindowAttn(C.Structure):
+    _fields_ = [
+        ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
+        ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
+        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i),
+    ]
+
+
+class SrChannelAttn(C.Structure):
+    _fields_ = [
+        ("y", _vp), ("pool_partial", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp),
+        ("skip", _vp), ("out", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("C_p", _i), ("Cr", _i), ("n_tiles", _i),
+        ("y_dtype", _i), ("skip_dtype", _i), ("out_dtype", _i), ("y_scale", _f),
+        ("skip2", _vp), ("skip2_dtype", _i),
+    ]
+
+
+# every symbol include/studiosr_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sr_abi_version": (_i, []),
+    "sr_last_error": (C.c_char_p, []),
+    "sr_ingest_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sr_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "sr_gemm": (_i, [C.POINTER(SrGemm), _vp]),
+    "sr_conv3x3": (_i, [C.POINTER(SrConv3x3), _vp]),
+    "sr_conv3x3_pool_tiles": (_i, [_i, _i, _i, _i]),
+    "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
+    "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libstudiosr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    proc = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise HipLibraryError("building libstudiosr_hip.so failed:\n" + proc.stdout[-4000:] + proc.stderr[-4000:])
+    if verbose:
+        print(proc.stdout)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises HipLibraryError when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipLibraryError(
+                        f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C studiosr_amd/csrc`). studiosr_amd has no CPU fallback."
+                    )
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SYMBOLS.items():
+                    fn = getattr(handle, name)  # AttributeError if the ABI drifted
+                    fn.restype, fn.argtypes = res, args
+                if handle.sr_abi_version() != 1:
+                    raise HipLibraryError("libstudiosr_hip.so ABI version mismatch")
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed ({rc}): {lib().sr_last_error().decode()}")

@@ -1,0 +1,168 @@
+// Shared device helpers for the studiosr_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every MFMA kernel in this directory
+// -------------------------------------------------------
+// * One "K-group" = 8 consecutive elements of the contraction axis held by one lane.
+//   A K-chunk = 4 K-groups = 32 elements = one v_mfma_f32_16x16x32_bf16 (bf16 mode)
+//   or eight v_mfma_f32_16x16x4_f32 (exact-fp32 mode, element j of both operands
+//   feeds instruction j, so the two modes share every layout and only differ in
+//   the element size).
+// * Operand fragment of a 16-row (or 16-col) tile: lane l holds K-group (l >> 4) of
+//   row/col (l & 15).  mma(X, Y, C) computes C[i][j] += sum_k X[i][k] * Y[j][k] with
+//   C laid out as col j = l & 15, row i = 4 * (l >> 4) + reg.
+// * Weights are pre-packed on the host in fragment order [n_tile][k_chunk][lane][8]
+//   so that a wave fetches one operand fragment with ONE fully coalesced 1 KiB
+//   (bf16) load straight into registers -- weights never pass through LDS.
+// * Activation tiles live in LDS "K-group major": image[kgroup][row] of 8-element
+//   cells (16 B bf16 / 32 B fp32).  Reading the fragment of 16 CONSECUTIVE rows is
+//   then bank-conflict free for ds_read_b128 for any starting row, which is what
+//   lets the 3x3 convolution read its nine shifted views from one halo tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SR_DEV __device__ __forceinline__
+
+// ----------------------------------------------------------------------------- fragments
+template <typename T>
+struct Frag;
+template <>
+struct __attribute__((aligned(16))) Frag<bf16> {
+    bf16x8 v;
+};
+template <>
+struct __attribute__((aligned(16))) Frag<float> {
+    f32x4 lo, hi;
+};
+
+SR_DEV void frag_zero(Frag<bf16>& f) { f.v = (bf16x8)(0.0f); }
+SR_DEV void frag_zero(Frag<float>& f) {
+    f.lo = (f32x4)(0.0f);
+    f.hi = (f32x4)(0.0f);
+}
+SR_DEV void frag_set(Frag<bf16>& f, int j, float x) { f.v[j] = (bf16)x; }
+SR_DEV void frag_set(Frag<float>& f, int j, float x) {
+    if (j < 4)
+        f.lo[j] = x;
+    else
+        f.hi[j - 4] = x;
+}
+SR_DEV float frag_get(const Frag<bf16>& f, int j) { return (float)f.v[j]; }
+SR_DEV float frag_get(const Frag<float>& f, int j) { return j < 4 ? f.lo[j] : f.hi[j - 4]; }
+
+SR_DEV Frag<bf16> frag_from8(const float* x) {
+    Frag<bf16> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (bf16)x[j];
+    return f;
+}
+template <typename T>
+SR_DEV Frag<T> frag_make(const float* x);
+template <>
+SR_DEV Frag<bf16> frag_make<bf16>(const float* x) {
+    return frag_from8(x);
+}
+template <>
+SR_DEV Frag<float> frag_make<float>(const float* x) {
+    Frag<float> f;
+    f.lo = f32x4{x[0], x[1], x[2], x[3]};
+    f.hi = f32x4{x[4], x[5], x[6], x[7]};
+    return f;
+}
+
+// C[i][j] += sum_k X[i][k] Y[j][k]; lane holds C col j = l&15, rows i = 4*(l>>4)+r.
+SR_DEV void mma(const Frag<bf16>& x, const Frag<bf16>& y, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, c, 0, 0, 0);
+}
+SR_DEV void mma(const Frag<float>& x, const Frag<float>& y, f32x4& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.lo[j], y.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.hi[j], y.hi[j], c, 0, 0, 0);
+}
+
+// ----------------------------------------------------------------------------- 8-element loads
+// Load 8 consecutive elements (one K-group) of type TIn and return them as a Frag<TC>.
+template <typename TC, typename TIn>
+SR_DEV Frag<TC> load_group(const TIn* p);
+template <>
+SR_DEV Frag<bf16> load_group<bf16, bf16>(const bf16* p) {
+    return *reinterpret_cast<const Frag<bf16>*>(p);
+}
+template <>
+SR_DEV Frag<float> load_group<float, float>(const float* p) {
+    return *reinterpret_cast<const Frag<float>*>(p);
+}
+template <>
+SR_DEV Frag<bf16> load_group<bf16, float>(const float* p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    Frag<bf16> f;
+    f.v[0] = (bf16)a[0];
+    f.v[1] = (bf16)a[1];
+    f.v[2] = (bf16)a[2];
+    f.v[3] = (bf16)a[3];
+    f.v[4] = (bf16)b[0];
+    f.v[5] = (bf16)b[1];
+    f.v[6] = (bf16)b[2];
+    f.v[7] = (bf16)b[3];
+    return f;
+}
+
+SR_DEV void load8f(const float* p, float* v) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// ----------------------------------------------------------------------------- 4-element stores
+SR_DEV void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+SR_DEV void store4(bf16* p, const f32x4& v) {
+    bf16x4 r;
+    r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+SR_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+SR_DEV f32x4 load4(const bf16* p) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+}
+
+// ----------------------------------------------------------------------------- activations
+enum { SR_ACT_NONE = 0, SR_ACT_RELU = 1, SR_ACT_LRELU = 2, SR_ACT_GELU = 3 };
+
+SR_DEV float apply_act(float x, int act) {
+    switch (act) {
+        case SR_ACT_RELU: return x > 0.f ? x : 0.f;
+        case SR_ACT_LRELU: return x > 0.f ? x : 0.01f * x;  // nn.LeakyReLU default slope
+        case SR_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));  // exact erf form
+        default: return x;
+    }
+}
+
+// window-order row -> image-order row (roll(-shift) + window_partition as one gather;
+// window_reverse + roll(+shift) is the same map used as a scatter).
+struct WinMap {
+    int H, W, ws, shift, nwx, ntok, hw;
+    SR_DEV int operator()(int row) const {
+        int b = row / hw;
+        int rem = row - b * hw;
+        int win = rem / ntok;
+        int tok = rem - win * ntok;
+        int wy = win / nwx, wx = win - wy * nwx;
+        int i = tok / ws, j = tok - i * ws;
+        int y = wy * ws + i + shift;
+        int x = wx * ws + j + shift;
+        if (y >= H) y -= H;
+        if (x >= W) x -= W;
+        return (b * H + y) * W + x;
+    }
+};
+
+SR_DEV float wave_sum_xor(float v, int mask) { return v + __shfl_xor(v, mask, 64); }

@@ -1,0 +1,253 @@
+// 3x3 convolution (stride 1, zero pad 1) as an im2col-free implicit GEMM, NHWC.
+//
+// One workgroup (4 waves) produces a TH x 16 pixel tile of N_T = WN*NW*16 output channels:
+//   * the (TH+2) x 18 input halo tile, ALL input channels, is staged once into LDS in the
+//     K-group-major image of sr_common.cuh (zero padding at the image border is written here);
+//   * an MFMA row tile is 16 horizontally adjacent output pixels, so its operand for tap
+//     (ky, kx) is 16 CONSECUTIVE rows of that image starting at (y+ky)*18 + kx: the nine
+//     shifted views are read from the one tile, conflict-free, with no im2col buffer;
+//   * weights are streamed per (tap, 32-channel chunk) straight from L2 into registers in
+//     fragment order (double buffered), never through LDS; waves split N (and M for narrow N);
+//   * no barrier in the 9*Cin/32-step main loop;
+//   * epilogue: bias, ReLU/LeakyReLU/GELU, res_scale, residual add and one of three stores:
+//     NHWC, NHWC through nn.PixelShuffle (the weight rows were permuted at pack time so that a
+//     lane's 4 consecutive accumulators are 4 consecutive channels of ONE shuffled pixel), or the
+//     final un-normalise + crop + NCHW fp32 image.  Optionally emits per-tile channel sums for
+//     channel attention (deterministic, no atomics).
+#include "sr_common.cuh"
+#include "sr_host.h"
+
+namespace {
+
+constexpr int HALO_W = 18;
+
+template <int TH>
+struct ConvGeo {
+    static constexpr int HH = TH + 2;
+    static constexpr int ROWS = ((HH * HALO_W + 15) / 16) * 16;
+};
+
+template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
+__global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
+    static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
+    constexpr int ROWS = ConvGeo<TH>::ROWS;
+    constexpr int HH = ConvGeo<TH>::HH;
+    constexpr int MTW = TH / WM;  // row tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<TC>* As = reinterpret_cast<Frag<TC>*>(smem);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_x = (c.W + 15) >> 4;
+    const int tiles_y = (c.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * 16, y0 = ty * TH;
+    const int KG = c.Cin_p >> 3, KC = c.Cin_p >> 5;
+
+    // ---- stage the halo tile (8 pixels x 8 K-groups per wave instruction: full 128-B lines)
+    {
+        const int r8 = lane & 7, kq = lane >> 3;
+        const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+        for (int pb = wave * 8; pb < ROWS; pb += 32) {
+            const int p = pb + r8;
+            const int py = p / HALO_W, px = p - py * HALO_W;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool valid = p < HH * HALO_W && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+            const TIn* src = xin + ((size_t)(b * c.H + (valid ? gy : 0)) * c.W + (valid ? gx : 0)) * c.Cin_p;
+            for (int kg = kq; kg < KG; kg += 8) {
+                Frag<TC> f;
+                if (valid)
+                    f = load_group<TC, TIn>(src + kg * 8);
+                else
+                    frag_zero(f);
+                As[kg * ROWS + p] = f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop over (tap, channel chunk)
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int ar = lane & 15, ag = lane >> 4;
+    const int ntile0 = blockIdx.y * (WN * NW) + wn * NW;
+    const int KCT = 9 * KC;
+    const Frag<TC>* Bp = reinterpret_cast<const Frag<TC>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
+
+    f32x4 acc[MTW][NW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4)(0.0f);
+
+    Frag<TC> bc[NW], bn[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) bc[n] = Bp[(size_t)n * KCT * 64];
+
+    int chunk = 0;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const Frag<TC>* abase = As + (wm * MTW + ky) * HALO_W + kx + ar + ag * ROWS;
+        for (int kc = 0; kc < KC; ++kc, ++chunk) {
+            const int cn = chunk + 1 < KCT ? chunk + 1 : chunk;
+#pragma unroll
+            for (int n = 0; n < NW; ++n) bn[n] = Bp[((size_t)n * KCT + cn) * 64];
+            const Frag<TC>* arow = abase + kc * 4 * ROWS;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const Frag<TC> a = arow[m * HALO_W];
+#pragma unroll
+                for (int n = 0; n < NW; ++n) mma(bc[n], a, acc[m][n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NW; ++n) bc[n] = bn[n];
+        }
+    }
+
+    // ---- epilogue: lane = pixel (x0 + ar), registers = 4 consecutive output channels
+    const int x = x0 + ar;
+    f32x4 pool[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) pool[n] = (f32x4)(0.0f);
+
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int y = y0 + wm * MTW + m;
+        const bool inb = (y < c.H) && (x < c.W);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int col = (ntile0 + n) * 16 + ag * 4;
+            f32x4 v = acc[m][n];
+            if (c.bias) v += load4(c.bias + col);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], c.act);
+            if (c.pool_partial && inb) pool[n] += v;
+            v *= c.out_scale;
+            if (!inb) continue;
+            if (c.out_mode == SR_OUT_FINAL_NCHW) {
+                int chb = col, yy = y, xx = x;
+                if (c.ps_r > 1) {  // "pixelshuffledirect": shuffle straight into the final image
+                    const int sub = col / c.cps_p;
+                    chb = col - sub * c.cps_p;
+                    const int i = sub / c.ps_r, j = sub - i * c.ps_r;
+                    yy = y * c.ps_r + i;
+                    xx = x * c.ps_r + j;
+                }
+                if (yy < c.fin_h && xx < c.fin_w) {
+                    float* o = reinterpret_cast<float*>(c.out);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = chb + r;
+                        if (ch < c.fin_c) o[((size_t)(b * c.fin_c + ch) * c.fin_h + yy) * c.fin_w + xx] = v[r] * c.fin_scale[ch] + c.fin_bias[ch];
+                    }
+                }
+                continue;
+            }
+            size_t off;
+            if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {
+                const int sub = col / c.cps_p, ch = col - sub * c.cps_p;
+                const int i = sub / c.ps_r, j = sub - i * c.ps_r;
+                off = ((size_t)(b * c.H * c.ps_r + y * c.ps_r + i) * (c.W * c.ps_r) + x * c.ps_r + j) * c.cps_p + ch;
+            } else {
+                off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + col;
+            }
+            if (c.skip) {
+                if (c.skip_dtype == SR_BF16)
+                    v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
+                else
+                    v += load4(reinterpret_cast<const float*>(c.skip) + off);
+            }
+            if (c.out_dtype == SR_BF16)
+                store4(reinterpret_cast<bf16*>(c.out) + off, v);
+            else
+                store4(reinterpret_cast<float*>(c.out) + off, v);
+        }
+    }
+
+    if (c.pool_partial) {
+        const int n_tiles = tiles_x * tiles_y * WM;
+        const int slot = (ty * tiles_x + tx) * WM + wm;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            f32x4 p = pool[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = p[r];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                p[r] = s;
+            }
+            if (ar == 0) store4(c.pool_partial + ((size_t)b * n_tiles + slot) * c.Cout_p + (ntile0 + n) * 16 + ag * 4, p);
+        }
+    }
+}
+
+template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
+int launch_conv(const SrConv3x3& c, hipStream_t st) {
+    constexpr int ROWS = ConvGeo<TH>::ROWS;
+    const int lds = c.Cin_p * ROWS * (int)sizeof(TC);
+    SR_REQUIRE(lds <= 160 * 1024, "sr_conv3x3: Cin_p=%d needs %d B of LDS", c.Cin_p, lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = sr_allow_lds(sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW>, 160 * 1024);
+        SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int tiles = ((c.W + 15) / 16) * ((c.H + TH - 1) / TH) * c.B;
+    dim3 grid(tiles, c.Cout_p / (WN * NW * 16));
+    hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW>), grid, dim3(256), lds, st, c);
+    SR_CHECK_LAUNCH("sr_conv3x3");
+    return SR_OK;
+}
+
+// pick the widest N tile that divides Cout_p
+template <typename TC, typename TIn, int TH>
+int dispatch_conv(const SrConv3x3& c, hipStream_t st) {
+    const int n = c.Cout_p;
+    if (n % 256 == 0) return launch_conv<TC, TIn, TH, 1, 4, 4>(c, st);
+    if (n % 192 == 0) return launch_conv<TC, TIn, TH, 1, 4, 3>(c, st);
+    if (n % 128 == 0) return launch_conv<TC, TIn, TH, 1, 4, 2>(c, st);
+    if (n % 64 == 0) return launch_conv<TC, TIn, TH, 2, 2, 2>(c, st);
+    if (n % 32 == 0) return launch_conv<TC, TIn, TH, 2, 2, 1>(c, st);
+    return launch_conv<TC, TIn, TH, 4, 1, 1>(c, st);
+}
+
+int conv_wm(int cout_p) {
+    if (cout_p % 256 == 0 || cout_p % 192 == 0 || cout_p % 128 == 0) return 1;
+    if (cout_p % 32 == 0) return 2;
+    return 4;
+}
+
+}  // namespace
+
+extern "C" int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype) {
+    // number of per-image partial-sum slots sr_conv3x3 writes into pool_partial for this geometry
+    const int th = compute_dtype == SR_BF16 ? 8 : 4;
+    return ((W + 15) / 16) * ((H + th - 1) / th) * conv_wm(Cout_p);
+}
+
+extern "C" int sr_conv3x3(const SrConv3x3* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->Wp && p->out, "sr_conv3x3: null pointer");
+    const SrConv3x3& c = *p;
+    SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.Cin_p % 32 == 0 && c.Cout_p % 16 == 0, "sr_conv3x3: bad geometry B=%d H=%d W=%d Cin_p=%d Cout_p=%d", c.B,
+               c.H, c.W, c.Cin_p, c.Cout_p);
+    if (c.out_mode == SR_OUT_PIXEL_SHUFFLE || (c.out_mode == SR_OUT_FINAL_NCHW && c.ps_r > 1))
+        SR_REQUIRE(c.ps_r >= 2 && c.cps_p % 4 == 0 && c.ps_r * c.ps_r * c.cps_p == c.Cout_p, "sr_conv3x3: pixel shuffle r=%d cps_p=%d Cout_p=%d", c.ps_r,
+                   c.cps_p, c.Cout_p);
+    if (c.out_mode == SR_OUT_FINAL_NCHW)
+        SR_REQUIRE(c.fin_scale && c.fin_bias && c.fin_c > 0 && c.fin_c <= c.Cout_p && c.fin_h <= c.H * (c.ps_r > 1 ? c.ps_r : 1) &&
+                       c.fin_w <= c.W * (c.ps_r > 1 ? c.ps_r : 1) && !c.skip,
+                   "sr_conv3x3: bad FINAL_NCHW arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c.compute_dtype == SR_BF16) {
+        if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 8>(c, st);
+        return dispatch_conv<bf16, bf16, 8>(c, st);
+    }
+    SR_REQUIRE(c.x_dtype == SR_F32, "sr_conv3x3: fp32 compute needs fp32 input");
+    return dispatch_conv<float, float, 4>(c, st);
+}

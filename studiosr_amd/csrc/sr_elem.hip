@@ -1,0 +1,233 @@
+// Memory-bound helpers around the MFMA kernels: image ingest (pad + normalise + NCHW->NHWC),
+// LayerNorm, standalone PixelShuffle and the channel-attention gate.  All HBM-bound: one pass,
+// 16-byte accesses, no LDS except the tiny channel-attention MLP.
+#include "sr_common.cuh"
+#include "sr_host.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- ingest
+// thread = one (pixel, 8-channel group) of the NHWC output.
+template <typename TOut>
+__global__ __launch_bounds__(256) void sr_ingest_kernel(const float* __restrict__ x, TOut* __restrict__ out, int B, int C, int H, int W, int Hp, int Wp,
+                                                        int Cp, int pad_mode, const float* __restrict__ scale, const float* __restrict__ bias) {
+    const int groups = Cp >> 3;
+    const long total = (long)B * Hp * Wp * groups;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        long p = i / groups;
+        const int xp = (int)(p % Wp);
+        p /= Wp;
+        const int yp = (int)(p % Hp);
+        const int b = (int)(p / Hp);
+        int ys = yp, xs = xp;
+        if (pad_mode == SR_PAD_EVAL_MIRROR) {  // cat([x, flip(x)])[: h + pad]  (edge-inclusive mirror)
+            if (ys >= H) ys = 2 * H - 1 - ys;
+            if (xs >= W) xs = 2 * W - 1 - xs;
+        } else if (pad_mode == SR_PAD_REFLECT) {  // F.pad(..., "reflect")  (edge-exclusive mirror)
+            if (ys >= H) ys = 2 * (H - 1) - ys;
+            if (xs >= W) xs = 2 * (W - 1) - xs;
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g * 8 + j;
+            v[j] = (c < C) ? x[((size_t)(b * C + c) * H + ys) * W + xs] * scale[c] + bias[c] : 0.f;
+        }
+        TOut* o = out + (size_t)i * 8;
+        store4(o, f32x4{v[0], v[1], v[2], v[3]});
+        store4(o + 4, f32x4{v[4], v[5], v[6], v[7]});
+    }
+}
+
+// ----------------------------------------------------------------------------- LayerNorm
+// 8 lanes per row (lane kq owns K-groups kq, kq+8, ...), two-pass statistics in registers.
+__global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int M, int C, int Cp, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r8 = lane & 7, kq = lane >> 3;
+    const int KG = Cp >> 3;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + r8;
+    const bool valid = row < M;
+    const float* src = x + (size_t)(valid ? row : 0) * Cp;
+    float v[6][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int kg = kq + 8 * i;
+        if (kg < KG && valid)
+            load8f(src + kg * 8, v[i]);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+    s = wave_sum_xor(s, 8);
+    s = wave_sum_xor(s, 16);
+    s = wave_sum_xor(s, 32);
+    const float inv = 1.0f / (float)C;
+    const float mean = s * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = ((kq + 8 * i) * 8 + j < C) ? v[i][j] - mean : 0.f;
+            q += d * d;
+        }
+    q = wave_sum_xor(q, 8);
+    q = wave_sum_xor(q, 16);
+    q = wave_sum_xor(q, 32);
+    const float rstd = rsqrtf(q * inv + eps);
+    if (!valid) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int kg = kq + 8 * i;
+        if (kg < KG) {
+            float gm[8], bt[8];
+            load8f(gamma + kg * 8, gm);
+            load8f(beta + kg * 8, bt);
+            float* o = y + (size_t)row * Cp + kg * 8;
+            store4(o, f32x4{(v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1], (v[i][2] - mean) * rstd * gm[2] + bt[2],
+                            (v[i][3] - mean) * rstd * gm[3] + bt[3]});
+            store4(o + 4, f32x4{(v[i][4] - mean) * rstd * gm[4] + bt[4], (v[i][5] - mean) * rstd * gm[5] + bt[5], (v[i][6] - mean) * rstd * gm[6] + bt[6],
+                                (v[i][7] - mean) * rstd * gm[7] + bt[7]});
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- PixelShuffle (NCHW, exact copy)
+template <typename T>
+__global__ __launch_bounds__(256) void sr_pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Co, int H, int W, int r) {
+    const int Ho = H * r, Wo = W * r;
+    const long total = (long)B * Co * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        long p = i / Wo;
+        const int yo = (int)(p % Ho);
+        p /= Ho;
+        const int c = (int)(p % Co);
+        const int b = (int)(p / Co);
+        const int ci = c * r * r + (yo % r) * r + (xo % r);
+        out[i] = in[((size_t)(b * Co * r * r + ci) * H + yo / r) * W + xo / r];
+    }
+}
+
+// ----------------------------------------------------------------------------- channel attention gate
+// grid = (pixel blocks, B).  Every workgroup recomputes the (tiny) squeeze MLP of its image from the
+// per-tile channel sums the producing conv wrote, then streams y -> y*s*y_scale + skip (+ skip2).
+template <typename T>
+SR_DEV f32x4 ld4(const void* p, size_t off, int dtype) {
+    return dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(p) + off) : load4(reinterpret_cast<const float*>(p) + off);
+}
+
+__global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
+    extern __shared__ float sm[];
+    float* mean = sm;           // [C]
+    float* hid = sm + a.C_p;    // [Cr]
+    float* gate = hid + a.Cr;   // [C_p]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float inv = 1.0f / (float)(a.H * a.W);
+    for (int c = tid; c < a.C_p; c += 256) {
+        float s = 0.f;
+        if (c < a.C)
+            for (int t = 0; t < a.n_tiles; ++t) s += a.pool_partial[((size_t)b * a.n_tiles + t) * a.C_p + c];
+        mean[c] = s * inv;
+    }
+    __syncthreads();
+    for (int j = tid; j < a.Cr; j += 256) {
+        float s = a.b1[j];
+        for (int c = 0; c < a.C; ++c) s += a.w1[j * a.C + c] * mean[c];
+        hid[j] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C_p; c += 256) {
+        float s = 0.f;
+        if (c < a.C) {
+            s = a.b2[c];
+            for (int j = 0; j < a.Cr; ++j) s += a.w2[c * a.Cr + j] * hid[j];
+            s = 1.0f / (1.0f + __expf(-s));
+        }
+        gate[c] = s * a.y_scale;
+    }
+    __syncthreads();
+    const int groups = a.C_p >> 2;
+    const long per_img = (long)a.H * a.W * groups;
+    for (long i = (long)blockIdx.x * 256 + tid; i < per_img; i += (long)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        const size_t off = (size_t)b * per_img * 4 + (size_t)i * 4;
+        f32x4 v = ld4<float>(a.y, off, a.y_dtype);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(gate + g * 4);
+        v *= s;
+        if (a.skip) v += ld4<float>(a.skip, off, a.skip_dtype);
+        if (a.skip2) v += ld4<float>(a.skip2, off, a.skip2_dtype);
+        if (a.out_dtype == SR_BF16)
+            store4(reinterpret_cast<bf16*>(a.out) + off, v);
+        else
+            store4(reinterpret_cast<float*>(a.out) + off, v);
+    }
+}
+
+int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int sr_ingest_nchw(const float* x, void* out, int out_dtype, int B, int C, int H, int W, int Hp, int Wp, int Cp, int pad_mode, const float* scale,
+                              const float* bias, void* stream) {
+    SR_REQUIRE(x && out && scale && bias, "sr_ingest_nchw: null pointer");
+    SR_REQUIRE(B > 0 && C > 0 && C <= Cp && Cp % 8 == 0 && Hp >= H && Wp >= W, "sr_ingest_nchw: bad geometry");
+    if (pad_mode == SR_PAD_EVAL_MIRROR) SR_REQUIRE(Hp <= 2 * H && Wp <= 2 * W, "sr_ingest_nchw: mirror pad larger than the image");
+    if (pad_mode == SR_PAD_REFLECT) SR_REQUIRE(Hp - H < H && Wp - W < W, "sr_ingest_nchw: reflect pad must be smaller than the image");
+    if (pad_mode == SR_PAD_NONE) SR_REQUIRE(Hp == H && Wp == W, "sr_ingest_nchw: SR_PAD_NONE with Hp != H");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)B * Hp * Wp * (Cp / 8);
+    if (out_dtype == SR_BF16)
+        hipLaunchKernelGGL(sr_ingest_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, x, reinterpret_cast<bf16*>(out), B, C, H, W, Hp, Wp, Cp, pad_mode,
+                           scale, bias);
+    else
+        hipLaunchKernelGGL(sr_ingest_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, reinterpret_cast<float*>(out), B, C, H, W, Hp, Wp, Cp, pad_mode,
+                           scale, bias);
+    SR_CHECK_LAUNCH("sr_ingest_nchw");
+    return SR_OK;
+}
+
+extern "C" int sr_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, int Cp, float eps, void* stream) {
+    SR_REQUIRE(x && y && gamma && beta, "sr_layernorm: null pointer");
+    SR_REQUIRE(M > 0 && C > 0 && C <= Cp && Cp % 8 == 0 && Cp <= 384, "sr_layernorm: bad geometry M=%d C=%d Cp=%d", M, C, Cp);
+    hipLaunchKernelGGL(sr_layernorm_kernel, dim3((M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, gamma, beta, M, C, Cp, eps);
+    SR_CHECK_LAUNCH("sr_layernorm");
+    return SR_OK;
+}
+
+extern "C" int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, int B, int C_out, int H, int W, int r, void* stream) {
+    SR_REQUIRE(in && out && B > 0 && C_out > 0 && H > 0 && W > 0 && r >= 1, "sr_pixel_shuffle_nchw: bad arguments");
+    SR_REQUIRE(elem_size == 2 || elem_size == 4, "sr_pixel_shuffle_nchw: elem_size %d", elem_size);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)B * C_out * H * r * W * r;
+    if (elem_size == 2)
+        hipLaunchKernelGGL(sr_pixel_shuffle_kernel<uint16_t>, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(in),
+                           reinterpret_cast<uint16_t*>(out), B, C_out, H, W, r);
+    else
+        hipLaunchKernelGGL(sr_pixel_shuffle_kernel<uint32_t>, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(in),
+                           reinterpret_cast<uint32_t*>(out), B, C_out, H, W, r);
+    SR_CHECK_LAUNCH("sr_pixel_shuffle_nchw");
+    return SR_OK;
+}
+
+extern "C" int sr_channel_attention(const SrChannelAttn* p, void* stream) {
+    SR_REQUIRE(p && p->y && p->pool_partial && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "sr_channel_attention: null pointer");
+    const SrChannelAttn& a = *p;
+    SR_REQUIRE(a.B > 0 && a.C > 0 && a.C <= a.C_p && a.C_p % 4 == 0 && a.Cr > 0 && a.n_tiles > 0, "sr_channel_attention: bad geometry");
+    const int lds = (2 * a.C_p + a.Cr) * (int)sizeof(float);
+    const long per_img = (long)a.H * a.W * (a.C_p / 4);
+    int gx = (int)((per_img + 255) / 256);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(sr_channel_attn_kernel, dim3(gx, a.B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    SR_CHECK_LAUNCH("sr_channel_attention");
+    return SR_OK;
+}

@@ -1,0 +1,30 @@
+// Host-side helpers shared by the C-ABI launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "../../include/studiosr_hip.h"
+
+void sr_set_error(const char* fmt, ...);
+
+#define SR_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            sr_set_error(__VA_ARGS__);        \
+            return SR_EINVAL;                 \
+        }                                     \
+    } while (0)
+
+#define SR_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            sr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return SR_ELAUNCH;                                                    \
+        }                                                                         \
+    } while (0)
+
+// Opt a kernel into more than 64 KiB of dynamic LDS (once per instantiation).
+template <typename K>
+static inline hipError_t sr_allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

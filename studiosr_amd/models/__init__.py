@@ -1,0 +1,7 @@
+"""studiosr.models-compatible classes whose forward() runs on the MI355X HIP kernels."""
+from .common import BaseModule, Model, Upsampler  # noqa: F401
+from .edsr import EDSR  # noqa: F401
+from .rcan import RCAN  # noqa: F401
+from .swinir import SwinIR  # noqa: F401
+
+__all__ = ["Model", "BaseModule", "Upsampler", "EDSR", "RCAN", "SwinIR"]

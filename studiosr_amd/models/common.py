@@ -1,0 +1,205 @@
+"""studiosr.models.common surface (reference: studiosr/models/common.py) on the HIP hot path.
+
+`Model` keeps the reference's public contract -- attributes scale / n_colors / img_range, `inference`,
+`inference_with_self_ensemble`, `get_model_config`, `get_training_config`, `from_pretrained`, `export`
+(common.py:29-98) -- while `forward` of every subclass runs hand-written HIP kernels through the C ABI.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops, packing
+from ..runtime import Workspace, compute_dtype, require_device, sr_dtype
+
+Tensor = torch.Tensor
+RGB_MEAN = (0.4488, 0.4371, 0.4040)  # common.py:112,223
+
+
+class Model(nn.Module):
+    """Base class (reference: studiosr/models/common.py:29-98)."""
+
+    def __init__(self, scale: int = 4, n_colors: int = 3, img_range: float = 1.0) -> None:
+        super().__init__()
+        self.scale: int = scale
+        self.n_colors: int = n_colors
+        self.img_range: float = img_range
+        # 'auto': bf16 under torch.autocast(bfloat16) (reference Trainer), fp32 otherwise (reference inference)
+        self.precision: str = "auto"
+        self._packed: Dict = {}
+        self._ws: Optional[Workspace] = None
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def set_precision(self, precision: str) -> "Model":
+        compute_dtype(precision)  # validates
+        self.precision = precision
+        return self
+
+    def _param_version(self) -> int:
+        return sum(p._version + (p.data_ptr() & 0xFFFF) for p in self.parameters())
+
+    def _get_packed(self, dt: torch.dtype) -> Dict:
+        """Fragment-ordered weights for compute dtype dt, rebuilt when a parameter changes."""
+        ver = self._param_version()
+        ent = self._packed.get(dt)
+        if ent is None or ent["__version__"] != ver:
+            with torch.no_grad():
+                ent = self._pack(dt)
+            ent["__version__"] = ver
+            self._packed[dt] = ent
+        return ent
+
+    def _pack(self, dt: torch.dtype) -> Dict:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _workspace(self, device: torch.device) -> Workspace:
+        if self._ws is None or self._ws.device != device:
+            self._ws = Workspace(device)
+        return self._ws
+
+    def _check_input(self, x: Tensor) -> Tensor:
+        require_device(x)
+        if x.dim() != 4 or x.shape[1] != self.n_colors:
+            raise RuntimeError(f"expected input [B,{self.n_colors},H,W], got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            raise NotImplementedError(
+                "studiosr_amd round 1 implements the inference forward only; call under torch.no_grad()/inference_mode() "
+                "(training backward is row (f)3 of SURVEY.md section 8)."
+            )
+        return x.detach().to(torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ reference API
+    @torch.inference_mode()
+    def inference(self, image: np.ndarray) -> np.ndarray:
+        """uint8 HWC -> uint8 HWC (studiosr/models/common.py:36-48): /scale, NCHW, forward, *scale,
+        round-half-even, clip, uint8; scale = 255 iff img_range == 1.0."""
+        self.eval()
+        scale = 255.0 if self.img_range == 1.0 else 1.0
+        device = next(self.parameters()).device
+        x = torch.from_numpy(image.astype(np.float32) / scale).to(device)
+        x = x.permute(2, 0, 1).unsqueeze(0).contiguous()
+        out = self.forward(x)[0].permute(1, 2, 0) * scale
+        return out.round().clip(0, 255).to(torch.uint8).cpu().numpy()
+
+    @torch.inference_mode()
+    def inference_with_self_ensemble(self, image: np.ndarray) -> np.ndarray:
+        """8 rot/flip variants averaged (studiosr/models/common.py:10-26,50-67).  Variants of equal shape are
+        batched into one forward (the reference runs 8 sequential forwards; results are identical because
+        batch items are independent)."""
+        self.eval()
+        scale = 255.0 if self.img_range == 1.0 else 1.0
+        device = next(self.parameters()).device
+        img = torch.from_numpy(image.astype(np.float32) / scale).to(device)
+        variants = []
+        for k in range(4):
+            r = torch.rot90(img, k, dims=[0, 1])
+            variants += [r, torch.fliplr(r)]
+        outs: List[Optional[Tensor]] = [None] * 8
+        groups: Dict = {}
+        for i, v in enumerate(variants):
+            groups.setdefault(tuple(v.shape), []).append(i)
+        for idxs in groups.values():
+            xb = torch.stack([variants[i].permute(2, 0, 1) for i in idxs]).contiguous()
+            yb = self.forward(xb)
+            for j, i in enumerate(idxs):
+                outs[i] = yb[j].permute(1, 2, 0)
+        merged = []
+        for i, o in enumerate(outs):
+            o = torch.fliplr(o) if i & 1 else o
+            merged.append(torch.rot90(o, i // 2, dims=[1, 0]))
+        out = torch.stack(merged).mean(dim=0) * scale
+        return out.round().clip(0, 255).to(torch.uint8).cpu().numpy()
+
+    def get_model_config(self) -> Dict:
+        return dict(scale=self.scale, n_colors=self.n_colors, img_range=self.img_range)
+
+    def get_training_config(self) -> Dict:
+        return dict()
+
+    @classmethod
+    def from_pretrained(cls, scale: int = 4) -> "Model":
+        return cls(scale=scale)
+
+    def export(self, path: Optional[str] = None, input_shape: List[int] = [1, 3, 256, 256], format: str = "onnx") -> str:
+        """Reference: common.py:86-98 (torch.onnx.export).  The HIP forward is not traceable to ONNX."""
+        raise NotImplementedError("ONNX export is outside the MI355X hot path (SURVEY.md section 8b item 7)")
+
+
+BaseModule = Model
+
+
+def conv2d(in_channels: int, out_channels: int, kernel_size: int) -> nn.Conv2d:
+    """Parameter container with the reference's shapes/init (common.py:104-105)."""
+    return nn.Conv2d(in_channels, out_channels, kernel_size, padding=kernel_size // 2)
+
+
+class Upsampler(nn.Sequential):
+    """Parameter container for the conv->PixelShuffle chain (common.py:124-137); state_dict keys
+    `0.weight`, `2.weight`, ... as in the reference.  Executed by `run_upsampler`."""
+
+    def __init__(self, scale: int, n_feats: int, num_out_ch: Optional[int] = None) -> None:
+        m: List[nn.Module] = []
+        self.stages: List = []
+        if num_out_ch is not None:
+            m += [conv2d(n_feats, scale * scale * num_out_ch, 3), nn.PixelShuffle(scale)]
+            stages = [(0, scale, num_out_ch)]
+        elif (scale & (scale - 1)) == 0:
+            stages = []
+            for i in range(int(round(np.log2(scale)))):
+                m += [conv2d(n_feats, 4 * n_feats, 3), nn.PixelShuffle(2)]
+                stages.append((2 * i, 2, n_feats))
+        else:
+            m += [conv2d(n_feats, scale * scale * n_feats, 3), nn.PixelShuffle(scale)]
+            stages = [(0, scale, n_feats)]
+        super().__init__(*m)
+        self.stages = stages  # (index of conv in the Sequential, r, channels after the shuffle)
+
+
+def pack_upsampler(up: Upsampler, cin_p: int, dt: torch.dtype, last_cps_p: Optional[int] = None):
+    """[(Wp, bias, r, cps_p)] for every conv+PixelShuffle stage; weight rows permuted so that the conv
+    epilogue can store straight through the shuffle."""
+    out = []
+    for si, (idx, r, c_ps) in enumerate(up.stages):
+        conv = up[idx]
+        cps_p = packing.round_up(c_ps, 32)
+        if last_cps_p is not None and si == len(up.stages) - 1:
+            cps_p = last_cps_p
+        rows = packing.pixel_shuffle_rows(c_ps, cps_p, r)
+        wp, b = packing.pack_conv3x3(conv.weight, conv.bias, cin_p, rows, dt)
+        out.append((wp, b, r, cps_p))
+        cin_p = cps_p
+    return out
+
+
+def conv_call(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, cdt: torch.dtype, *, act: int = L.ACT_NONE,
+              out_scale: float = 1.0, skip: Optional[Tensor] = None, out_mode: int = L.OUT_NHWC, ps_r: int = 0, cps_p: int = 0,
+              pool: Optional[Tensor] = None, fin=None, cout_p: Optional[int] = None) -> Tensor:
+    """One sr_conv3x3 launch on NHWC tensors (shapes are taken from the tensors)."""
+    B, H, W, cin_p = x.shape
+    if cout_p is None:
+        cout_p = out.shape[-1] if out_mode == L.OUT_NHWC else ps_r * ps_r * cps_p
+    kw = dict(
+        x=x.data_ptr(), Wp=wp.data_ptr(), bias=None if bias is None else bias.data_ptr(), out=out.data_ptr(),
+        skip=None if skip is None else skip.data_ptr(), pool_partial=None if pool is None else pool.data_ptr(),
+        B=B, H=H, W=W, Cin_p=cin_p, Cout_p=cout_p,
+        x_dtype=sr_dtype(x.dtype), out_dtype=sr_dtype(out.dtype), skip_dtype=sr_dtype(skip.dtype) if skip is not None else 0,
+        compute_dtype=sr_dtype(cdt), act=act, out_scale=out_scale, out_mode=out_mode, ps_r=ps_r, cps_p=cps_p,
+    )
+    if fin is not None:
+        fscale, fbias, fc, fh, fw = fin
+        kw.update(fin_scale=fscale.data_ptr(), fin_bias=fbias.data_ptr(), fin_c=fc, fin_h=fh, fin_w=fw)
+    ops.conv3x3(**kw)
+    return out
+
+
+def run_upsampler(packed, x: Tensor, ws: Workspace, cdt: torch.dtype, name: str) -> Tensor:
+    for si, (wp, b, r, cps_p) in enumerate(packed):
+        B, H, W, _ = x.shape
+        out = ws.get(f"{name}.up{si}", (B, H * r, W * r, cps_p), cdt)
+        conv_call(x, wp, b, out, cdt, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=r, cps_p=cps_p)
+        x = out
+    return x

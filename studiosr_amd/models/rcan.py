@@ -1,0 +1,149 @@
+"""RCAN on the MI355X HIP hot path (reference: studiosr/models/rcan.py).
+
+Per RCAB (rcan.py:11-24): conv+ReLU -> conv (its epilogue also emits per-tile channel sums) ->
+channel-attention gate kernel: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid -> y*s + x (common.py:156-170).
+Per ResidualGroup (:27-36): 20 RCABs + conv + skip.  Head / tail as EDSR.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops, packing
+from ..runtime import compute_dtype, sr_dtype
+from .common import Model, Upsampler, conv2d, conv_call, pack_upsampler, run_upsampler
+from .edsr import MeanShift, mean_shift_affine
+
+Tensor = torch.Tensor
+
+
+class ChannelAttention(nn.Module):
+    """Parameters of common.py:156-165 (keys conv_du.0 / conv_du.2)."""
+
+    def __init__(self, channel: int, reduction: int = 16) -> None:
+        super().__init__()
+        self.conv_du = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1), nn.ReLU(True), nn.Conv2d(channel // reduction, channel, 1), nn.Sigmoid())
+
+
+class RCAB(nn.Module):
+    def __init__(self, n_feat: int, kernel_size: int, reduction: int) -> None:
+        super().__init__()
+        self.body = nn.Sequential(conv2d(n_feat, n_feat, kernel_size), nn.ReLU(True), conv2d(n_feat, n_feat, kernel_size), ChannelAttention(n_feat, reduction))
+
+
+class ResidualGroup(nn.Module):
+    def __init__(self, n_feat: int, kernel_size: int, reduction: int, n_resblocks: int) -> None:
+        super().__init__()
+        self.body = nn.Sequential(*[RCAB(n_feat, kernel_size, reduction) for _ in range(n_resblocks)], conv2d(n_feat, n_feat, kernel_size))
+
+
+def pack_ca(w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
+    f = lambda t: t.detach().to(torch.float32).reshape(t.shape[0], -1).contiguous()  # noqa: E731
+    return f(w1), b1.detach().float().contiguous(), f(w2), b2.detach().float().contiguous()
+
+
+def run_channel_attention(ca, y: Tensor, pool: Tensor, n_tiles: int, C: int, out: Tensor, skip=None, skip2=None, y_scale: float = 1.0) -> None:
+    w1, b1, w2, b2 = ca
+    B, H, W, Cp = y.shape
+    ops.channel_attention(
+        y=y.data_ptr(), pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(),
+        skip=None if skip is None else skip.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, C=C, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles,
+        y_dtype=sr_dtype(y.dtype), skip_dtype=sr_dtype(skip.dtype) if skip is not None else 0, out_dtype=sr_dtype(out.dtype), y_scale=y_scale,
+        skip2=None if skip2 is None else skip2.data_ptr(), skip2_dtype=sr_dtype(skip2.dtype) if skip2 is not None else 0,
+    )
+
+
+class RCAN(Model):
+    def __init__(self, scale: int = 4, n_colors: int = 3, img_range: float = 1.0, n_feats: int = 64, n_resblocks: int = 20,
+                 n_resgroups: int = 10, reduction: int = 16) -> None:
+        super().__init__(scale, n_colors, img_range)
+        self.n_feats, self.n_resblocks, self.n_resgroups, self.reduction = n_feats, n_resblocks, n_resgroups, reduction
+        self.sub_mean = MeanShift(img_range)
+        self.add_mean = MeanShift(img_range, sign=1)
+        k = 3
+        self.head = nn.Sequential(conv2d(n_colors, n_feats, k))
+        self.body = nn.Sequential(*[ResidualGroup(n_feats, k, reduction, n_resblocks) for _ in range(n_resgroups)], conv2d(n_feats, n_feats, k))
+        self.tail = nn.Sequential(Upsampler(scale, n_feats), conv2d(n_feats, n_colors, k))
+
+    def _pack(self, dt: torch.dtype) -> Dict:
+        F = self.n_feats
+        Fp = packing.round_up(F, 32)
+        ident = packing.identity_idx(F, Fp)
+        pc = lambda m, cin_p=Fp: packing.pack_conv3x3(m.weight, m.bias, cin_p, ident, dt)  # noqa: E731
+        P: Dict = {"Fp": Fp, "ing": mean_shift_affine(self.sub_mean), "fin": mean_shift_affine(self.add_mean)}
+        P["head"] = pc(self.head[0], 32)
+        P["groups"] = []
+        for gi in range(self.n_resgroups):
+            grp = self.body[gi]
+            blocks = []
+            for bi in range(self.n_resblocks):
+                b = grp.body[bi].body
+                du = b[3].conv_du
+                blocks.append((pc(b[0]), pc(b[2]), pack_ca(du[0].weight, du[0].bias, du[2].weight, du[2].bias)))
+            P["groups"].append((blocks, pc(grp.body[self.n_resblocks])))
+        P["body_last"] = pc(self.body[self.n_resgroups])
+        P["up"] = pack_upsampler(self.tail[0], Fp, dt)
+        P["tail"] = packing.pack_conv3x3(self.tail[1].weight, self.tail[1].bias, P["up"][-1][3], packing.identity_idx(self.n_colors, 16), dt)
+        return P
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self._check_input(x)
+        cdt = compute_dtype(self.precision)
+        P = self._get_packed(cdt)
+        ws_ = self._workspace(x.device)
+        B, _, H, W = x.shape
+        Fp = P["Fp"]
+        f32 = torch.float32
+        xin = ws_.get("xin", (B, H, W, 32), cdt)
+        ops.ingest_nchw(x, xin, L.PAD_NONE, *P["ing"])
+        h = ws_.get("head", (B, H, W, Fp), f32)
+        conv_call(xin, *P["head"], h, cdt)
+        n_tiles = ops.conv_pool_tiles(H, W, Fp, sr_dtype(cdt))
+        pool = ws_.get("pool", (B, n_tiles, Fp), f32)
+        mid = ws_.get("mid", (B, H, W, Fp), cdt)
+        y = ws_.get("y", (B, H, W, Fp), f32)
+        ga, gb = ws_.get("ga", (B, H, W, Fp), f32), ws_.get("gb", (B, H, W, Fp), f32)
+        ra, rb = ws_.get("ra", (B, H, W, Fp), f32), ws_.get("rb", (B, H, W, Fp), f32)
+        g = h
+        for blocks, gconv in P["groups"]:
+            r = g
+            for (c1, c2, ca) in blocks:  # RCAB: r = CA(conv2(relu(conv1(r)))) + r
+                conv_call(r, *c1, mid, cdt, act=L.ACT_RELU)
+                conv_call(mid, *c2, y, cdt, pool=pool)
+                nxt = ra if (r is not ra) else rb
+                run_channel_attention(ca, y, pool, n_tiles, self.n_feats, nxt, skip=r)
+                r = nxt
+            gn = ga if (g is not ga) else gb
+            conv_call(r, *gconv, gn, cdt, skip=g)  # group conv + skip (rcan.py:33-36)
+            g = gn
+        res = ws_.get("res", (B, H, W, Fp), cdt)
+        conv_call(g, *P["body_last"], res, cdt, skip=h)
+        up = run_upsampler(P["up"], res, ws_, cdt, "rcan")
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=f32, device=x.device)
+        conv_call(up, *P["tail"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(*P["fin"], self.n_colors, H * s, W * s), cout_p=16)
+        return out
+
+    def get_model_config(self) -> Dict:
+        config = super().get_model_config()
+        config.update(dict(scale=self.scale, n_colors=self.n_colors, img_range=self.img_range, n_feats=self.n_feats,
+                           n_resblocks=self.n_resblocks, n_resgroups=self.n_resgroups, reduction=self.reduction))
+        return config
+
+    def get_training_config(self) -> Dict:  # rcan.py:93-104
+        return dict(batch_size=16, learning_rate=0.0001, beta1=0.9, beta2=0.99, weight_decay=0.0, max_iters=1000000, gamma=0.5,
+                    milestones=[200000, 400000, 600000, 800000])
+
+    @classmethod
+    def from_pretrained(cls, scale: int = 4) -> "RCAN":
+        """rcan.py:107-119: RCAN_BIX{scale}.pt with img_range 255, read from ./pretrained (no network here)."""
+        path = os.path.join("pretrained", "models_ECCV2018RCAN", f"RCAN_BIX{scale}.pt")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found (no network access here; place the official checkpoint there)")
+        model = cls(scale=scale, img_range=255.0)
+        model.load_state_dict(torch.load(path, map_location="cpu"), False)
+        return model

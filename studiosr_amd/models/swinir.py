@@ -1,0 +1,388 @@
+"""SwinIR on the MI355X HIP hot path (reference: studiosr/models/swinir.py).
+
+Same constructor kwargs, attributes, `state_dict` keys/shapes (official checkpoints load unchanged) and
+`get_model_config` / `get_training_config` / `from_pretrained` surface as the reference class.  `forward`
+is not a torch graph: it is a fixed sequence of C-ABI launches over NHWC buffers
+(2 + 4 per block + 1 per RSTB + 6 kernels):
+
+  ingest (pad + normalise, swinir.py:249-255,356-359)  -> conv_first (:361)  -> LayerNorm (:28-32)
+  per block (:146-174):  [LN1 + QKV GEMM, rows gathered through roll+partition] -> window attention
+                         -> [proj GEMM + residual, rows scattered through reverse+roll]
+                         -> [LN2 + fc1 GEMM + GELU] -> [fc2 GEMM + residual]
+  per RSTB (:245-246):   conv3x3 + residual
+  LayerNorm (:349) -> conv_after_body + long skip (:362) -> conv_before_upsample + LeakyReLU (:365)
+  -> Upsampler convs storing through PixelShuffle (:366) -> conv_last + unnormalise + crop to NCHW (:366-372)
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops, packing
+from ..runtime import compute_dtype, sr_dtype
+from .common import RGB_MEAN, Model, Upsampler, conv_call, pack_upsampler, run_upsampler
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- parameter containers
+class WindowAttention(nn.Module):
+    """Parameters of swinir.py:35-76 (qkv, proj, bias table, index buffer)."""
+
+    def __init__(self, dim: int, window_size: int, num_heads: int) -> None:
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        ws = window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        ys, xs = torch.div(torch.arange(ws * ws), ws, rounding_mode="floor"), torch.arange(ws * ws) % ws
+        rpi = (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
+        self.register_buffer("relative_position_index", rpi)  # swinir.py:56-67
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class MlpParams(nn.Module):
+    """common.py:173-187."""
+
+    def __init__(self, dim: int, hidden: int) -> None:
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class SwinTransformerBlock(nn.Module):
+    """Parameters of swinir.py:108-144."""
+
+    def __init__(self, dim: int, num_heads: int, window_size: int, shift_size: int, mlp_ratio: float) -> None:
+        super().__init__()
+        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        self.shift_size = shift_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MlpParams(dim, int(dim * mlp_ratio))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim: int, depth: int, num_heads: int, window_size: int, mlp_ratio: float) -> None:
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            [SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio) for i in range(depth)]
+        )
+
+
+class RSTB(nn.Module):
+    """swinir.py:216-246."""
+
+    def __init__(self, dim: int, depth: int, num_heads: int, window_size: int, mlp_ratio: float) -> None:
+        super().__init__()
+        self.residual_group = BasicLayer(dim, depth, num_heads, window_size, mlp_ratio)
+        self.conv = nn.Conv2d(dim, dim, 3, 1, 1)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, embed_dim: int) -> None:
+        super().__init__()
+        self.norm = nn.LayerNorm(embed_dim)
+
+
+# --------------------------------------------------------------------------- shared transformer pieces
+class SwinGeometry:
+    """Padded sizes shared by SwinIR and HAT."""
+
+    def __init__(self, C: int, heads: int, ws: int, hidden: int) -> None:
+        self.C, self.heads, self.ws, self.hidden = C, heads, ws, hidden
+        self.Cp = packing.round_up(C, 64)
+        self.hd = C // heads
+        self.hd_p = packing.round_up(self.hd, 32)
+        if (heads * self.hd_p) % 64:
+            self.hd_p = packing.round_up(self.hd, 64)
+        self.HP = heads * self.hd_p
+        self.hid_p = packing.round_up(hidden, 64)
+        self.ntok = ws * ws
+
+
+def pack_ln(norm: nn.LayerNorm, n_pad: int):
+    return packing.pad_vec(norm.weight, n_pad).contiguous(), packing.pad_vec(norm.bias, n_pad).contiguous()
+
+
+def pack_attention(attn: nn.Module, geo: SwinGeometry, dt: torch.dtype, rpi: Optional[Tensor] = None) -> Dict:
+    C, Cp, heads, hd_p = geo.C, geo.Cp, geo.heads, geo.hd_p
+    qkv_w, qkv_b = packing.pack_qkv(attn.qkv.weight, attn.qkv.bias, C, Cp, heads, hd_p, dt)
+    proj_w, proj_b = packing.pack_linear(attn.proj.weight, attn.proj.bias, packing.identity_idx(C, Cp), packing.head_idx(heads, geo.hd, hd_p), dt)
+    rpi = attn.relative_position_index if rpi is None else rpi
+    bias = packing.gather_bias(attn.relative_position_bias_table, rpi, geo.ntok, geo.ntok)
+    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, bias=bias)
+
+
+def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
+    fc1_w, fc1_b = packing.pack_linear(mlp.fc1.weight, mlp.fc1.bias, packing.identity_idx(geo.hidden, geo.hid_p), packing.identity_idx(geo.C, geo.Cp), dt)
+    fc2_w, fc2_b = packing.pack_linear(mlp.fc2.weight, mlp.fc2.bias, packing.identity_idx(geo.C, geo.Cp), packing.identity_idx(geo.hidden, geo.hid_p), dt)
+    return dict(fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b)
+
+
+def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa") -> None:
+    """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
+    t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip)."""
+    B, H, W, Cp = t_in.shape
+    M = B * H * W
+    nb = M // geo.ntok
+    sdt = sr_dtype(cdt)
+    q = ws_.get(name + ".q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
+    k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
+    vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
+    o = ws_.get(name + ".o", (M, geo.HP), cdt)
+    ops.gemm(
+        A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=ln[0].data_ptr(), ln_beta=ln[1].data_ptr(),
+        out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
+        a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
+        H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5,
+    )
+    ops.window_attention(
+        q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
+        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt,
+    )
+    ops.gemm(
+        A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
+        M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,
+        out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_STD,
+    )
+
+
+def run_mlp(p: Dict, ln, geo: SwinGeometry, t: Tensor, ws_, cdt: torch.dtype, name: str = "mlp") -> None:
+    """t += fc2(GELU(fc1(LN(t))))  in place on the fp32 stream [.., Cp]."""
+    Cp = t.shape[-1]
+    M = t.numel() // Cp
+    sdt = sr_dtype(cdt)
+    h = ws_.get(name + ".h", (M, geo.hid_p), cdt)
+    ops.gemm(
+        A=t.data_ptr(), Wp=p["fc1_w"].data_ptr(), bias=p["fc1_b"].data_ptr(), ln_gamma=ln[0].data_ptr(), ln_beta=ln[1].data_ptr(),
+        out=h.data_ptr(), M=M, K=Cp, N=geo.hid_p, k_real=geo.C, lda=Cp, ldo=geo.hid_p, a_dtype=L.SR_F32, out_dtype=sdt,
+        compute_dtype=sdt, act=L.ACT_GELU, out_scale=1.0, epi=L.EPI_STD, ln_eps=1e-5,
+    )
+    ops.gemm(
+        A=h.data_ptr(), Wp=p["fc2_w"].data_ptr(), bias=p["fc2_b"].data_ptr(), out=t.data_ptr(), skip=t.data_ptr(), M=M, K=geo.hid_p,
+        N=Cp, lda=geo.hid_p, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
+        epi=L.EPI_STD,
+    )
+
+
+def final_affine(img_range: float, n_colors: int, device) -> tuple:
+    """Normalizer.unnormalize (common.py:232-233): (x + mean) * range = x*range + mean*range."""
+    mean = torch.tensor(RGB_MEAN[:n_colors], dtype=torch.float32, device=device)
+    return torch.full((n_colors,), float(img_range), dtype=torch.float32, device=device), (mean * img_range).contiguous()
+
+
+def ingest_affine(img_range: float, n_colors: int, device) -> tuple:
+    """Normalizer.normalize (common.py:228-230): x / range - mean."""
+    mean = torch.tensor(RGB_MEAN[:n_colors], dtype=torch.float32, device=device)
+    return torch.full((n_colors,), 1.0 / float(img_range), dtype=torch.float32, device=device), (-mean).contiguous()
+
+
+def direct_cps_p(c_ps: int, r: int) -> int:
+    cps = packing.round_up(c_ps, 4)
+    while (r * r * cps) % 16:
+        cps += 4
+    return cps
+
+
+# --------------------------------------------------------------------------- the model
+class SwinIR(Model):
+    def __init__(
+        self,
+        scale: int = 4,
+        n_colors: int = 3,
+        img_range: float = 1.0,
+        embed_dim: int = 180,
+        depths: List[int] = [6, 6, 6, 6, 6, 6],
+        num_heads: List[int] = [6, 6, 6, 6, 6, 6],
+        window_size: int = 8,
+        mlp_ratio: float = 2.0,
+        drop_rate: float = 0.0,
+        attn_drop_rate: float = 0.0,
+        drop_path_rate: float = 0.1,
+        upsampler: str = "pixelshuffle",
+        resi_connection: Optional[nn.Module] = None,
+    ) -> None:
+        super().__init__(scale, n_colors, img_range)
+        if resi_connection is not None:
+            raise NotImplementedError("custom resi_connection modules are outside the HIP hot path")
+        assert n_colors == 3, "Normalizer mean has 3 channels (common.py:223)"
+        self.embed_dim = embed_dim
+        self.depths = depths
+        self.num_heads = num_heads
+        self.window_size = window_size
+        self.mlp_ratio = mlp_ratio
+        self.drop_rate = drop_rate
+        self.attn_drop_rate = attn_drop_rate
+        self.drop_path_rate = drop_path_rate
+        self.upsampler = upsampler
+
+        self.conv_first = nn.Conv2d(n_colors, embed_dim, 3, 1, 1)
+        self.patch_embed = PatchEmbed(embed_dim)
+        self.layers = nn.ModuleList([RSTB(embed_dim, depths[i], num_heads[i], window_size, mlp_ratio) for i in range(len(depths))])
+        self.norm = nn.LayerNorm(embed_dim)
+        self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
+        if upsampler == "pixelshuffle":
+            num_feat = 64
+            self.conv_before_upsample = nn.Sequential(nn.Conv2d(embed_dim, num_feat, 3, 1, 1), nn.LeakyReLU(inplace=True))
+            self.upsample = Upsampler(scale, num_feat)
+            self.conv_last = nn.Conv2d(num_feat, n_colors, 3, 1, 1)
+        elif upsampler == "pixelshuffledirect":
+            self.upsample = Upsampler(scale, embed_dim, n_colors)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m: nn.Module) -> None:  # swinir.py:333-340
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ packing
+    def _geo(self, li: int) -> SwinGeometry:
+        return SwinGeometry(self.embed_dim, self.num_heads[li], self.window_size, int(self.embed_dim * self.mlp_ratio))
+
+    def _pack(self, dt: torch.dtype) -> Dict:
+        C = self.embed_dim
+        geo0 = self._geo(0)
+        Cp = geo0.Cp
+        dev = self.conv_first.weight.device
+        P: Dict = {}
+        P["first"] = packing.pack_conv3x3(self.conv_first.weight, self.conv_first.bias, 32, packing.identity_idx(C, Cp), dt)
+        P["pe_norm"] = pack_ln(self.patch_embed.norm, Cp)
+        P["layers"] = []
+        for li, layer in enumerate(self.layers):
+            geo = self._geo(li)
+            blocks = []
+            for blk in layer.residual_group.blocks:
+                e = dict(shift=blk.shift_size, ln1=pack_ln(blk.norm1, Cp), ln2=pack_ln(blk.norm2, Cp))
+                e.update(pack_attention(blk.attn, geo, dt))
+                e.update(pack_mlp(blk.mlp, geo, dt))
+                blocks.append(e)
+            conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, packing.identity_idx(C, Cp), dt)
+            P["layers"].append(dict(blocks=blocks, conv=conv, geo=geo))
+        P["norm"] = pack_ln(self.norm, Cp)
+        P["after_body"] = packing.pack_conv3x3(self.conv_after_body.weight, self.conv_after_body.bias, Cp, packing.identity_idx(C, Cp), dt)
+        P["fin"] = final_affine(self.img_range, self.n_colors, dev)
+        P["ing"] = ingest_affine(self.img_range, self.n_colors, dev)
+        if self.upsampler == "pixelshuffle":
+            cbu = self.conv_before_upsample[0]
+            P["before_up"] = packing.pack_conv3x3(cbu.weight, cbu.bias, Cp, packing.identity_idx(64, 64), dt)
+            P["up"] = pack_upsampler(self.upsample, 64, dt)
+            P["last"] = packing.pack_conv3x3(self.conv_last.weight, self.conv_last.bias, 64, packing.identity_idx(self.n_colors, 16), dt)
+        elif self.upsampler == "pixelshuffledirect":
+            P["up"] = pack_upsampler(self.upsample, Cp, dt, last_cps_p=direct_cps_p(self.n_colors, self.scale))
+        return P
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor) -> Tensor:
+        x = self._check_input(x)
+        cdt = compute_dtype(self.precision)
+        P = self._get_packed(cdt)
+        ws_ = self._workspace(x.device)
+        B, _, H, W = x.shape
+        w8 = self.window_size
+        if self.training:  # check_image_size: reflect pad to the next multiple (swinir.py:356, common.py:277-282)
+            Hp, Wp, pad_mode = H + (w8 - H % w8) % w8, W + (w8 - W % w8) % w8, L.PAD_REFLECT
+            if Hp - H >= H or Wp - W >= W:
+                raise RuntimeError("Padding size should be less than the corresponding input dimension (reflect pad)")
+        else:  # check_image_size_for_eval: always adds 1..ws rows/cols (swinir.py:249-255)
+            Hp, Wp, pad_mode = (H // w8 + 1) * w8, (W // w8 + 1) * w8, L.PAD_EVAL_MIRROR
+        Cp = P["layers"][0]["geo"].Cp if P["layers"] else packing.round_up(self.embed_dim, 64)
+
+        xin = ws_.get("xin", (B, Hp, Wp, 32), cdt)
+        ops.ingest_nchw(x, xin, pad_mode, *P["ing"])
+        first = ws_.get("first", (B, Hp, Wp, Cp), torch.float32)
+        conv_call(xin, *P["first"], first, cdt)
+        ta = ws_.get("ta", (B, Hp, Wp, Cp), torch.float32)
+        tb = ws_.get("tb", (B, Hp, Wp, Cp), torch.float32)
+        ops.layernorm(first, ta, *P["pe_norm"], self.embed_dim)
+
+        for lp in P["layers"]:
+            geo = lp["geo"]
+            cur = ta  # RSTB input stays in ta until the closing conv has consumed it as the skip
+            for bp in lp["blocks"]:
+                run_window_msa(bp, bp["ln1"], geo, cur, tb, cur, ws_, cdt, bp["shift"])
+                run_mlp(bp, bp["ln2"], geo, tb, ws_, cdt)
+                cur = tb
+            # ta = conv(cur) + ta   (swinir.py:245-246).  Within an RSTB the first block reads `ta` and
+            # writes `tb`; later blocks work in place on `tb`; a zero-depth RSTB convolves `ta` itself.
+            if cur is ta:
+                cur = ws_.get("tc", (B, Hp, Wp, Cp), torch.float32)
+                cur.copy_(ta)
+            conv_call(cur, *lp["conv"], ta, cdt, skip=ta)
+        ops.layernorm(ta, tb, *P["norm"], self.embed_dim)
+        body = ws_.get("body", (B, Hp, Wp, Cp), cdt)
+        conv_call(tb, *P["after_body"], body, cdt, skip=first)  # conv_after_body(features) + x  (swinir.py:362)
+
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
+        fin = (*P["fin"], self.n_colors, H * s, W * s)
+        if self.upsampler == "pixelshuffle":
+            feat = ws_.get("feat", (B, Hp, Wp, 64), cdt)
+            conv_call(body, *P["before_up"], feat, cdt, act=L.ACT_LRELU)
+            up = run_upsampler(P["up"], feat, ws_, cdt, "swin")
+            conv_call(up, *P["last"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=fin, cout_p=16)
+        else:
+            wp, b, r, cps_p = P["up"][0]
+            conv_call(body, wp, b, out, cdt, out_mode=L.OUT_FINAL_NCHW, ps_r=r, cps_p=cps_p, fin=fin, cout_p=r * r * cps_p)
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def get_model_config(self) -> Dict:
+        config = super().get_model_config()
+        config.update(
+            dict(
+                embed_dim=self.embed_dim,
+                depths=self.depths,
+                num_heads=self.num_heads,
+                window_size=self.window_size,
+                mlp_ratio=self.mlp_ratio,
+                drop_rate=self.drop_rate,
+                attn_drop_rate=self.attn_drop_rate,
+                drop_path_rate=self.drop_path_rate,
+                upsampler=self.upsampler,
+            )
+        )
+        return config
+
+    def get_training_config(self) -> Dict:  # swinir.py:391-402
+        return dict(
+            batch_size=32,
+            learning_rate=0.0002,
+            beta1=0.9,
+            beta2=0.99,
+            weight_decay=0.0,
+            max_iters=500000,
+            gamma=0.5,
+            milestones=[250000, 400000, 450000, 475000],
+        )
+
+    @classmethod
+    def from_pretrained(cls, scale: int = 4, light: bool = False, dataset: str = "DF2K", pretrained: bool = True) -> "SwinIR":
+        """Same configurations and checkpoint file names as swinir.py:404-445; weights are read from
+        ./pretrained/<file> (the GPU box has no network, so a missing file is an error, not a download)."""
+        assert scale in [2, 3, 4, 8]
+        assert dataset in ["DIV2K", "DF2K"]
+        config: Dict = {"scale": scale}
+        img_size = 64 if dataset == "DF2K" else 48
+        task, label = "001_classicalSR", "M"
+        if light:
+            config.update(depths=[6, 6, 6, 6], embed_dim=60, num_heads=[6, 6, 6, 6], upsampler="pixelshuffledirect")
+            task, dataset, img_size, label = "002_lightweightSR", "DIV2K", 64, "S"
+        model = cls(**config)
+        if pretrained:
+            path = os.path.join("pretrained", f"{task}_{dataset}_s{img_size}w8_SwinIR-{label}_x{scale}.pth")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found (no network access here; place the official checkpoint there)")
+            ckpt = torch.load(path, map_location="cpu")
+            model.load_state_dict(ckpt["params"] if "params" in ckpt else ckpt, strict=False)
+        return model

@@ -1,0 +1,89 @@
+"""Python faces of the C-ABI entry points (tensor -> raw pointers).  No math happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.SR_F32
+    if t.dtype == torch.bfloat16:
+        return L.SR_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.HipLibraryError("studiosr_amd ops need ROCm device tensors (there is no CPU path)")
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ingest_nchw(x: Tensor, out: Tensor, pad_mode: int, scale: Tensor, bias: Tensor) -> Tensor:
+    B, Cc, H, W = x.shape
+    _, Hp, Wp, Cp = out.shape
+    assert x.dtype == torch.float32
+    L.check(L.lib().sr_ingest_nchw(_p(x), _p(out), _dt(out), B, Cc, H, W, Hp, Wp, Cp, pad_mode, _p(scale), _p(bias), _stream()), "sr_ingest_nchw")
+    return out
+
+
+def layernorm(x: Tensor, out: Tensor, gamma: Tensor, beta: Tensor, C_real: int, eps: float = 1e-5) -> Tensor:
+    Cp = x.shape[-1]
+    M = x.numel() // Cp
+    L.check(L.lib().sr_layernorm(_p(x), _p(out), _p(gamma), _p(beta), M, C_real, Cp, eps, _stream()), "sr_layernorm")
+    return out
+
+
+def gemm(**kw) -> None:
+    g = L.SrGemm()
+    for k, v in kw.items():
+        setattr(g, k, v)
+    L.check(L.lib().sr_gemm(C.byref(g), _stream()), "sr_gemm")
+
+
+def conv3x3(**kw) -> None:
+    c = L.SrConv3x3()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    L.check(L.lib().sr_conv3x3(C.byref(c), _stream()), "sr_conv3x3")
+
+
+def window_attention(**kw) -> None:
+    a = L.SrWindowAttn()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_window_attention(C.byref(a), _stream()), "sr_window_attention")
+
+
+def channel_attention(**kw) -> None:
+    a = L.SrChannelAttn()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_channel_attention(C.byref(a), _stream()), "sr_channel_attention")
+
+
+def pixel_shuffle(x: Tensor, r: int) -> Tensor:
+    """nn.PixelShuffle(r) on an NCHW device tensor (bit-exact copy kernel)."""
+    B, Cin, H, W = x.shape
+    assert Cin % (r * r) == 0 and x.element_size() in (2, 4)
+    x = x.contiguous()
+    out = torch.empty(B, Cin // (r * r), H * r, W * r, dtype=x.dtype, device=x.device)
+    L.check(L.lib().sr_pixel_shuffle_nchw(_p(x), _p(out), x.element_size(), B, Cin // (r * r), H, W, r, _stream()), "sr_pixel_shuffle_nchw")
+    return out
+
+
+def conv_pool_tiles(H: int, W: int, cout_p: int, compute_dtype: int) -> int:
+    return L.lib().sr_conv3x3_pool_tiles(H, W, cout_p, compute_dtype)
