@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HR megapixels / second of SwinIR x4 on 64x64 LR tiles (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one eval-mode forward of the default SwinIR x4 (embed 180, 6x6 blocks, window 8) over one
+batch of 8 synthetic 64x64 LR tiles (BASELINE.json configs[2]), bf16 operands / fp32 accumulate, inputs
+resident in HBM, whole forward replayed from one HIP graph.  With N > 1 (launched by torch.distributed.run,
+one rank per GPU) every rank processes its own batch of 8 tiles -- tiles are independent, so there is no
+data-path collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
+
+The JSON line also carries
+  roofline      dominant kernel (the LayerNorm+GEMM row kernel `sr_gemm_kernel`) vs the bf16 MFMA peak,
+                timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
+  cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this
+                host's cores on a bounded sample of the same workload.
+  parity        PSNR of the HIP output against the oracle output on the sample, and the metric's
+                "PSNR delta" against a fixed synthetic target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TILE = 64
+BATCH = 8
+SCALE = 4
+FLOP_PER_LR_PIXEL = 26_150_616  # 2*MAC over conv/Linear/QK^T/AV, default SwinIR x4
+PADDED = 72  # eval-mode pad 64 -> 72 (swinir.py:249-255)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+CPU_SAMPLE_TILES = 2
+
+
+def build_model(device):
+    import studiosr_amd as S
+
+    torch.manual_seed(0)
+    model = S.SwinIR(scale=SCALE).eval()  # reference defaults: C 180, depths 6x6, heads 6, ws 8, mlp 2.0
+    return model.to(device).set_precision("bf16")
+
+
+def time_dominant_kernel(model, x, iters: int = 30):
+    """Average duration of ONE launch of the dominant kernel shape (LN1 + QKV projection of one block:
+    M = 8*72*72 window-gathered rows, K = 192, N = 576) measured with HIP events on the launch stream,
+    plus its algorithmic FLOPs."""
+    import studiosr_amd._lib as L
+    from studiosr_amd import ops
+    from studiosr_amd.runtime import sr_dtype
+
+    cdt = torch.bfloat16
+    P = model._get_packed(cdt)
+    ws_ = model._workspace(x.device)
+    lp = P["layers"][0]
+    geo, bp = lp["geo"], lp["blocks"][1]
+    B = x.shape[0]
+    t_in = ws_.get("ta", (B, PADDED, PADDED, geo.Cp), torch.float32)
+    M = B * PADDED * PADDED
+    nb = M // geo.ntok
+    q = ws_.get("msa.q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
+    k = ws_.get("msa.k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
+    vt = ws_.get("msa.vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
+    sdt = sr_dtype(cdt)
+
+    def launch():
+        ops.gemm(
+            A=t_in.data_ptr(), Wp=bp["qkv_w"].data_ptr(), bias=bp["qkv_b"].data_ptr(), ln_norm_only=1,
+            out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=geo.Cp, N=3 * geo.HP,
+            k_real=geo.C, lda=geo.Cp, a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
+            a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=PADDED, W=PADDED, ws=geo.ws, shift=bp["shift"], epi=L.EPI_QKV,
+            heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5,
+        )
+
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * geo.C * 3 * geo.C  # algorithmic: 180 -> 540, un-padded
+    return ms, flops
+
+
+def cpu_baseline_and_parity(model, device):
+    """Oracle (CPU, fp32) on CPU_SAMPLE_TILES tiles of the same synthetic workload: throughput + parity."""
+    from oracle import metrics as OMT
+    from oracle import models as OM
+
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in model.state_dict().items()}
+    cfg = model.get_model_config()
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(CPU_SAMPLE_TILES, 3, TILE, TILE, generator=g)
+    cores = torch.get_num_threads()
+    with torch.inference_mode():
+        OM.swinir_forward(sd, x[:1], cfg)  # warm-up
+        t0 = time.perf_counter()
+        ref = OM.swinir_forward(sd, x, cfg)
+        dt = time.perf_counter() - t0
+    mpix = CPU_SAMPLE_TILES * (TILE * SCALE) ** 2 / 1e6
+    cpu = dict(value=round(mpix / dt, 5), unit="HR-Mpix/s", cores=cores, kind="port",
+               sample=f"{CPU_SAMPLE_TILES} tiles of the same workload (SwinIR x4 eval, 64x64 LR, fp32, torch CPU, 1 timed forward after 1 warm-up)")
+
+    tgt = torch.rand(CPU_SAMPLE_TILES, 3, TILE * SCALE, TILE * SCALE, generator=g)
+
+    def to_u8(t):
+        return (t.permute(0, 2, 3, 1) * 255.0).round().clip(0, 255).to(torch.uint8).numpy()
+
+    par = {}
+    ref_u8, tgt_u8 = to_u8(ref), to_u8(tgt)
+    for prec in ("fp32", "bf16"):
+        model.set_precision(prec)
+        with torch.no_grad():
+            y = model(x.to(device)).cpu()
+        mse = float(((y - ref) ** 2).mean())
+        par[f"psnr_vs_oracle_{prec}_db"] = round(10 * np.log10(1.0 / max(mse, 1e-20)), 3)
+        par[f"max_abs_diff_{prec}"] = float((y - ref).abs().max())
+        y_u8 = to_u8(y)
+        d = [abs(OMT.compute_psnr(y_u8[i], tgt_u8[i], y_only=True, crop_border=SCALE) - OMT.compute_psnr(ref_u8[i], tgt_u8[i], y_only=True, crop_border=SCALE))
+             for i in range(CPU_SAMPLE_TILES)]
+        par[f"psnr_delta_{prec}_db"] = float(max(d))
+    model.set_precision("bf16")
+    return cpu, par
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+
+    from studiosr_amd.runtime import GraphedForward
+
+    model = build_model(device)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(BATCH, 3, TILE, TILE, generator=g).to(device)
+
+    def fwd(inp):
+        with torch.no_grad():
+            return model(inp)
+
+    step = fwd if args.no_graph else GraphedForward(fwd, x)
+    for _ in range(args.warmup):
+        step(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(x)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    hr_mpix_per_step = world * BATCH * (TILE * SCALE) ** 2 / 1e6
+    value = hr_mpix_per_step / (elapsed / args.steps)
+
+    if rank == 0:
+        k_ms, k_flops = time_dominant_kernel(model, x)
+        achieved = k_flops / (k_ms * 1e-3) / 1e12
+        fwd_flops = BATCH * PADDED * PADDED * FLOP_PER_LR_PIXEL  # per GPU per step, reference semantics (padded tile)
+        fwd_tflops = fwd_flops / (ms_per_step * 1e-3) / 1e12
+        roof = dict(
+            bound="mfma", kernel="sr_gemm_kernel<bf16,float,3> (LN1 + QKV projection, M=41472 K=180 N=540)",
+            achieved=round(achieved, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+            traffic=None, kernel_ms=round(k_ms, 5),
+            forward=dict(achieved=round(fwd_tflops, 2), frac=round(fwd_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                         frac_unpadded=round(fwd_tflops * (TILE * TILE) / (PADDED * PADDED) / MFMA_BF16_PEAK_TFLOPS, 4),
+                         gflop_per_step=round(fwd_flops / 1e9, 2)),
+        )
+        out = {
+            "metric": "HR megapixels/sec at SwinIR x4, 64x64 LR tiles",
+            "value": round(value, 3),
+            "unit": "HR-Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "SwinIR x4 (embed 180, 6x6 blocks, ws 8) eval forward, 64x64 LR tiles, batch 8 per GPU",
+                       "tiles_per_step": world * BATCH, "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "roofline": roof,
+        }
+        if not args.skip_cpu and world == 1:
+            cpu, par = cpu_baseline_and_parity(model, device)
+            out["cpu_baseline"] = cpu
+            out["parity"] = par
+        elif not args.skip_cpu:
+            out["cpu_baseline"] = None  # reported on rank 0 at N=1 only
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,8 +67,45 @@ typedef struct SrGemm {
     int epi;              /* SR_EPI_* */
     int heads, hd_p, ntok;/* QKV epilogue: q,k -> [bwin][head][tok][hd_p], v -> [bwin][head][hd_p][ntok] */
     float ln_eps;
+    int ln_norm_only;     /* 1: prologue is (x - mean) * rstd only (gamma/beta were folded into Wp/bias at pack time) */
 } SrGemm;
 int sr_gemm(const SrGemm* a, void* stream);
+
+typedef struct SrSwinAttn {
+    /* out = x + proj(window_attention(qkv(LayerNorm1(x)))) in ONE kernel: swinir.py:146-171 (norm1, roll,
+     * window_partition, WindowAttention :78-105 incl. bias table + calculate_mask, window_reverse, roll back,
+     * shortcut add); hat.py:164-192 (attention branch).  One workgroup per window, one wave per head; q/k/v, the
+     * logits and the attention output stay in registers / LDS.  bf16 operands, fp32 stream; out may alias x. */
+    const float* x;       /* [B,H,W,ldx] fp32 stream */
+    float* out;
+    const void* wqkv;     /* packed [3*heads*hd_p x Cp] bf16: LayerNorm affine folded in, q rows pre-scaled */
+    const float* bqkv;    /* [3*heads*hd_p] */
+    const void* wproj;    /* packed [Cp x heads*hd_p] bf16 */
+    const float* bproj;   /* [Cp] */
+    const float* bias;    /* relative-position bias in fragment order [heads][qt][kt][lane][4] (packing.bias_fragments) */
+    int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift;
+    float eps;
+} SrSwinAttn;
+int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype);
+int sr_swin_attn_fused(const SrSwinAttn* a, void* stream);
+
+typedef struct SrMlp {
+    /* x_out = x + fc2(GELU(fc1(LayerNorm(x)))) in ONE kernel (common.py:173-195, swinir.py:172, hat.py:193,292):
+     * the hidden activations never leave the CU.  bf16 operands / fp32 accumulate; out may alias x. */
+    const float* x;       /* [M, ldx] fp32 stream */
+    float* out;           /* [M, ldx] fp32 */
+    const float* ln_gamma;/* [Cp], or NULL when gamma/beta are folded into w1p/b1 */
+    const float* ln_beta; /* [Cp] or NULL */
+    const void* w1p;      /* packed fc1 [Hp x Cp] bf16 */
+    const float* b1;      /* [Hp] */
+    const void* w2p;      /* packed fc2 [Cp x Hp] bf16 */
+    const float* b2;      /* [Cp] */
+    int M, C, Cp, Hp, ldx;
+    float eps;
+    int debug_flags;      /* 0 in production; timing-only ablations used by tools/kbench.py (results are wrong when set) */
+} SrMlp;
+int sr_mlp_fused_supported(int Cp, int Hp, int compute_dtype); /* 1 if sr_mlp_fused covers this shape */
+int sr_mlp_fused(const SrMlp* a, void* stream);
 
 typedef struct SrConv3x3 {
     /* nn.Conv2d(k=3, s=1, p=1) as an im2col-free implicit GEMM on an LDS halo tile, fused bias /

@@ -35,7 +35,22 @@ class SrGemm(C.Structure):
         ("a_map", _i), ("o_map", _i),
         ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
         ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
-        ("ln_eps", _f),
+        ("ln_eps", _f), ("ln_norm_only", _i),
+    ]
+
+
+class SrSwinAttn(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("bias", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
+        ("eps", _f),
+    ]
+
+
+class SrMlp(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("out", _vp), ("ln_gamma", _vp), ("ln_beta", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp),
+        ("M", _i), ("C", _i), ("Cp", _i), ("Hp", _i), ("ldx", _i), ("eps", _f), ("debug_flags", _i),
     ]
 
 
@@ -75,6 +90,10 @@ SYMBOLS = {
     "sr_ingest_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sr_gemm": (_i, [C.POINTER(SrGemm), _vp]),
+    "sr_swin_attn_supported": (_i, [_i, _i, _i, _i, _i]),
+    "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
+    "sr_mlp_fused_supported": (_i, [_i, _i, _i]),
+    "sr_mlp_fused": (_i, [C.POINTER(SrMlp), _vp]),
     "sr_conv3x3": (_i, [C.POINTER(SrConv3x3), _vp]),
     "sr_conv3x3_pool_tiles": (_i, [_i, _i, _i, _i]),
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),

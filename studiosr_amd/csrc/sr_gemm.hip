@@ -35,7 +35,7 @@ SR_DEV void stage_rows(const SrGemm& g, Frag<TC>* As, int m0, const WinMap& wm, 
         const TIn* src = reinterpret_cast<const TIn*>(g.A) + (size_t)srow * g.lda;
         Frag<TC>* dst = As + rb + r8;
         if constexpr (sizeof(TIn) == 4) {
-            if (g.ln_gamma != nullptr) {
+            if (g.ln_gamma != nullptr || g.ln_norm_only) {
                 // fused LayerNorm: 8 lanes share one row, lane kq owns K-groups kq, kq+8, ...
                 float v[6][8];
                 float s = 0.f;
@@ -75,8 +75,13 @@ SR_DEV void stage_rows(const SrGemm& g, Frag<TC>* As, int m0, const WinMap& wm, 
                     const int kg = kq + 8 * i;
                     if (kg < KG) {
                         float gm[8], bt[8], o[8];
-                        load8f(g.ln_gamma + kg * 8, gm);
-                        load8f(g.ln_beta + kg * 8, bt);
+                        if (g.ln_norm_only) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) gm[j] = (kg * 8 + j < g.k_real) ? 1.f : 0.f, bt[j] = 0.f;
+                        } else {
+                            load8f(g.ln_gamma + kg * 8, gm);
+                            load8f(g.ln_beta + kg * 8, bt);
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gm[j] + bt[j];
                         dst[kg * M_T] = frag_make<TC>(o);
@@ -252,8 +257,8 @@ extern "C" int sr_gemm(const SrGemm* a, void* stream) {
     const SrGemm& g = *a;
     SR_REQUIRE(g.M > 0 && g.K > 0 && g.K % 32 == 0 && g.N > 0 && g.N % 64 == 0, "sr_gemm: bad M/K/N %d/%d/%d", g.M, g.K, g.N);
     SR_REQUIRE(g.lda >= g.K && g.lda % 8 == 0, "sr_gemm: lda %d", g.lda);
-    if (g.ln_gamma) {
-        SR_REQUIRE(g.a_dtype == SR_F32 && g.ln_beta && g.K <= 384 && g.k_real > 0 && g.k_real <= g.K, "sr_gemm: LayerNorm prologue needs fp32 A and K <= 384");
+    if (g.ln_gamma || g.ln_norm_only) {
+        SR_REQUIRE(g.a_dtype == SR_F32 && (g.ln_norm_only || g.ln_beta) && g.K <= 384 && g.k_real > 0 && g.k_real <= g.K, "sr_gemm: LayerNorm prologue needs fp32 A and K <= 384");
     }
     if (g.a_map == SR_MAP_WINDOW || g.o_map == SR_MAP_WINDOW) {
         SR_REQUIRE(g.ws > 0 && g.H % g.ws == 0 && g.W % g.ws == 0 && g.shift >= 0 && g.shift < g.ws && g.M % (g.H * g.W) == 0,
@@ -269,6 +274,10 @@ extern "C" int sr_gemm(const SrGemm* a, void* stream) {
         SR_REQUIRE(!g.skip || g.ldskip >= g.N, "sr_gemm: ldskip");
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {
+        const int r = sr_gemm_v2_try(g, st);
+        if (r != 1) return r;
+    }
     if (g.compute_dtype == SR_BF16) {
         if (g.a_dtype == SR_F32) return dispatch_nw<bf16, float>(g, st);
         return dispatch_nw<bf16, bf16>(g, st);

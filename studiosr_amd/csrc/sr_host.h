@@ -6,6 +6,9 @@
 
 void sr_set_error(const char* fmt, ...);
 
+// sr_gemm2.hip: specialised hot-shape row GEMM; returns 1 if the shape is not covered.
+int sr_gemm_v2_try(const SrGemm& g, hipStream_t st);
+
 #define SR_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \

@@ -111,17 +111,29 @@ def pack_ln(norm: nn.LayerNorm, n_pad: int):
     return packing.pad_vec(norm.weight, n_pad).contiguous(), packing.pad_vec(norm.bias, n_pad).contiguous()
 
 
-def pack_attention(attn: nn.Module, geo: SwinGeometry, dt: torch.dtype, rpi: Optional[Tensor] = None) -> Dict:
+def fold_ln(dt: torch.dtype) -> bool:
+    """bf16 kernels take LayerNorm's gamma/beta folded into the following Linear (one less dependent load
+    and 2 fewer VALU ops per element in the prologue); the exact-fp32 path keeps the reference's op order."""
+    return dt == torch.bfloat16
+
+
+def pack_attention(attn: nn.Module, geo: SwinGeometry, dt: torch.dtype, rpi: Optional[Tensor] = None, norm: Optional[nn.LayerNorm] = None) -> Dict:
     C, Cp, heads, hd_p = geo.C, geo.Cp, geo.heads, geo.hd_p
-    qkv_w, qkv_b = packing.pack_qkv(attn.qkv.weight, attn.qkv.bias, C, Cp, heads, hd_p, dt)
+    qw, qb = attn.qkv.weight, attn.qkv.bias
+    if norm is not None and fold_ln(dt):
+        qw, qb = packing.fold_layernorm(qw, qb, norm.weight, norm.bias)
+    qkv_w, qkv_b = packing.pack_qkv(qw, qb, C, Cp, heads, hd_p, dt)
     proj_w, proj_b = packing.pack_linear(attn.proj.weight, attn.proj.bias, packing.identity_idx(C, Cp), packing.head_idx(heads, geo.hd, hd_p), dt)
     rpi = attn.relative_position_index if rpi is None else rpi
     bias = packing.gather_bias(attn.relative_position_bias_table, rpi, geo.ntok, geo.ntok)
-    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, bias=bias)
+    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, bias=bias, bias_frag=packing.bias_fragments(bias))
 
 
-def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
-    fc1_w, fc1_b = packing.pack_linear(mlp.fc1.weight, mlp.fc1.bias, packing.identity_idx(geo.hidden, geo.hid_p), packing.identity_idx(geo.C, geo.Cp), dt)
+def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[nn.LayerNorm] = None) -> Dict:
+    w1, b1 = mlp.fc1.weight, mlp.fc1.bias
+    if norm is not None and fold_ln(dt):
+        w1, b1 = packing.fold_layernorm(w1, b1, norm.weight, norm.bias)
+    fc1_w, fc1_b = packing.pack_linear(w1, b1, packing.identity_idx(geo.hidden, geo.hid_p), packing.identity_idx(geo.C, geo.Cp), dt)
     fc2_w, fc2_b = packing.pack_linear(mlp.fc2.weight, mlp.fc2.bias, packing.identity_idx(geo.C, geo.Cp), packing.identity_idx(geo.hidden, geo.hid_p), dt)
     return dict(fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b)
 
@@ -133,13 +145,20 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     M = B * H * W
     nb = M // geo.ntok
     sdt = sr_dtype(cdt)
+    if skip is t_in and ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt):  # one kernel per attention half
+        ops.swin_attn_fused(
+            x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
+            bproj=p["proj_b"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
+            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5,
+        )
+        return
     q = ws_.get(name + ".q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
     ops.gemm(
-        A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=ln[0].data_ptr(), ln_beta=ln[1].data_ptr(),
-        out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
+        A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
+        ln_beta=None if fold_ln(cdt) else ln[1].data_ptr(), ln_norm_only=int(fold_ln(cdt)), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
         a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
         H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5,
     )
@@ -159,10 +178,16 @@ def run_mlp(p: Dict, ln, geo: SwinGeometry, t: Tensor, ws_, cdt: torch.dtype, na
     Cp = t.shape[-1]
     M = t.numel() // Cp
     sdt = sr_dtype(cdt)
+    if ops.mlp_fused_supported(Cp, geo.hid_p, sdt):  # one kernel, hidden activations stay on the CU
+        ops.mlp_fused(
+            x=t.data_ptr(), out=t.data_ptr(), ln_gamma=None, ln_beta=None, w1p=p["fc1_w"].data_ptr(),
+            b1=p["fc1_b"].data_ptr(), w2p=p["fc2_w"].data_ptr(), b2=p["fc2_b"].data_ptr(), M=M, C=geo.C, Cp=Cp, Hp=geo.hid_p, ldx=Cp, eps=1e-5,
+        )
+        return
     h = ws_.get(name + ".h", (M, geo.hid_p), cdt)
     ops.gemm(
-        A=t.data_ptr(), Wp=p["fc1_w"].data_ptr(), bias=p["fc1_b"].data_ptr(), ln_gamma=ln[0].data_ptr(), ln_beta=ln[1].data_ptr(),
-        out=h.data_ptr(), M=M, K=Cp, N=geo.hid_p, k_real=geo.C, lda=Cp, ldo=geo.hid_p, a_dtype=L.SR_F32, out_dtype=sdt,
+        A=t.data_ptr(), Wp=p["fc1_w"].data_ptr(), bias=p["fc1_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
+        ln_beta=None if fold_ln(cdt) else ln[1].data_ptr(), ln_norm_only=int(fold_ln(cdt)), out=h.data_ptr(), M=M, K=Cp, N=geo.hid_p, k_real=geo.C, lda=Cp, ldo=geo.hid_p, a_dtype=L.SR_F32, out_dtype=sdt,
         compute_dtype=sdt, act=L.ACT_GELU, out_scale=1.0, epi=L.EPI_STD, ln_eps=1e-5,
     )
     ops.gemm(
@@ -264,8 +289,8 @@ class SwinIR(Model):
             blocks = []
             for blk in layer.residual_group.blocks:
                 e = dict(shift=blk.shift_size, ln1=pack_ln(blk.norm1, Cp), ln2=pack_ln(blk.norm2, Cp))
-                e.update(pack_attention(blk.attn, geo, dt))
-                e.update(pack_mlp(blk.mlp, geo, dt))
+                e.update(pack_attention(blk.attn, geo, dt, norm=blk.norm1))
+                e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
                 blocks.append(e)
             conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, packing.identity_idx(C, Cp), dt)
             P["layers"].append(dict(blocks=blocks, conv=conv, geo=geo))

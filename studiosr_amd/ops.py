@@ -54,6 +54,28 @@ def gemm(**kw) -> None:
     L.check(L.lib().sr_gemm(C.byref(g), _stream()), "sr_gemm")
 
 
+def swin_attn_supported(Cp: int, heads: int, hd_p: int, ws: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_swin_attn_supported(Cp, heads, hd_p, ws, compute_dtype))
+
+
+def swin_attn_fused(**kw) -> None:
+    a = L.SrSwinAttn()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_swin_attn_fused(C.byref(a), _stream()), "sr_swin_attn_fused")
+
+
+def mlp_fused_supported(Cp: int, Hp: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_mlp_fused_supported(Cp, Hp, compute_dtype))
+
+
+def mlp_fused(**kw) -> None:
+    a = L.SrMlp()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_mlp_fused(C.byref(a), _stream()), "sr_mlp_fused")
+
+
 def conv3x3(**kw) -> None:
     c = L.SrConv3x3()
     for k, v in kw.items():

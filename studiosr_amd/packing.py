@@ -75,6 +75,14 @@ def pack_linear(w: Tensor, b: Optional[Tensor], row_idx: Tensor, col_idx: Tensor
     return to_fragments(wm, dtype), bias.contiguous()
 
 
+def fold_layernorm(w: Tensor, b: Optional[Tensor], gamma: Tensor, beta: Tensor):
+    """LN(x) @ W^T + b  ==  ((x - mean) * rstd) @ (W * gamma)^T + (b + W @ beta): returns (W', b') in fp32."""
+    w32 = w.detach().to(torch.float32)
+    g32, be32 = gamma.detach().to(torch.float32), beta.detach().to(torch.float32)
+    b32 = torch.zeros(w32.shape[0], device=w32.device) if b is None else b.detach().to(torch.float32)
+    return w32 * g32[None, :], b32 + w32 @ be32
+
+
 def pack_qkv(w: Tensor, b: Tensor, C: int, C_p: int, heads: int, hd_p: int, dtype):
     """qkv Linear [3C, C]: padded row n' = part*heads*hd_p + head*hd_p + d; q rows pre-multiplied by hd**-0.5."""
     hd = C // heads
@@ -117,3 +125,12 @@ def gather_bias(table: Tensor, rpi: Tensor, n_q: int, n_k: int) -> Tensor:
     idx = rpi.reshape(-1).to(t.device)
     idx = torch.where(idx < 0, idx + t.shape[0], idx)
     return t[idx].reshape(n_q, n_k, -1).permute(2, 0, 1).contiguous()
+
+
+def bias_fragments(bias: Tensor) -> Tensor:
+    """[heads, Nq, Nk] fp32 -> accumulator-fragment order [heads][qt][kt][lane][4] with
+    element = bias[h][16*qt + (lane & 15)][16*kt + 4*(lane >> 4) + r]: the fused attention kernel then
+    initialises each S^T accumulator tile with ONE coalesced 1 KiB load."""
+    heads, nq, nk = bias.shape
+    b = bias.reshape(heads, nq // 16, 16, nk // 16, 4, 4)  # [h, qt, q16, kt, g, r]
+    return b.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)  # [h, qt, kt, g, q16, r] -> lane = g*16 + q16
