@@ -102,7 +102,6 @@ typedef struct SrMlp {
     const float* b2;      /* [Cp] */
     int M, C, Cp, Hp, ldx;
     float eps;
-    int debug_flags;      /* 0 in production; timing-only ablations used by tools/kbench.py (results are wrong when set) */
 } SrMlp;
 int sr_mlp_fused_supported(int Cp, int Hp, int compute_dtype); /* 1 if sr_mlp_fused covers this shape */
 int sr_mlp_fused(const SrMlp* a, void* stream);

@@ -50,7 +50,7 @@ class SrSwinAttn(C.Structure):
 class SrMlp(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("ln_gamma", _vp), ("ln_beta", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp),
-        ("M", _i), ("C", _i), ("Cp", _i), ("Hp", _i), ("ldx", _i), ("eps", _f), ("debug_flags", _i),
+        ("M", _i), ("C", _i), ("Cp", _i), ("Hp", _i), ("ldx", _i), ("eps", _f),
     ]
 
 

@@ -28,6 +28,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define SR_DEV __device__ __forceinline__
 
+// In-kernel cycle stamps (diagnostic builds only: `make STAMPS=1`; see tools/stamp_test*.py).  One lane of one
+// workgroup writes s_memtime into a __device__ array that only the sr_debug_*_stamps() readers touch.
+#ifdef SR_STAMPS
+#define SR_STAMP(arr, i) do { if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) arr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SR_STAMP(arr, i) do { } while (0)
+#endif
+
 // ----------------------------------------------------------------------------- fragments
 template <typename T>
 struct Frag;
@@ -146,6 +154,32 @@ SR_DEV float apply_act(float x, int act) {
     }
 }
 
+// Compile-time activation (the run-time switch above gets if-converted by hipcc: every element then
+// pays for erff even when act == NONE).  Kernels dispatch ONCE per wave with act_dispatch().
+template <int ACT>
+SR_DEV float act_ct(float x) {
+    if constexpr (ACT == SR_ACT_RELU) return x > 0.f ? x : 0.f;
+    if constexpr (ACT == SR_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
+    if constexpr (ACT == SR_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return x;
+}
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+// f(IntC<ACT>{}) under a wave-uniform branch on the run-time activation code.
+template <typename F>
+SR_DEV void act_dispatch(int act, F&& f) {
+    if (act == SR_ACT_NONE)
+        f(IntC<SR_ACT_NONE>{});
+    else if (act == SR_ACT_RELU)
+        f(IntC<SR_ACT_RELU>{});
+    else if (act == SR_ACT_LRELU)
+        f(IntC<SR_ACT_LRELU>{});
+    else
+        f(IntC<SR_ACT_GELU>{});
+}
+
 // GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): ~14 VALU ops instead of the
 // ~100 of ocml erff.  Used by the bf16 kernels (the exact-fp32 path keeps erff).
 SR_DEV float gelu_fast(float x) {
@@ -159,6 +193,15 @@ SR_DEV float gelu_fast(float x) {
     const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
     const float h = 0.5f * x;
     return h + fabsf(h) * e;  // 0.5*x*(1 + sign(x)*erf(|x|/sqrt2))
+}
+
+// tanh-form GELU written as x * sigmoid(2u): 5 VALU + v_exp + v_rcp.  |error| <= 4.8e-4 against the exact erf
+// form, i.e. ~8x below the bf16 rounding of the value it produces; used ONLY where the result is stored as bf16.
+SR_DEV float gelu_bf16(float x) {
+    const float s = x * x;
+    const float p = fmaf(s, -0.1029432f, -2.3022082f);  // -(2*sqrt(2/pi)*log2(e)) * (1 + 0.044715 x^2)
+    const float e = __builtin_amdgcn_exp2f(x * p);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // window-order row -> image-order row (roll(-shift) + window_partition as one gather;

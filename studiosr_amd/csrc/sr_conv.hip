@@ -21,13 +21,16 @@ namespace {
 
 constexpr int HALO_W = 18;
 
+__device__ unsigned long long sr_dbg_conv[16];
+#define STAMP(i) SR_STAMP(sr_dbg_conv, i)
+
 template <int TH>
 struct ConvGeo {
     static constexpr int HH = TH + 2;
     static constexpr int ROWS = ((HH * HALO_W + 15) / 16) * 16;
 };
 
-template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
+template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
     constexpr int ROWS = ConvGeo<TH>::ROWS;
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     const int b = t / tiles_y;
     const int x0 = tx * 16, y0 = ty * TH;
     const int KG = c.Cin_p >> 3, KC = c.Cin_p >> 5;
+    STAMP(0);
 
     // ---- stage the halo tile (8 pixels x 8 K-groups per wave instruction: full 128-B lines)
     {
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             }
         }
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     // ---- main loop over (tap, channel chunk)
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -83,36 +89,74 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4)(0.0f);
 
-    Frag<TC> bc[NW], bn[NW];
+    if constexpr (KCS > 0) {
+        // Fully unrolled (tap, chunk) walk: K-chunk count is a compile-time constant, so the 3-slot weight ring
+        // (chunk t in slot t % 3, fetched 2 chunks = 2*MTW*NW MFMAs ahead) and every accumulator stay in fixed registers.
+        constexpr int RING = 3;
+        constexpr int KCTS = 9 * KCS;
+        Frag<TC> br[RING][NW];
 #pragma unroll
-    for (int n = 0; n < NW; ++n) bc[n] = Bp[(size_t)n * KCT * 64];
-
-    int chunk = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const Frag<TC>* abase = As + (wm * MTW + ky) * HALO_W + kx + ar + ag * ROWS;
-        for (int kc = 0; kc < KC; ++kc, ++chunk) {
-            const int cn = chunk + 1 < KCT ? chunk + 1 : chunk;
+        for (int t = 0; t < RING - 1; ++t)
 #pragma unroll
-            for (int n = 0; n < NW; ++n) bn[n] = Bp[((size_t)n * KCT + cn) * 64];
-            const Frag<TC>* arow = abase + kc * 4 * ROWS;
+            for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + t) * 64];
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const Frag<TC> a = arow[m * HALO_W];
+        for (int tap = 0; tap < 9; ++tap) {
+            const Frag<TC>* abase = As + (wm * MTW + tap / 3) * HALO_W + (tap % 3) + ar + ag * ROWS;
 #pragma unroll
-                for (int n = 0; n < NW; ++n) mma(bc[n], a, acc[m][n]);
+            for (int kc = 0; kc < KCS; ++kc) {
+                const int t = tap * KCS + kc;
+                if (t + RING - 1 < KCTS) {
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
+                }
+                const Frag<TC>* arow = abase + kc * 4 * ROWS;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const Frag<TC> a = arow[m * HALO_W];
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], a, acc[m][n]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one fence per chunk: bounds live ranges, keeps the ring order
             }
+        }
+    } else {
+        // generic channel count: run-time loop, weights double-buffered one chunk ahead
+        Frag<TC> bc[NW], bn[NW];
 #pragma unroll
-            for (int n = 0; n < NW; ++n) bc[n] = bn[n];
+        for (int n = 0; n < NW; ++n) bc[n] = Bp[(size_t)n * KCT * 64];
+        int chunk = 0;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const Frag<TC>* abase = As + (wm * MTW + ky) * HALO_W + kx + ar + ag * ROWS;
+            for (int kc = 0; kc < KC; ++kc, ++chunk) {
+                const int cn = chunk + 1 < KCT ? chunk + 1 : chunk;
+#pragma unroll
+                for (int n = 0; n < NW; ++n) bn[n] = Bp[((size_t)n * KCT + cn) * 64];
+                const Frag<TC>* arow = abase + kc * 4 * ROWS;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const Frag<TC> a = arow[m * HALO_W];
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(bc[n], a, acc[m][n]);
+                }
+#pragma unroll
+                for (int n = 0; n < NW; ++n) bc[n] = bn[n];
+            }
         }
     }
 
+    STAMP(3);
     // ---- epilogue: lane = pixel (x0 + ar), registers = 4 consecutive output channels
     const int x = x0 + ar;
     f32x4 pool[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) pool[n] = (f32x4)(0.0f);
 
+    f32x4 bias_r[NW];  // fetched before the first store: stores may alias, so later loads would serialise behind them
+#pragma unroll
+    for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
+    act_dispatch(c.act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int y = y0 + wm * MTW + m;
@@ -120,10 +164,9 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int col = (ntile0 + n) * 16 + ag * 4;
-            f32x4 v = acc[m][n];
-            if (c.bias) v += load4(c.bias + col);
+            f32x4 v = acc[m][n] + bias_r[n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], c.act);
+            for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
             if (c.pool_partial && inb) pool[n] += v;
             v *= c.out_scale;
             if (!inb) continue;
@@ -166,7 +209,9 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
                 store4(reinterpret_cast<float*>(c.out) + off, v);
         }
     }
+    });
 
+    STAMP(4);
     if (c.pool_partial) {
         const int n_tiles = tiles_x * tiles_y * WM;
         const int slot = (ty * tiles_x + tx) * WM + wm;
@@ -187,29 +232,44 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     }
 }
 
-template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
-int launch_conv(const SrConv3x3& c, hipStream_t st) {
+template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
+int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
     constexpr int ROWS = ConvGeo<TH>::ROWS;
     const int lds = c.Cin_p * ROWS * (int)sizeof(TC);
     SR_REQUIRE(lds <= 160 * 1024, "sr_conv3x3: Cin_p=%d needs %d B of LDS", c.Cin_p, lds);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW>, 160 * 1024);
+        hipError_t e = sr_allow_lds(sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>, 160 * 1024);
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     const int tiles = ((c.W + 15) / 16) * ((c.H + TH - 1) / TH) * c.B;
     dim3 grid(tiles, c.Cout_p / (WN * NW * 16));
-    hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW>), grid, dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>), grid, dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
+}
+
+// unrolled variants for the channel counts of the reference models (32 = RGB ingest, 64, 192 = 180 padded, 256);
+// bf16 only -- the exact-fp32 parity path keeps the generic loop
+template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
+int launch_conv(const SrConv3x3& c, hipStream_t st) {
+    if constexpr (sizeof(TC) == 2) {
+        switch (c.Cin_p) {
+            case 32: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 1>(c, st);
+            case 64: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 2>(c, st);
+            case 192: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 6>(c, st);
+            case 256: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 8>(c, st);
+            default: break;
+        }
+    }
+    return launch_conv_k<TC, TIn, TH, WM, WN, NW, 0>(c, st);
 }
 
 // pick the widest N tile that divides Cout_p
 template <typename TC, typename TIn, int TH>
 int dispatch_conv(const SrConv3x3& c, hipStream_t st) {
     const int n = c.Cout_p;
-    if (n % 256 == 0) return launch_conv<TC, TIn, TH, 1, 4, 4>(c, st);
     if (n % 192 == 0) return launch_conv<TC, TIn, TH, 1, 4, 3>(c, st);
     if (n % 128 == 0) return launch_conv<TC, TIn, TH, 1, 4, 2>(c, st);
     if (n % 64 == 0) return launch_conv<TC, TIn, TH, 2, 2, 2>(c, st);
@@ -218,12 +278,16 @@ int dispatch_conv(const SrConv3x3& c, hipStream_t st) {
 }
 
 int conv_wm(int cout_p) {
-    if (cout_p % 256 == 0 || cout_p % 192 == 0 || cout_p % 128 == 0) return 1;
+    if (cout_p % 192 == 0 || cout_p % 128 == 0) return 1;
     if (cout_p % 32 == 0) return 2;
     return 4;
 }
 
 }  // namespace
+
+extern "C" int sr_debug_conv_stamps(unsigned long long* host16) {
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(sr_dbg_conv), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 
 extern "C" int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype) {
     // number of per-image partial-sum slots sr_conv3x3 writes into pool_partial for this geometry

@@ -143,6 +143,8 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
     // ------------------------------------------------------------------ epilogue
     if constexpr (SWAPPED) {
         const int HP = g.heads * g.hd_p;
+        act_dispatch(g.act, [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int row = m0 + m * 16 + ar;
@@ -154,7 +156,7 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
                 f32x4 v = acc[m][n];
                 if (g.bias) v += load4(g.bias + col);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act) * g.out_scale;
+                for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]) * g.out_scale;
                 if (g.epi == SR_EPI_QKV) {
                     const int part = col / HP;
                     const int rem = col - part * HP;
@@ -176,6 +178,7 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
                 }
             }
         }
+        });
     } else {
         // V third of a QKV projection: lane = feature (ar), registers = 4 consecutive rows.
         const int HP = g.heads * g.hd_p;

@@ -249,10 +249,12 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
             for (int m = 0; m < MT; ++m) {
                 if (orow[m] < 0) continue;
                 f32x4 v = acc[m][n] + bias;
-                if (!a.acc_from_skip) {
+                if (g.act != SR_ACT_NONE) {  // wave-uniform; erff-free (compile-time variants only)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (g.act == SR_ACT_GELU ? gelu_fast(v[r]) : apply_act(v[r], g.act)) * g.out_scale;
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = g.act == SR_ACT_GELU ? gelu_fast(v[r]) : (v[r] > 0.f ? v[r] : (g.act == SR_ACT_LRELU ? 0.01f * v[r] : 0.f));
                 }
+                if (g.out_scale != 1.0f) v *= g.out_scale;
                 if (g.epi == SR_EPI_QKV) {
                     const int row = m0 + m * 16 + ar;
                     const int bwin = row >> a.ntok_log2, tok = row & (g.ntok - 1);

@@ -23,6 +23,9 @@
 
 namespace {
 
+__device__ unsigned long long sr_dbg_swa[16];
+#define STAMP(i) SR_STAMP(sr_dbg_swa, i)
+
 struct SwinAttnDev {
     SrSwinAttn a;
     FastDiv div_nw, div_nwx;  // windows per image, windows per row
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave = head
     const int ar = lane & 15, ag = lane >> 4;
 
+    STAMP(0);
     // ---- window geometry
     uint32_t bimg, win, wy, wx;
     dv.div_nw.divmod(blockIdx.x, bimg, win);
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) xr[m][n] = load4(a.x + (size_t)pix[m] * a.ldx + h * 32 + n * 16 + ag * 4);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
     {
         const float inv = 1.0f / (float)a.C;
         float mean[4], rstd[4];
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- S1: q, k (swapped: lane = token, registers = 4 features) then v (un-swapped: lane = feature,
     //          registers = 4 tokens) of head h, one 32-column pass each so that only 8 accumulator tiles are live
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
             if (t + RING < 3 * KC) stream_load(t + RING, slot);  // the proj weights are fetched after the attention
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(3 + part);
         if (part < 2) {
             const f32x4 b0 = load4(a.bqkv + part * 192 + h * 32 + ag * 4), b1 = load4(a.bqkv + part * 192 + h * 32 + 16 + ag * 4);
 #pragma unroll
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         }
     }
 
+    STAMP(6);
     // ---- S2: attention for head h, two query halves of 32
     const bool masked = a.shift > 0 && ((int)wy == a.H / WS - 1 || (int)wx == a.W / WS - 1);
     const f32x4* bias = reinterpret_cast<const f32x4*>(a.bias) + (size_t)h * 16 * 64 + lane;  // [h][qt][kt][lane]
@@ -248,7 +256,9 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     }
 #pragma unroll
     for (int c = 0; c < RING; ++c) stream_load(3 * KC + c, (3 * KC + c) % RING);
+    STAMP(7);
     __syncthreads();
+    STAMP(8);
 
     // ---- S3: proj columns [32h, 32h+32) on top of the residual
     {
@@ -277,9 +287,14 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) store4(a.out + (size_t)pix[m] * a.ldx + h * 32 + n * 16 + ag * 4, xr[m][n]);
     }
+    STAMP(9);
 }
 
 }  // namespace
+
+extern "C" int sr_debug_swa_stamps(unsigned long long* host16) {
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(sr_dbg_swa), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 
 extern "C" int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype) {
     return (compute_dtype == SR_BF16 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8) ? 1 : 0;

@@ -35,7 +35,7 @@ def main():
     lp = P["layers"][0]
     geo, bp = lp["geo"], lp["blocks"][1]
     which = sys.argv[1:] or ["mlp", "qkv", "attn", "proj", "msa"]
-    for B in ((1, 8) if "mlpab" in which else (1, 2, 4, 8, 16)):
+    for B in (1, 2, 4, 8, 16):
         H = W = 72
         t = torch.randn(B, H, W, geo.Cp, device=dev)
         t[..., geo.C:] = 0
@@ -44,15 +44,44 @@ def main():
         res = {}
         if "mlp" in which:
             res["mlp"] = timeit(lambda: SW.run_mlp(bp, bp["ln2"], geo, t, ws_, cdt))
-        if "mlpab" in which:
-            for fl in (0, 1, 2, 4, 5, 7):
-                res[f"mlp_f{fl}"] = timeit(lambda: ops.mlp_fused(
-                    x=t.data_ptr(), out=t.data_ptr(), ln_gamma=None, ln_beta=None, w1p=bp["fc1_w"].data_ptr(), b1=bp["fc1_b"].data_ptr(),
-                    w2p=bp["fc2_w"].data_ptr(), b2=bp["fc2_b"].data_ptr(), M=M, C=geo.C, Cp=geo.Cp, Hp=geo.hid_p, ldx=geo.Cp, eps=1e-5, debug_flags=fl))
         if "msa" in which:
             res["msa"] = timeit(lambda: SW.run_window_msa(bp, bp["ln1"], geo, t, t, t, ws_, cdt, bp["shift"]))
         print(f"B={B:2d} M={M:6d} WG64={M // 64:5d} " + " ".join(f"{k}={v:8.1f}us" for k, v in res.items()), flush=True)
 
+
+
+
+def conv_bench():
+    """conv3x3 micro-benchmarks: python tools/kbench.py conv"""
+    from studiosr_amd.models.common import conv_call
+    from studiosr_amd import packing
+    dev = torch.device("cuda")
+    cdt = torch.bfloat16
+    for (B, H, W, cin, cout, mode) in [(1, 144, 144, 64, 256, "nhwc"), (2, 144, 144, 64, 256, "nhwc"), (4, 144, 144, 64, 256, "nhwc"), (1, 72, 72, 192, 192, "nhwc"), (8, 144, 144, 64, 256, "ps"), (8, 144, 144, 64, 256, "nhwc"), (8, 72, 72, 64, 256, "ps"), (8, 72, 72, 192, 192, "nhwc"),
+                                       (8, 72, 72, 192, 192, "nhwc_f32"), (8, 288, 288, 64, 16, "nhwc")]:
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        b = torch.randn(cout, device=dev)
+        if mode == "ps":
+            rows = packing.pixel_shuffle_rows(cout // 4, cout // 4, 2)
+        else:
+            rows = packing.identity_idx(cout, cout)
+        wp, bp = packing.pack_conv3x3(w, b, cin, rows, cdt)
+        xdt = torch.float32 if mode == "nhwc_f32" else cdt
+        x = torch.randn(B, H, W, cin, device=dev).to(xdt)
+        if mode == "ps":
+            out = torch.empty(B, 2 * H, 2 * W, cout // 4, device=dev, dtype=cdt)
+            fn = lambda: conv_call(x, wp, bp, out, cdt, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=2, cps_p=cout // 4)
+        else:
+            out = torch.empty(B, H, W, cout, device=dev, dtype=torch.float32 if mode == "nhwc_f32" else cdt)
+            fn = lambda: conv_call(x, wp, bp, out, cdt)
+        us = timeit(fn)
+        gf = 2.0 * B * H * W * 9 * cin * cout / 1e9
+        print(f"conv B={B} {H}x{W} {cin}->{cout} {mode:9s}: {us:8.1f} us  {gf / us * 1e3:8.1f} TF/s", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "conv":
+    conv_bench()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
