@@ -26,7 +26,7 @@ enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element typ
 enum { SR_ACT_NONE_ = 0, SR_ACT_RELU_ = 1, SR_ACT_LRELU_ = 2, SR_ACT_GELU_ = 3 };
 enum { SR_PAD_NONE = 0, SR_PAD_EVAL_MIRROR = 1, SR_PAD_REFLECT = 2 };
 enum { SR_MAP_IDENTITY = 0, SR_MAP_WINDOW = 1 };
-enum { SR_EPI_STD = 0, SR_EPI_QKV = 1 };
+enum { SR_EPI_STD = 0, SR_EPI_QKV = 1, SR_EPI_QKV_OCA = 2 };
 enum { SR_OUT_NHWC = 0, SR_OUT_PIXEL_SHUFFLE = 1, SR_OUT_FINAL_NCHW = 2 };
 
 int sr_abi_version(void);
@@ -68,6 +68,9 @@ typedef struct SrGemm {
     int heads, hd_p, ntok;/* QKV epilogue: q,k -> [bwin][head][tok][hd_p], v -> [bwin][head][hd_p][ntok] */
     float ln_eps;
     int ln_norm_only;     /* 1: prologue is (x - mean) * rstd only (gamma/beta were folded into Wp/bias at pack time) */
+    int oca_pad;          /* SR_EPI_QKV_OCA (HAT OCAB, hat.py:247-264): q -> window order as SR_EPI_QKV; k -> zero-bordered image
+                           * [B][H+2p][W+2p][heads][hd_p]; v -> transposed zero-bordered [B][heads][hd_p][(H+2p)*(W+2p)]; p = oca_pad = physical border (multiple of 4).
+                           * Rows must be in window order (a_map = SR_MAP_WINDOW, shift 0); the borders are zeroed by the caller. */
 } SrGemm;
 int sr_gemm(const SrGemm* a, void* stream);
 
@@ -144,6 +147,20 @@ typedef struct SrWindowAttn {
     int dtype;
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
+
+typedef struct SrOcaAttn {
+    /* HAT overlapping cross attention core (hat.py:266-283): every ws x ws query window attends to the
+     * (ws+2p) x (ws+2p) neighbourhood around it (nn.Unfold with zero padding, :217-221,255): softmax(q k^T + bias) v.
+     * Buffers as written by sr_gemm with SR_EPI_QKV_OCA. */
+    const void* q;        /* [bwin][head][ws*ws][hd_p] T, pre-scaled */
+    const void* k;        /* [B][H+2e][W+2e][heads][hd_p] T, zero border of e = `border` pixels (e >= pad, e % 4 == 0) */
+    const void* vt;       /* [B][heads][hd_p][(H+2e)*(W+2e)] T, zero border */
+    const float* bias;    /* [heads][ws*ws][nk_pad] fp32, nk_pad = keys padded to a multiple of 32 (pad columns ignored) */
+    void* out;            /* [bwin*ws*ws][heads*hd_p] T (window-order rows) */
+    int B, H, W, heads, hd_p, ws, pad, border, nk_pad;
+    int dtype;
+} SrOcaAttn;
+int sr_oca_attention(const SrOcaAttn* a, void* stream);
 
 /* nn.PixelShuffle (common.py:129,133,136) standalone: out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w].
  * elem_size 2 or 4 bytes; tensors are plain NCHW. Bit-exact copy. */

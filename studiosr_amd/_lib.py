@@ -18,7 +18,7 @@ SR_F32, SR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
 PAD_NONE, PAD_EVAL_MIRROR, PAD_REFLECT = 0, 1, 2
 MAP_IDENTITY, MAP_WINDOW = 0, 1
-EPI_STD, EPI_QKV = 0, 1
+EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
@@ -35,7 +35,7 @@ class SrGemm(C.Structure):
         ("a_map", _i), ("o_map", _i),
         ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
         ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
-        ("ln_eps", _f), ("ln_norm_only", _i),
+        ("ln_eps", _f), ("ln_norm_only", _i), ("oca_pad", _i),
     ]
 
 
@@ -73,6 +73,13 @@ class SrWindowAttn(C.Structure):
     ]
 
 
+class SrOcaAttn(C.Structure):
+    _fields_ = [
+        ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("pad", _i), ("border", _i), ("nk_pad", _i), ("dtype", _i),
+    ]
+
+
 class SrChannelAttn(C.Structure):
     _fields_ = [
         ("y", _vp), ("pool_partial", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp),
@@ -97,6 +104,7 @@ SYMBOLS = {
     "sr_conv3x3": (_i, [C.POINTER(SrConv3x3), _vp]),
     "sr_conv3x3_pool_tiles": (_i, [_i, _i, _i, _i]),
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
+    "sr_oca_attention": (_i, [C.POINTER(SrOcaAttn), _vp]),
     "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),
 }

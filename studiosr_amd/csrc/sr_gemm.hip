@@ -157,12 +157,18 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
                 if (g.bias) v += load4(g.bias + col);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]) * g.out_scale;
-                if (g.epi == SR_EPI_QKV) {
+                if (g.epi != SR_EPI_STD) {
                     const int part = col / HP;
                     const int rem = col - part * HP;
                     const int head = rem / g.hd_p, d0 = rem - head * g.hd_p;
                     const int bwin = row / g.ntok, tok = row - bwin * g.ntok;
-                    const size_t off = (((size_t)bwin * g.heads + head) * g.ntok + tok) * g.hd_p + d0;
+                    size_t off = (((size_t)bwin * g.heads + head) * g.ntok + tok) * g.hd_p + d0;
+                    if (g.epi == SR_EPI_QKV_OCA && part == 1) {  // k -> zero-bordered image order
+                        const int pimg = wm(row);
+                        const int bb = pimg / wm.hw, rem2 = pimg - bb * wm.hw;
+                        const int yy = rem2 / g.W, xx = rem2 - yy * g.W;
+                        off = ((((size_t)bb * (g.H + 2 * g.oca_pad) + yy + g.oca_pad) * (g.W + 2 * g.oca_pad) + xx + g.oca_pad) * g.heads + head) * g.hd_p + d0;
+                    }
                     void* base = part == 0 ? g.out : g.out_k;
                     if (g.out_dtype == SR_BF16)
                         store4(reinterpret_cast<bf16*>(base) + off, v);
@@ -194,7 +200,14 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
                 if (g.bias) v += g.bias[col];
                 const int rem = col - 2 * HP;
                 const int head = rem / g.hd_p, d = rem - head * g.hd_p;
-                const size_t off = (((size_t)bwin * g.heads + head) * g.hd_p + d) * g.ntok + tok0;
+                size_t off = (((size_t)bwin * g.heads + head) * g.hd_p + d) * g.ntok + tok0;
+                if (g.epi == SR_EPI_QKV_OCA) {  // v -> transposed zero-bordered image (4 consecutive tokens = 4 consecutive x)
+                    const int pimg = wm(row0);
+                    const int bb = pimg / wm.hw, rem2 = pimg - bb * wm.hw;
+                    const int yy = rem2 / g.W, xx = rem2 - yy * g.W;
+                    const size_t plane = (size_t)(g.H + 2 * g.oca_pad) * (g.W + 2 * g.oca_pad);
+                    off = (((size_t)bb * g.heads + head) * g.hd_p + d) * plane + (size_t)(yy + g.oca_pad) * (g.W + 2 * g.oca_pad) + xx + g.oca_pad;
+                }
                 if (g.out_dtype == SR_BF16)
                     store4(reinterpret_cast<bf16*>(g.out_vt) + off, v);
                 else
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256) void sr_gemm_kernel(SrGemm g) {
     stage_rows<TC, TIn>(g, As, m0, wm, lane, wave);
     __syncthreads();
 
-    const bool vpart = (g.epi == SR_EPI_QKV) && ((int)blockIdx.y * 64 * NW >= 2 * g.heads * g.hd_p);
+    const bool vpart = (g.epi != SR_EPI_STD) && ((int)blockIdx.y * 64 * NW >= 2 * g.heads * g.hd_p);
     if (vpart)
         gemm_body<TC, NW, false>(g, As, m0, wm, lane, wave);
     else
@@ -247,7 +260,7 @@ int launch_gemm(const SrGemm& g, hipStream_t st) {
 template <typename TC, typename TIn>
 int dispatch_nw(const SrGemm& g, hipStream_t st) {
     int unit = g.N;
-    if (g.epi == SR_EPI_QKV) unit = g.heads * g.hd_p;
+    if (g.epi != SR_EPI_STD) unit = g.heads * g.hd_p;
     if (unit % 192 == 0) return launch_gemm<TC, TIn, 3>(g, st);
     if (unit % 128 == 0) return launch_gemm<TC, TIn, 2>(g, st);
     return launch_gemm<TC, TIn, 1>(g, st);
@@ -267,7 +280,9 @@ extern "C" int sr_gemm(const SrGemm* a, void* stream) {
         SR_REQUIRE(g.ws > 0 && g.H % g.ws == 0 && g.W % g.ws == 0 && g.shift >= 0 && g.shift < g.ws && g.M % (g.H * g.W) == 0,
                    "sr_gemm: bad window geometry H=%d W=%d ws=%d shift=%d M=%d", g.H, g.W, g.ws, g.shift, g.M);
     }
-    if (g.epi == SR_EPI_QKV) {
+    if (g.epi != SR_EPI_STD) {
+        if (g.epi == SR_EPI_QKV_OCA)
+            SR_REQUIRE(g.a_map == SR_MAP_WINDOW && g.shift == 0 && g.oca_pad >= 0 && g.ws % 4 == 0 && g.ntok == g.ws * g.ws, "sr_gemm: bad OCA epilogue geometry");
         SR_REQUIRE(g.out_k && g.out_vt && g.heads > 0 && g.hd_p % 16 == 0 && g.N == 3 * g.heads * g.hd_p && g.ntok % 16 == 0 && g.M % g.ntok == 0 &&
                        (g.heads * g.hd_p) % 64 == 0,
                    "sr_gemm: bad QKV epilogue geometry");

@@ -321,7 +321,7 @@ int launch2(const Gemm2& a, hipStream_t st) {
 
 // returns 1 when the shape is not one of the specialised ones (caller falls back to the generic kernel)
 int sr_gemm_v2_try(const SrGemm& g, hipStream_t st) {
-    if (g.compute_dtype != SR_BF16 || g.N % 192 != 0) return 1;
+    if (g.compute_dtype != SR_BF16 || g.N % 192 != 0 || g.epi == SR_EPI_QKV_OCA) return 1;
     if (!(g.K == 192 || (g.K == 384 && g.a_dtype == SR_BF16))) return 1;
     Gemm2 a;
     a.g = g;

@@ -1,0 +1,362 @@
+"""HAT on the MI355X HIP hot path (reference: studiosr/models/hat.py).
+
+Same constructor kwargs / attributes / state_dict keys (incl. the model-level buffers
+relative_position_index_SA / _OCA, hat.py:428-431) as the reference.  forward is a sequence of C-ABI launches:
+
+  ingest (reflect pad + normalise, hat.py:544-546) -> conv_first -> LayerNorm
+  per HAB (hat.py:153-195):
+      LayerNorm kernel -> CAB: conv3x3+GELU -> conv3x3 (+ per-tile channel sums)              (:41-52)
+      (shifted) window attention on x: fused kernel when the geometry allows, else
+          [LN + QKV GEMM] -> window attention -> [proj GEMM + shortcut]                        (:55-110)
+      channel-attention gate: x = (shortcut + attn) + conv_scale * cab * sigmoid(..)           (:25-38,192)
+      MLP: fused LN + fc1 + GELU + fc2 + residual                                              (:193)
+  per OCAB (hat.py:239-293):
+      [LN + QKV GEMM] with q -> window order, k -> zero-bordered image, v -> transposed zero-bordered planes
+      overlapping cross attention (neighbourhood gathered by addressing, never unfolded)
+      [proj GEMM + shortcut] -> MLP
+  per RHAG: conv3x3 + residual (:385);  tail as SwinIR (:549-554)
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops, packing
+from ..runtime import compute_dtype, sr_dtype
+from .common import Model, Upsampler, conv_call, pack_upsampler, run_upsampler
+from .rcan import pack_ca, run_channel_attention
+from .swinir import (
+    MlpParams,
+    PatchEmbed,
+    SwinGeometry,
+    final_affine,
+    fold_ln,
+    ingest_affine,
+    pack_attention,
+    pack_ln,
+    pack_mlp,
+    run_mlp,
+    run_window_msa,
+)
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- parameter containers
+class ChannelAttention(nn.Module):
+    """hat.py:25-34 (keys attention.1 / attention.3)."""
+
+    def __init__(self, num_feat: int, squeeze_factor: int = 16) -> None:
+        super().__init__()
+        self.attention = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1),
+            nn.Conv2d(num_feat, num_feat // squeeze_factor, 1, padding=0),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(num_feat // squeeze_factor, num_feat, 1, padding=0),
+            nn.Sigmoid(),
+        )
+
+
+class CAB(nn.Module):
+    """hat.py:41-49 (keys cab.0 / cab.2 / cab.3)."""
+
+    def __init__(self, num_feat: int, compress_ratio: int = 3, squeeze_factor: int = 30) -> None:
+        super().__init__()
+        self.cab = nn.Sequential(
+            nn.Conv2d(num_feat, num_feat // compress_ratio, 3, 1, 1),
+            nn.GELU(),
+            nn.Conv2d(num_feat // compress_ratio, num_feat, 3, 1, 1),
+            ChannelAttention(num_feat, squeeze_factor),
+        )
+
+
+class WindowAttention(nn.Module):
+    """hat.py:55-83 (no index buffer: HAT keeps it at model level)."""
+
+    def __init__(self, dim: int, window_size: int, num_heads: int) -> None:
+        super().__init__()
+        ws = window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class HAB(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, compress_ratio, squeeze_factor, conv_scale) -> None:
+        super().__init__()
+        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        self.shift_size, self.conv_scale = shift_size, conv_scale
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads)
+        self.conv_block = CAB(dim, compress_ratio, squeeze_factor)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MlpParams(dim, int(dim * mlp_ratio))
+
+
+class OCAB(nn.Module):
+    def __init__(self, dim, num_heads, window_size, mlp_ratio, overlap_ratio) -> None:
+        super().__init__()
+        self.overlap_win_size = int(window_size * overlap_ratio) + window_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.qkv = nn.Linear(dim, dim * 3)
+        n = window_size + self.overlap_win_size - 1
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(n * n, num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.proj = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MlpParams(dim, int(dim * mlp_ratio))
+
+
+class AttenBlocks(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, compress_ratio, squeeze_factor, conv_scale, overlap_ratio) -> None:
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            [HAB(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio, compress_ratio, squeeze_factor, conv_scale) for i in range(depth)]
+        )
+        self.overlap_attn = OCAB(dim, num_heads, window_size, mlp_ratio, overlap_ratio)
+
+
+class RHAG(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, compress_ratio, squeeze_factor, conv_scale, overlap_ratio) -> None:
+        super().__init__()
+        self.residual_group = AttenBlocks(dim, depth, num_heads, window_size, mlp_ratio, compress_ratio, squeeze_factor, conv_scale, overlap_ratio)
+        self.conv = nn.Conv2d(dim, dim, 3, 1, 1)
+
+
+def rpi_sa(ws: int) -> Tensor:
+    """hat.py:480-492."""
+    ys, xs = torch.div(torch.arange(ws * ws), ws, rounding_mode="floor"), torch.arange(ws * ws) % ws
+    return (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
+
+
+def rpi_oca(ws: int, overlap_ratio: float) -> Tensor:
+    """hat.py:494-517 (entries may be negative: the table is indexed python-style, i.e. they wrap)."""
+    wse = ws + int(overlap_ratio * ws)
+    qy, qx = torch.div(torch.arange(ws * ws), ws, rounding_mode="floor"), torch.arange(ws * ws) % ws
+    ky, kx = torch.div(torch.arange(wse * wse), wse, rounding_mode="floor"), torch.arange(wse * wse) % wse
+    dy = ky[None, :] - qy[:, None] + ws - wse + 1
+    dx = kx[None, :] - qx[:, None] + ws - wse + 1
+    return dy * (ws + wse - 1) + dx
+
+
+class HAT(Model):
+    def __init__(
+        self,
+        scale: int = 4,
+        n_colors: int = 3,
+        img_range: float = 1.0,
+        embed_dim: int = 180,
+        depths: List[int] = [6, 6, 6, 6, 6, 6],
+        num_heads: List[int] = [6, 6, 6, 6, 6, 6],
+        window_size: int = 16,
+        mlp_ratio: float = 2.0,
+        drop_rate: float = 0.0,
+        attn_drop_rate: float = 0.0,
+        drop_path_rate: float = 0.1,
+        compress_ratio: int = 3,
+        squeeze_factor: int = 30,
+        conv_scale: float = 0.01,
+        overlap_ratio: float = 0.5,
+    ) -> None:
+        super().__init__(scale, n_colors, img_range)
+        assert n_colors == 3, "Normalizer mean has 3 channels (common.py:223)"
+        self.embed_dim, self.depths, self.num_heads, self.window_size, self.mlp_ratio = embed_dim, depths, num_heads, window_size, mlp_ratio
+        self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        self.compress_ratio, self.squeeze_factor, self.conv_scale, self.overlap_ratio = compress_ratio, squeeze_factor, conv_scale, overlap_ratio
+        self.shift_size = window_size // 2
+        self.register_buffer("relative_position_index_SA", rpi_sa(window_size))
+        self.register_buffer("relative_position_index_OCA", rpi_oca(window_size, overlap_ratio))
+        self.conv_first = nn.Conv2d(n_colors, embed_dim, 3, 1, 1)
+        self.patch_embed = PatchEmbed(embed_dim)
+        self.layers = nn.ModuleList(
+            [RHAG(embed_dim, depths[i], num_heads[i], window_size, mlp_ratio, compress_ratio, squeeze_factor, conv_scale, overlap_ratio) for i in range(len(depths))]
+        )
+        self.norm = nn.LayerNorm(embed_dim)
+        self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
+        num_feat = 64
+        self.conv_before_upsample = nn.Sequential(nn.Conv2d(embed_dim, num_feat, 3, 1, 1), nn.LeakyReLU(inplace=True))
+        self.upsample = Upsampler(scale, num_feat)
+        self.conv_last = nn.Conv2d(num_feat, n_colors, 3, 1, 1)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m: nn.Module) -> None:  # hat.py:471-478
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ packing
+    def _geo(self, li: int) -> SwinGeometry:
+        return SwinGeometry(self.embed_dim, self.num_heads[li], self.window_size, int(self.embed_dim * self.mlp_ratio))
+
+    def _pack(self, dt: torch.dtype) -> Dict:
+        C = self.embed_dim
+        Cp = self._geo(0).Cp
+        dev = self.conv_first.weight.device
+        ws = self.window_size
+        wse = ws + int(self.overlap_ratio * ws)
+        nk = wse * wse
+        nk_pad = packing.round_up(nk, 32)
+        c3 = C // self.compress_ratio
+        c3p = packing.round_up(c3, 32)
+        ident = packing.identity_idx(C, Cp)
+        P: Dict = dict(Cp=Cp, c3p=c3p, wse=wse, nk_pad=nk_pad, pad=(wse - ws) // 2)
+        P["border"] = packing.round_up(P["pad"], 4)
+        P["first"] = packing.pack_conv3x3(self.conv_first.weight, self.conv_first.bias, 32, ident, dt)
+        P["pe_norm"] = pack_ln(self.patch_embed.norm, Cp)
+        P["layers"] = []
+        for li, layer in enumerate(self.layers):
+            geo = self._geo(li)
+            if geo.hd_p != 32:
+                raise NotImplementedError("HAT HIP path supports head_dim <= 32")
+            blocks = []
+            for blk in layer.residual_group.blocks:
+                e = dict(shift=blk.shift_size, ln1=pack_ln(blk.norm1, Cp), ln2=pack_ln(blk.norm2, Cp))
+                e.update(pack_attention(blk.attn, geo, dt, rpi=self.relative_position_index_SA, norm=blk.norm1))
+                e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
+                cab = blk.conv_block.cab
+                e["cab1"] = packing.pack_conv3x3(cab[0].weight, cab[0].bias, Cp, packing.identity_idx(c3, c3p), dt)
+                e["cab2"] = packing.pack_conv3x3(cab[2].weight, cab[2].bias, c3p, ident, dt)
+                att = cab[3].attention
+                e["ca"] = pack_ca(att[1].weight, att[1].bias, att[3].weight, att[3].bias)
+                blocks.append(e)
+            oc = layer.residual_group.overlap_attn
+            o = dict(ln1=pack_ln(oc.norm1, Cp), ln2=pack_ln(oc.norm2, Cp))
+            o.update(pack_attention(oc, geo, dt, rpi=self.relative_position_index_SA, norm=oc.norm1))  # qkv / proj packing (bias replaced below)
+            ob = packing.gather_bias(oc.relative_position_bias_table, self.relative_position_index_OCA, geo.ntok, nk)  # [heads, nq, nk], negative idx wrap
+            obp = torch.zeros(ob.shape[0], ob.shape[1], nk_pad, dtype=torch.float32, device=ob.device)
+            obp[:, :, :nk] = ob
+            o["oca_bias"] = obp.contiguous()
+            o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
+            conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, ident, dt)
+            P["layers"].append(dict(blocks=blocks, ocab=o, conv=conv, geo=geo))
+        P["norm"] = pack_ln(self.norm, Cp)
+        P["after_body"] = packing.pack_conv3x3(self.conv_after_body.weight, self.conv_after_body.bias, Cp, ident, dt)
+        P["fin"] = final_affine(self.img_range, self.n_colors, dev)
+        P["ing"] = ingest_affine(self.img_range, self.n_colors, dev)
+        cbu = self.conv_before_upsample[0]
+        P["before_up"] = packing.pack_conv3x3(cbu.weight, cbu.bias, Cp, packing.identity_idx(64, 64), dt)
+        P["up"] = pack_upsampler(self.upsample, 64, dt)
+        P["last"] = packing.pack_conv3x3(self.conv_last.weight, self.conv_last.bias, 64, packing.identity_idx(self.n_colors, 16), dt)
+        return P
+
+    # ------------------------------------------------------------------ blocks
+    def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt) -> None:
+        """t = HAB(t_in); t_in may be t (in place)."""
+        B, H, W, Cp = t_in.shape
+        f32 = torch.float32
+        # conv branch on LayerNorm1(x)  (hat.py:165-170)
+        n1 = ws_.get("hab.n1", (B, H, W, Cp), f32)
+        ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+        mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
+        conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
+        y = ws_.get("hab.y", (B, H, W, Cp), f32)
+        n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt))
+        pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
+        conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
+        # attention branch + shortcut -> t   (hat.py:172-188)
+        run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab")
+        # x = shortcut + attn + conv_scale * CA(cab)   (hat.py:192)
+        run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
+        run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")
+
+    def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt) -> None:
+        """t = OCAB(t) in place (hat.py:239-293)."""
+        B, H, W, Cp = t.shape
+        M = B * H * W
+        nb = M // geo.ntok
+        sdt = sr_dtype(cdt)
+        e = P["border"]
+        q = ws_.get("oca.q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
+        k = ws_.get("oca.k", (B, H + 2 * e, W + 2 * e, geo.heads, geo.hd_p), cdt)  # zero border: allocated zeroed, border never written
+        vt = ws_.get("oca.vt", (B, geo.heads, geo.hd_p, H + 2 * e, W + 2 * e), cdt)  # 5-D key: the zero border must never alias another geometry
+        o = ws_.get("oca.o", (M, geo.HP), cdt)
+        fold = fold_ln(cdt)
+        ops.gemm(
+            A=t.data_ptr(), Wp=op["qkv_w"].data_ptr(), bias=op["qkv_b"].data_ptr(), ln_gamma=None if fold else op["ln1"][0].data_ptr(),
+            ln_beta=None if fold else op["ln1"][1].data_ptr(), ln_norm_only=int(fold), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(),
+            M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp, a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
+            a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=H, W=W, ws=geo.ws, shift=0, epi=L.EPI_QKV_OCA, heads=geo.heads, hd_p=geo.hd_p,
+            ntok=geo.ntok, ln_eps=1e-5, oca_pad=e,
+        )
+        ops.oca_attention(
+            q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=op["oca_bias"].data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=geo.heads,
+            hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt,
+        )
+        ops.gemm(
+            A=o.data_ptr(), Wp=op["proj_w"].data_ptr(), bias=op["proj_b"].data_ptr(), out=t.data_ptr(), skip=t.data_ptr(), M=M, K=geo.HP, N=Cp,
+            lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
+            a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=0, epi=L.EPI_STD,
+        )
+        run_mlp(op, op["ln2"], geo, t, ws_, cdt, name="oca")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor) -> Tensor:
+        x = self._check_input(x)
+        cdt = compute_dtype(self.precision)
+        P = self._get_packed(cdt)
+        ws_ = self._workspace(x.device)
+        B, _, H, W = x.shape
+        w = self.window_size
+        Hp, Wp = H + (w - H % w) % w, W + (w - W % w) % w  # check_image_size: reflect pad (hat.py:544)
+        if Hp - H >= H or Wp - W >= W:
+            raise RuntimeError("Padding size should be less than the corresponding input dimension (reflect pad)")
+        Cp = P["Cp"]
+        f32 = torch.float32
+        xin = ws_.get("xin", (B, Hp, Wp, 32), cdt)
+        ops.ingest_nchw(x, xin, L.PAD_REFLECT if (Hp != H or Wp != W) else L.PAD_NONE, *P["ing"])
+        first = ws_.get("first", (B, Hp, Wp, Cp), f32)
+        conv_call(xin, *P["first"], first, cdt)
+        ta = ws_.get("ta", (B, Hp, Wp, Cp), f32)
+        tb = ws_.get("tb", (B, Hp, Wp, Cp), f32)
+        ops.layernorm(first, ta, *P["pe_norm"], self.embed_dim)
+        for lp in P["layers"]:
+            geo = lp["geo"]
+            cur = ta
+            for bp in lp["blocks"]:
+                self._run_hab(bp, geo, P, cur, tb, ws_, cdt)
+                cur = tb
+            if cur is ta:
+                tb.copy_(ta)
+            self._run_ocab(lp["ocab"], geo, P, tb, ws_, cdt)
+            conv_call(tb, *lp["conv"], ta, cdt, skip=ta)  # ta = conv(group(ta)) + ta  (hat.py:385)
+        ops.layernorm(ta, tb, *P["norm"], self.embed_dim)
+        body = ws_.get("body", (B, Hp, Wp, Cp), cdt)
+        conv_call(tb, *P["after_body"], body, cdt, skip=first)
+        feat = ws_.get("feat", (B, Hp, Wp, 64), cdt)
+        conv_call(body, *P["before_up"], feat, cdt, act=L.ACT_LRELU)
+        up = run_upsampler(P["up"], feat, ws_, cdt, "hat")
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=f32, device=x.device)
+        conv_call(up, *P["last"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(*P["fin"], self.n_colors, H * s, W * s), cout_p=16)
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def get_model_config(self) -> Dict:
+        config = super().get_model_config()
+        config.update(
+            dict(
+                embed_dim=self.embed_dim, depths=self.depths, num_heads=self.num_heads, window_size=self.window_size, mlp_ratio=self.mlp_ratio,
+                drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate, drop_path_rate=self.drop_path_rate,
+                compress_ratio=self.compress_ratio, squeeze_factor=self.squeeze_factor, conv_scale=self.conv_scale, overlap_ratio=self.overlap_ratio,
+            )
+        )
+        return config
+
+    @classmethod
+    def from_pretrained(cls, scale: int = 4) -> "HAT":
+        """hat.py:576-593: HAT_SRx{scale}.pth (key params_ema), read from ./pretrained (no network here)."""
+        path = os.path.join("pretrained", f"HAT_SRx{scale}.pth")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found (no network access here; place the official checkpoint there)")
+        model = cls(scale=scale)
+        model.load_state_dict(torch.load(path, map_location="cpu")["params_ema"])
+        return model

@@ -90,6 +90,13 @@ def window_attention(**kw) -> None:
     L.check(L.lib().sr_window_attention(C.byref(a), _stream()), "sr_window_attention")
 
 
+def oca_attention(**kw) -> None:
+    a = L.SrOcaAttn()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_oca_attention(C.byref(a), _stream()), "sr_oca_attention")
+
+
 def channel_attention(**kw) -> None:
     a = L.SrChannelAttn()
     for k, v in kw.items():
