@@ -26,7 +26,7 @@ def compute_dtype(precision: str) -> torch.dtype:
     fp32 residual stream / LayerNorm / softmax), or 'auto' = bf16 under torch.autocast(bfloat16) as in the
     reference Trainer (studiosr/engine/trainer.py:80,102), fp32 otherwise."""
     if precision == "auto":
-        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             return torch.bfloat16
         return torch.float32
     if precision == "bf16":

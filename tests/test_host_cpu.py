@@ -1,0 +1,147 @@
+"""CPU-side tests of the host logic: C-ABI library loads and exports what include/studiosr_hip.h declares, weight
+packing is a pure (invertible) index shuffle, model classes mirror the reference's state_dict, and the product refuses
+to run without a GPU (no CPU fallback)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT, golden_cfg, golden_sd, load_golden
+
+import studiosr_amd as S
+from studiosr_amd import _lib as L
+from studiosr_amd import packing
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "studiosr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as G
+
+    if not os.path.exists(L.LIB_PATH):
+        G.build()
+    lib = L.lib()
+    names = header_symbols()
+    assert names, "no symbols parsed from the header"
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/studiosr_hip.h but not exported"
+        assert n in L.SYMBOLS, f"{n} has no ctypes prototype in studiosr_amd/_lib.py"
+    assert sorted(L.SYMBOLS) == names
+    assert lib.sr_abi_version() == 1
+
+
+def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof() of every argument struct."""
+    import subprocess
+
+    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn"]
+    c = tmp_path / "sz.c"
+    c.write_text('#include <stdio.h>\n#include "studiosr_hip.h"\nint main(){' + "".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    import ctypes
+
+    for s in structs:
+        assert int(out[s]) == ctypes.sizeof(getattr(L, s)), s
+
+
+def test_fragment_packing_is_an_index_shuffle():
+    torch.manual_seed(0)
+    w = torch.randn(48, 96)
+    frag = packing.to_fragments(w, torch.float32).reshape(48 // 16, 96 // 32, 64, 8)
+    for (nt, kc, lane, j) in [(0, 0, 0, 0), (2, 1, 37, 5), (1, 2, 63, 7), (0, 2, 16, 3)]:
+        assert frag[nt, kc, lane, j] == w[16 * nt + (lane & 15), 32 * kc + 8 * (lane >> 4) + j]
+    assert torch.equal(torch.sort(frag.reshape(-1))[0], torch.sort(w.reshape(-1))[0])
+
+
+def test_pixel_shuffle_rows_and_bias_fragments():
+    rows = packing.pixel_shuffle_rows(3, 4, 2)  # packed row (i*r+j)*cps_p + c  <-  c*r*r + i*r + j
+    assert rows.tolist() == [0, 4, 8, -1, 1, 5, 9, -1, 2, 6, 10, -1, 3, 7, 11, -1]
+    b = torch.arange(2 * 64 * 64, dtype=torch.float32).reshape(2, 64, 64)
+    fr = packing.bias_fragments(b).reshape(2, 4, 4, 64, 4)
+    for (h, qt, kt, lane, r) in [(0, 0, 0, 0, 0), (1, 3, 2, 45, 3), (0, 2, 1, 17, 1)]:
+        assert fr[h, qt, kt, lane, r] == b[h, 16 * qt + (lane & 15), 16 * kt + 4 * (lane >> 4) + r]
+
+
+def test_layernorm_folding_is_exact_algebra():
+    torch.manual_seed(1)
+    x = torch.randn(7, 20, dtype=torch.float64)
+    w, b = torch.randn(12, 20, dtype=torch.float64), torch.randn(12, dtype=torch.float64)
+    g, be = torch.randn(20, dtype=torch.float64), torch.randn(20, dtype=torch.float64)
+    ref = F.linear(F.layer_norm(x, (20,), g, be, 1e-5), w, b)
+    wf, bf = packing.fold_layernorm(w.float(), b.float(), g.float(), be.float())
+    xn = F.layer_norm(x, (20,), None, None, 1e-5)
+    torch.testing.assert_close(F.linear(xn, wf.double(), bf.double()), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_bias_wraps_negative_indices_like_python():
+    table = torch.arange(10.0).reshape(5, 2)
+    rpi = torch.tensor([[-1, 0], [4, -5]])
+    out = packing.gather_bias(table, rpi, 2, 2)  # [heads, 2, 2]
+    assert torch.equal(out[0], table[rpi.reshape(-1), 0].reshape(2, 2))
+
+
+WHOLE = [("f11_swinir_x4", "SwinIR"), ("f11_swinir_direct_x4", "SwinIR"), ("f11_edsr_x3", "EDSR"), ("f11_rcan_x4", "RCAN"),
+         ("f11_hat_w8_x4", "HAT"), ("f11_hat_w16_x2", "HAT")]
+
+
+@pytest.mark.parametrize("name,kind", WHOLE)
+def test_model_surface_matches_reference(name, kind):
+    """Same kwargs -> same state_dict keys / shapes / integer buffers and the same get_model_config()."""
+    g = load_golden(name)
+    cfg, sd = golden_cfg(g), golden_sd(g)
+    m = getattr(S, kind)(**cfg)
+    own = m.state_dict()
+    assert sorted(own) == sorted(sd)
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+        if not v.is_floating_point():
+            assert torch.equal(own[k], v), k
+    m.load_state_dict(sd)  # strict
+    assert m.get_model_config() == cfg
+    assert json.dumps(m.get_model_config())  # JSON-serialisable like the reference's params.json
+    assert (m.scale, m.n_colors, m.img_range) == (cfg["scale"], cfg["n_colors"], cfg["img_range"])
+
+
+def test_training_configs_match_reference_literals():
+    assert S.SwinIR(embed_dim=60, depths=[1], num_heads=[6]).get_training_config()["milestones"] == [250000, 400000, 450000, 475000]
+    assert S.EDSR(n_feats=32, n_resblocks=1).get_training_config()["batch_size"] == 16
+    assert S.RCAN(n_feats=32, n_resblocks=1, n_resgroups=1).get_training_config()["learning_rate"] == 0.0001
+    assert S.HAT(embed_dim=60, depths=[1], num_heads=[6], window_size=8).get_training_config() == {}
+
+
+def test_no_cpu_fallback():
+    m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).eval()
+    with pytest.raises(L.HipLibraryError):
+        m(torch.rand(1, 3, 8, 8))
+    with pytest.raises(L.HipLibraryError):
+        m.inference(np.zeros((8, 8, 3), np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "studiosr_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the test oracle"
+
+
+def test_tile_partition():
+    from studiosr_amd.parallel import tile_partition
+
+    assert tile_partition(8, 3) == [(0, 3), (3, 6), (6, 8)]
+    assert tile_partition(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    for n in range(0, 20):
+        for w in (1, 2, 3, 8):
+            parts = tile_partition(n, w)
+            assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
