@@ -10,7 +10,7 @@ one rank per GPU) every rank processes its own batch of 8 tiles -- tiles are ind
 data-path collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
 
 The JSON line also carries
-  roofline      dominant kernel (the LayerNorm+GEMM row kernel `sr_gemm_kernel`) vs the bf16 MFMA peak,
+  roofline      dominant kernel (the fused window-attention kernel `sr_swin_attn_kernel`) vs the bf16 MFMA peak,
                 timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this
                 host's cores on a bounded sample of the same workload.
@@ -49,36 +49,25 @@ def build_model(device):
     return model.to(device).set_precision("bf16")
 
 
-def time_dominant_kernel(model, x, iters: int = 30):
-    """Average duration of ONE launch of the dominant kernel shape (LN1 + QKV projection of one block:
-    M = 8*72*72 window-gathered rows, K = 192, N = 576) measured with HIP events on the launch stream,
-    plus its algorithmic FLOPs."""
-    import studiosr_amd._lib as L
-    from studiosr_amd import ops
-    from studiosr_amd.runtime import sr_dtype
+def time_dominant_kernel(model, x, iters: int = 50):
+    """Average duration of ONE launch of the dominant kernel, `sr_swin_attn_kernel` (LayerNorm1 + QKV + shifted-window
+    attention + proj + residual of one block at the bench shape: 648 windows = 41,472 tokens), timed with HIP events
+    on the launch stream (torch's current stream is the stream the C-ABI call enqueues on), and its ALGORITHMIC FLOPs:
+    2*MAC of qkv (180->540), QK^T + AV (6 heads x 64 x 64 x 30) and proj (180->180) per token = 305,280 FLOP
+    (194,400 + 46,080 + 64,800)."""
+    from studiosr_amd.models import swinir as SW
 
     cdt = torch.bfloat16
     P = model._get_packed(cdt)
     ws_ = model._workspace(x.device)
     lp = P["layers"][0]
-    geo, bp = lp["geo"], lp["blocks"][1]
+    geo, bp = lp["geo"], lp["blocks"][1]  # a shifted block (mask path included)
     B = x.shape[0]
-    t_in = ws_.get("ta", (B, PADDED, PADDED, geo.Cp), torch.float32)
-    M = B * PADDED * PADDED
-    nb = M // geo.ntok
-    q = ws_.get("msa.q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
-    k = ws_.get("msa.k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
-    vt = ws_.get("msa.vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
-    sdt = sr_dtype(cdt)
+    t = ws_.get("ta", (B, PADDED, PADDED, geo.Cp), torch.float32)
+    o = ws_.get("tb", (B, PADDED, PADDED, geo.Cp), torch.float32)
 
     def launch():
-        ops.gemm(
-            A=t_in.data_ptr(), Wp=bp["qkv_w"].data_ptr(), bias=bp["qkv_b"].data_ptr(), ln_norm_only=1,
-            out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=geo.Cp, N=3 * geo.HP,
-            k_real=geo.C, lda=geo.Cp, a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
-            a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=PADDED, W=PADDED, ws=geo.ws, shift=bp["shift"], epi=L.EPI_QKV,
-            heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5,
-        )
+        SW.run_window_msa(bp, bp["ln1"], geo, t, o, t, ws_, cdt, bp["shift"])
 
     for _ in range(5):
         launch()
@@ -90,7 +79,7 @@ def time_dominant_kernel(model, x, iters: int = 30):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * geo.C * 3 * geo.C  # algorithmic: 180 -> 540, un-padded
+    flops = float(B * PADDED * PADDED) * 305_280.0
     return ms, flops
 
 
@@ -103,7 +92,8 @@ def cpu_baseline_and_parity(model, device):
     cfg = model.get_model_config()
     g = torch.Generator().manual_seed(0)
     x = torch.rand(CPU_SAMPLE_TILES, 3, TILE, TILE, generator=g)
-    cores = torch.get_num_threads()
+    cores = max(1, min(int(os.environ.get("SR_CPU_THREADS", "16")), os.cpu_count() or 1))  # the GPU box gives one GPU ~16 host cores
+    torch.set_num_threads(cores)
     with torch.inference_mode():
         OM.swinir_forward(sd, x[:1], cfg)  # warm-up
         t0 = time.perf_counter()
@@ -199,7 +189,7 @@ def main() -> None:
         fwd_flops = BATCH * PADDED * PADDED * FLOP_PER_LR_PIXEL  # per GPU per step, reference semantics (padded tile)
         fwd_tflops = fwd_flops / (ms_per_step * 1e-3) / 1e12
         roof = dict(
-            bound="mfma", kernel="sr_gemm_kernel<bf16,float,3> (LN1 + QKV projection, M=41472 K=180 N=540)",
+            bound="mfma", kernel="sr_swin_attn_kernel (LN1 + QKV + shifted-window attention + proj + residual, 648 windows x 64 tokens)",
             achieved=round(achieved, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
             traffic=None, kernel_ms=round(k_ms, 5),
             forward=dict(achieved=round(fwd_tflops, 2), frac=round(fwd_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
