@@ -132,6 +132,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--inflight", type=int, default=2, help="independent batches in flight per GPU (one HIP graph + stream + workspace each)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,13 +155,51 @@ def main() -> None:
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(BATCH, 3, TILE, TILE, generator=g).to(device)
 
-    def fwd(inp):
+    def fwd_m(m, inp):
         with torch.no_grad():
-            return model(inp)
+            return m(inp)
 
-    step = fwd if args.no_graph else GraphedForward(fwd, x)
-    for _ in range(args.warmup):
-        step(x)
+    def fwd(inp):
+        return fwd_m(model, inp)
+
+    # `inflight` independent pipelines (own module copy = own workspace, own HIP graph, own stream): a batch of 8 tiles is
+    # 648 windows on 256 CUs, so the tail of one step's kernels leaves CUs idle that the next step's kernels can use.
+    n_pipe = 1 if args.no_graph else max(1, args.inflight)
+    if args.no_graph:
+        pipes = [(fwd, torch.cuda.current_stream())]
+    else:
+        from studiosr_amd.runtime import Workspace
+
+        pipes = []
+        for i in range(n_pipe):
+            ws_i = Workspace(device)  # weights are shared; every pipeline owns its activations
+
+            def fwd_i(inp, ws_i=ws_i):
+                model._ws = ws_i
+                return fwd(inp)
+
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                gf = GraphedForward(fwd_i, x)
+            pipes.append((gf, st, ws_i))  # the graph holds raw pointers into ws_i: keep it alive with the pipeline
+            if os.environ.get("SR_BENCH_SERIAL"):
+                torch.cuda.synchronize()
+                print(f"[bench] pipeline {i} captured", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+
+    def run_steps(n):
+        for i in range(n):
+            f, st = pipes[i % len(pipes)][:2]
+            if args.no_graph:
+                f(x)
+            else:
+                with torch.cuda.stream(st):
+                    f.replay()
+                if os.environ.get("SR_BENCH_SERIAL"):
+                    torch.cuda.synchronize()
+                    print(f"[bench] step {i} on pipeline {i % len(pipes)} done", file=sys.stderr, flush=True)
+
+    run_steps(args.warmup)
 
     def barrier():
         if world > 1:
@@ -169,8 +208,7 @@ def main() -> None:
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(x)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -210,7 +248,7 @@ def main() -> None:
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "SwinIR x4 (embed 180, 6x6 blocks, ws 8) eval forward, 64x64 LR tiles, batch 8 per GPU",
-                       "tiles_per_step": world * BATCH, "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "tiles_per_step": world * BATCH, "launch": "eager" if args.no_graph else "hipGraph replay", "batches_in_flight": len(pipes)},
             "roofline": roof,
         }
         if not args.skip_cpu and world == 1:

@@ -82,12 +82,21 @@ typedef struct SrSwinAttn {
     const float* x;       /* [B,H,W,ldx] fp32 stream */
     float* out;
     const void* wqkv;     /* packed [3*heads*hd_p x Cp] bf16: LayerNorm affine folded in, q rows pre-scaled */
-    const float* bqkv;    /* [3*heads*hd_p] */
+    const float* bqkv;    /* [3*heads*hd_p]; only the q third is read: the k bias cancels in the softmax and the v bias
+                           * must be folded into bproj (bproj' = bproj + Wproj b_v), see models/swinir.py pack_attention */
     const void* wproj;    /* packed [Cp x heads*hd_p] bf16 */
-    const float* bproj;   /* [Cp] */
+    const float* bproj;   /* [Cp] (with W_proj b_v folded in) */
     const float* bias;    /* relative-position bias in fragment order [heads][qt][kt][lane][4] (packing.bias_fragments) */
     int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift;
     float eps;
+    /* optional MLP tail: when w1p != NULL the kernel continues with out += fc2(GELU(fc1(LayerNorm2(out)))) on the same
+     * tokens (the WHOLE SwinTransformerBlock, swinir.py:146-174, in one launch; x1 never leaves the CU).  LayerNorm2's
+     * affine must be folded into w1p / b1. */
+    const void* w1p;      /* packed fc1 [Hp x Cp] bf16 or NULL */
+    const float* b1;      /* [Hp] */
+    const void* w2p;      /* packed fc2 [Cp x Hp] bf16 */
+    const float* b2;      /* [Cp] */
+    int Hp;               /* 384 */
 } SrSwinAttn;
 int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype);
 int sr_swin_attn_fused(const SrSwinAttn* a, void* stream);

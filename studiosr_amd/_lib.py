@@ -43,7 +43,7 @@ class SrSwinAttn(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("bias", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
-        ("eps", _f),
+        ("eps", _f), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("Hp", _i),
     ]
 
 

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = wave_max_xor(mx, 16);
+        mx = wave_max_xor(mx, 32);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
                 s[kt][t][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = wave_sum_xor(sum, 16);
+        sum = wave_sum_xor(sum, 32);
         inv_sum[t] = 1.0f / sum;
     }
 

@@ -223,7 +223,47 @@ struct WinMap {
     }
 };
 
-SR_DEV float wave_sum_xor(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+// Cross-lane butterfly steps without the LDS crossbar (ds_bpermute costs a full LDS round trip per step and sat on the
+// critical path of every LayerNorm / softmax): lane ^ 32 and lane ^ 16 via v_permlane{32,16}_swap (gfx950), lane ^ 8 via
+// DPP row_ror:8.  The swap builtins mis-compile when both operands are the same value (ROCm 7.2), hence inline asm; the
+// s_nop covers the VALU-write -> permlane-read hazard (2 wait states).
+SR_DEV void lane_xor32_pair(float x, float& a, float& b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+SR_DEV void lane_xor16_pair(float x, float& a, float& b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+SR_DEV float wave_sum_xor(float v, int mask) {  // mask is a literal at every call site
+    if (mask == 32) {
+        float a, b;
+        lane_xor32_pair(v, a, b);
+        return a + b;
+    }
+    if (mask == 16) {
+        float a, b;
+        lane_xor16_pair(v, a, b);
+        return a + b;
+    }
+    if (mask == 8) return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    return v + __shfl_xor(v, mask, 64);
+}
+SR_DEV float wave_max_xor(float v, int mask) {
+    if (mask == 32) {
+        float a, b;
+        lane_xor32_pair(v, a, b);
+        return fmaxf(a, b);
+    }
+    if (mask == 16) {
+        float a, b;
+        lane_xor16_pair(v, a, b);
+        return fmaxf(a, b);
+    }
+    return fmaxf(v, __shfl_xor(v, mask, 64));
+}
 
 // Exact unsigned division by a run-time constant (Granlund-Montgomery round-up method); the
 // multiplier is computed on the host so that no kernel executes an integer divide.

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void sr_oca_kernel(SrOcaAttn a) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = wave_max_xor(mx, 16);
+    mx = wave_max_xor(mx, 32);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void sr_oca_kernel(SrOcaAttn a) {
             s[kt][r] = e;
             sum += e;
         }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = wave_sum_xor(sum, 16);
+    sum = wave_sum_xor(sum, 32);
     const float inv_sum = 1.0f / sum;
 
     // ---- O^T = V^T P^T ; K-slot (lane group g, element j) of step ks <-> key 32 ks + 16 (j >> 2) + 4 g + (j & 3)

@@ -4,7 +4,7 @@
 // into addressing).  The fp32 stream is read ONCE and written ONCE; q, k, v, the logits and the
 // attention output never leave the CU.
 //
-// One workgroup = one 8x8 window (64 tokens), 6 waves; wave h OWNS HEAD h end to end:
+// One workgroup = two 8x8 windows (2 x 64 tokens), 12 waves; wave (w, h) OWNS HEAD h of window w end to end:
 //   S0  every wave loads its 64 x 32-column slice of x in accumulator layout (it stays in registers
 //       as the residual), LayerNorm statistics are combined across waves through 3 KiB of LDS,
 //       normalised bf16 rows go to the K-group-major LDS image                        | 3 barriers
@@ -17,7 +17,7 @@
 //   S3  O -> LDS (bf16, natural feature order)                                        | barrier
 //       proj for output columns [32h, 32h+32) on top of the residual registers, 16-byte stores
 //       scattered back through the window map.
-// 48 KiB LDS and <= 168 VGPRs -> two workgroups (12 waves) per CU.
+// 2 x 75 KiB LDS and <= 168 VGPRs -> one 12-wave workgroup = 3 waves on every SIMD of a CU.
 #include "sr_common.cuh"
 #include "sr_host.h"
 
@@ -41,103 +41,132 @@ SR_DEV Frag<bf16> pack2(const f32x4& lo, const f32x4& hi) {
 }
 
 // Specialised for Cp = 192, heads = 6, hd_p = 32, ws = 8 (SwinIR / HAT-w8 default geometry).
-__global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
-    constexpr int NTOK = 64, KC = 6, HEADS = 6, WS = 8, RING = 3;
+//
+// Register budget (<= 168 VGPRs so that two 6-wave workgroups always fit a CU; round 1 measured 140 B/lane of spills
+// = +64 MB of HBM traffic per launch when the residual slice lived in registers): the fp32 residual slice is parked in
+// LDS between LayerNorm and the proj epilogue, the attention output reuses the LayerNorm image (one extra barrier),
+// q / k / v run as three 32-column passes, the attention core handles one 16-query tile at a time, and the weight
+// stream is a 5-slot x 2-fragment ring that runs 4 chunks (~512 cycles) ahead through q, k, v and proj.
+template <bool MLP>
+__global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
+    constexpr int NTOK = 64, KC = 6, HEADS = 6, WS = 8, RING = 6;
     const SrSwinAttn& a = dv.a;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<bf16>* Aimg = reinterpret_cast<Frag<bf16>*>(smem);   // [24][64] LayerNorm1(x)
-    Frag<bf16>* Oimg = Aimg + KC * 4 * NTOK;                   // [24][64] attention output
-    float* red = reinterpret_cast<float*>(Oimg + KC * 4 * NTOK);  // [2][64][6] LayerNorm partials
+    // One workgroup = TWO windows (12 waves = exactly 3 per SIMD): two independent 6-wave workgroups at 3 waves per SIMD
+    // only co-reside when the hardware happens to start the second one on the right SIMD (measured: it mostly does not).
+    constexpr int LDS_PER_WINDOW = 24 * 64 * 16 + 6 * 8 * 64 * 16 + 64 * 6 * 2 * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave_all >= HEADS ? 1 : 0;
+    char* smem = smem_all + pair * LDS_PER_WINDOW;
+    Frag<bf16>* Aimg = reinterpret_cast<Frag<bf16>*>(smem);                       // [24][64] LayerNorm1(x), later the attention output
+    f32x4* stash = reinterpret_cast<f32x4*>(Aimg + KC * 4 * NTOK);                // [6 waves][8][64 lanes] residual slice (fp32)
+    float* red = reinterpret_cast<float*>(stash + HEADS * 8 * 64);                // [64][6][2] LayerNorm partial sums
 
     const int lane = threadIdx.x & 63;
-    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave = head
+    const int h = wave_all - pair * HEADS;  // wave = (window of the pair, head)
     const int ar = lane & 15, ag = lane >> 4;
-
     STAMP(0);
+
     // ---- window geometry
     uint32_t bimg, win, wy, wx;
-    dv.div_nw.divmod(blockIdx.x, bimg, win);
+    const int n_windows = a.B * (a.H / WS) * (a.W / WS);
+    int widx = blockIdx.x * 2 + pair;
+    const bool live = widx < n_windows;  // odd window count: the last workgroup's second half recomputes a window and stores nothing
+    if (!live) widx = n_windows - 1;
+    dv.div_nw.divmod((uint32_t)widx, bimg, win);
     dv.div_nwx.divmod(win, wy, wx);
-    int pix[4];  // image-order row of token 16m + ar (roll + partition as one gather)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int t = m * 16 + ar;
+    auto pixel_row = [&](int m) {  // image-order row of token 16m + ar (roll + partition as one gather); recomputed at
+        const int t = m * 16 + ar;  // both ends of the kernel instead of holding 4 addresses in registers throughout
         int y = wy * WS + (t >> 3) + a.shift;
         int x = wx * WS + (t & 7) + a.shift;
         if (y >= a.H) y -= a.H;
         if (x >= a.W) x -= a.W;
-        pix[m] = ((int)bimg * a.H + y) * a.W + x;
-    }
+        return ((int)bimg * a.H + y) * a.W + x;
+    };
 
-    // ---- weight stream: 2 n-tiles x 6 K-chunks for each of q, k, v, proj (positions 0..23), 3-slot register ring
-    const Frag<bf16>* Wq = reinterpret_cast<const Frag<bf16>*>(a.wqkv) + lane;
-    const Frag<bf16>* Wp = reinterpret_cast<const Frag<bf16>*>(a.wproj) + lane;
+    // ---- weight stream: 2 n-tiles x 6 K-chunks for each of q, k, v, proj = positions 0..23; slot = t % RING
+    // (uniform fragment base in SGPRs + lane offset in one VGPR: no per-fragment 64-bit address registers)
+    const Frag<bf16>* Wq = reinterpret_cast<const Frag<bf16>*>(a.wqkv);
+    const Frag<bf16>* Wp = reinterpret_cast<const Frag<bf16>*>(a.wproj);
     Frag<bf16> wr[RING][2];
-    auto stream_load = [&](int t, int slot) {
+    auto stream_load = [&](int t) {  // t is a compile-time constant at every call site
         if (t < 3 * KC) {
-            const int part = t / KC, c = t - part * KC;  // compile-time after unrolling
+            const int part = t / KC, c = t - part * KC;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) wr[slot][n] = Wq[((size_t)(part * 2 * HEADS + 2 * h + n) * KC + c) * 64];
+            for (int n = 0; n < 2; ++n) {
+                const Frag<bf16>* fb = Wq + ((size_t)(part * 2 * HEADS + 2 * h + n) * KC + c) * 64;  // wave-uniform
+                wr[t % RING][n] = fb[lane];
+            }
         } else if (t < 4 * KC) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) wr[slot][n] = Wp[((size_t)(2 * h + n) * KC + (t - 3 * KC)) * 64];
+            for (int n = 0; n < 2; ++n) {
+                const Frag<bf16>* fb = Wp + ((size_t)(2 * h + n) * KC + (t - 3 * KC)) * 64;
+                wr[t % RING][n] = fb[lane];
+            }
+        } else if (MLP && t < 6 * KC) {  // fc1: wave h owns hidden columns [64h, 64h+64) = n-tiles 4h..4h+3, two per pass
+            const int half = (t - 4 * KC) / KC, c = (t - 4 * KC) - half * KC;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const Frag<bf16>* fb = reinterpret_cast<const Frag<bf16>*>(a.w1p) + ((size_t)(4 * h + 2 * half + n) * KC + c) * 64;
+                wr[t % RING][n] = fb[lane];
+            }
+        } else if (MLP && t < 6 * KC + 2 * KC) {  // fc2: K = 384 = 12 chunks, wave h owns output columns [32h, 32h+32)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const Frag<bf16>* fb = reinterpret_cast<const Frag<bf16>*>(a.w2p) + ((size_t)(2 * h + n) * (2 * KC) + (t - 6 * KC)) * 64;
+                wr[t % RING][n] = fb[lane];
+            }
         }
     };
 #pragma unroll
-    for (int c = 0; c < RING; ++c) stream_load(c, c);
+    for (int c = 0; c < RING - 1; ++c) stream_load(c);
 
-    // ---- S0: x slice (residual registers) + LayerNorm1 -> Aimg
-    f32x4 xr[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) xr[m][n] = load4(a.x + (size_t)pix[m] * a.ldx + h * 32 + n * 16 + ag * 4);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(1);
+    // ---- S0: x slice + one-pass LayerNorm1 statistics -> Aimg ; slice parked in LDS
     {
-        const float inv = 1.0f / (float)a.C;
-        float mean[4], rstd[4];
+        f32x4 xr[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) xr[m][n] = load4(a.x + (size_t)pixel_row(m) * a.ldx + h * 32 + n * 16 + ag * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s += xr[m][n][r];
-            s = wave_sum_xor(s, 16);
-            s = wave_sum_xor(s, 32);
-            if (ag == 0) red[(m * 16 + ar) * HEADS + h] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < HEADS; ++w) s += red[(m * 16 + ar) * HEADS + w];
-            mean[m] = s * inv;
-            float q = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int c = h * 32 + n * 16 + ag * 4 + r;
-                    const float d = c < a.C ? xr[m][n][r] - mean[m] : 0.f;
-                    q += d * d;
+                    s1 += xr[m][n][r];
+                    s2 += xr[m][n][r] * xr[m][n][r];
                 }
-            q = wave_sum_xor(q, 16);
-            q = wave_sum_xor(q, 32);
-            if (ag == 0) red[NTOK * HEADS + (m * 16 + ar) * HEADS + h] = q;
+            s1 = wave_sum_xor(s1, 16);
+            s1 = wave_sum_xor(s1, 32);
+            s2 = wave_sum_xor(s2, 16);
+            s2 = wave_sum_xor(s2, 32);
+            if (ag == 0) {
+                red[((m * 16 + ar) * HEADS + h) * 2] = s1;
+                red[((m * 16 + ar) * HEADS + h) * 2 + 1] = s2;
+            }
+            stash[(h * 8 + m * 2) * 64 + lane] = xr[m][0];
+            stash[(h * 8 + m * 2 + 1) * 64 + lane] = xr[m][1];
         }
         __syncthreads();
+        const float inv = 1.0f / (float)a.C;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float q = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < HEADS; ++w) q += red[NTOK * HEADS + (m * 16 + ar) * HEADS + w];
-            rstd[m] = rsqrtf(q * inv + a.eps);
+            for (int w = 0; w < HEADS; ++w) {
+                s1 += red[((m * 16 + ar) * HEADS + w) * 2];
+                s2 += red[((m * 16 + ar) * HEADS + w) * 2 + 1];
+            }
+            const float mean = s1 * inv;
+            const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + a.eps);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const f32x4 o = (xr[m][n] - mean[m]) * rstd[m];  // gamma / beta are folded into wqkv / bqkv
+                const f32x4 o = (xr[m][n] - mean) * rstd;  // gamma / beta are folded into wqkv / bqkv
                 bf16x4 ob;
                 ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
                 char* dst = reinterpret_cast<char*>(Aimg + (h * 4 + n * 2 + (ag >> 1)) * NTOK + m * 16 + ar) + (ag & 1) * 8;
@@ -154,6 +183,13 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     Frag<bf16> vf[2][2];  // [d tile][32-key step]
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
+        // Only q carries a bias here: a k bias adds the same q.b_k to every logit of a row and cancels in the softmax,
+        // a v bias passes through the row-stochastic P unchanged and is folded into the proj bias at pack time.
+        f32x4 b0 = (f32x4)(0.f), b1 = (f32x4)(0.f);
+        if (part == 0) {
+            b0 = load4(a.bqkv + h * 32 + ag * 4);
+            b1 = load4(a.bqkv + h * 32 + 16 + ag * 4);
+        }
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -162,7 +198,7 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int t = part * KC + c;
-            const int slot = t % RING;
+            if (t + RING - 1 < 3 * KC) stream_load(t + RING - 1);  // the proj weights are fetched after the attention core
             const Frag<bf16>* arow = Aimg + (c * 4 + ag) * NTOK + ar;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -170,43 +206,48 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     if (part < 2)
-                        mma(wr[slot][n], av, acc[m][n]);
+                        mma(wr[t % RING][n], av, acc[m][n]);
                     else
-                        mma(av, wr[slot][n], acc[m][n]);
+                        mma(av, wr[t % RING][n], acc[m][n]);
                 }
+                if (m == 1) __builtin_amdgcn_sched_barrier(0);  // at most two activation fragments in flight (register budget)
             }
-            if (t + RING < 3 * KC) stream_load(t + RING, slot);  // the proj weights are fetched after the attention
             __builtin_amdgcn_sched_barrier(0);
         }
         STAMP(3 + part);
-        if (part < 2) {
-            const f32x4 b0 = load4(a.bqkv + part * 192 + h * 32 + ag * 4), b1 = load4(a.bqkv + part * 192 + h * 32 + 16 + ag * 4);
+        if (part == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (part == 0)
-                    qf[m] = pack2(acc[m][0] + b0, acc[m][1] + b1);
-                else
-                    kf[m] = pack2(acc[m][0] + b0, acc[m][1] + b1);
-            }
+            for (int m = 0; m < 4; ++m) qf[m] = pack2(acc[m][0] + b0, acc[m][1] + b1);
+        } else if (part == 1) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) kf[m] = pack2(acc[m][0], acc[m][1]);
         } else {
-            const float bv0 = a.bqkv[384 + h * 32 + ar], bv1 = a.bqkv[384 + h * 32 + 16 + ar];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                vf[0][ks] = pack2(acc[2 * ks][0] + bv0, acc[2 * ks + 1][0] + bv0);
-                vf[1][ks] = pack2(acc[2 * ks][1] + bv1, acc[2 * ks + 1][1] + bv1);
+                vf[0][ks] = pack2(acc[2 * ks][0], acc[2 * ks + 1][0]);
+                vf[1][ks] = pack2(acc[2 * ks][1], acc[2 * ks + 1][1]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-
+    __syncthreads();  // every wave is done reading LayerNorm1(x): the image is reused for the attention output
     STAMP(6);
-    // ---- S2: attention for head h, two query halves of 32
+
+    // ---- S2: attention for head h, one 16-query tile at a time; the bias fragments of tile qt+1 are in flight
     const bool masked = a.shift > 0 && ((int)wy == a.H / WS - 1 || (int)wx == a.W / WS - 1);
     const f32x4* bias = reinterpret_cast<const f32x4*>(a.bias) + (size_t)h * 16 * 64 + lane;  // [h][qt][kt][lane]
+    f32x4 bnext[4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {  // one 16-query tile at a time: 4 accumulator tiles of logits live
+    for (int kt = 0; kt < 4; ++kt) bnext[kt] = bias[kt * 64];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
         f32x4 s[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[kt] = bias[(qt * 4 + kt) * 64];
+        for (int kt = 0; kt < 4; ++kt) s[kt] = bnext[kt];
+        if (qt < 3) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) bnext[kt] = bias[((qt + 1) * 4 + kt) * 64];
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) mma(kf[kt], qf[qt], s[kt]);
         if (masked) {
@@ -226,8 +267,8 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = wave_max_xor(mx, 16);
+        mx = wave_max_xor(mx, 32);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -237,8 +278,8 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
                 s[kt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = wave_sum_xor(sum, 16);
+        sum = wave_sum_xor(sum, 32);
         const float inv_sum = __builtin_amdgcn_rcpf(sum);
         const Frag<bf16> p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
 #pragma unroll
@@ -249,43 +290,170 @@ __global__ __launch_bounds__(384, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
             o *= inv_sum;
             bf16x4 ob;
             ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
-            char* dst = reinterpret_cast<char*>(Oimg + (h * 4 + dt * 2 + (ag >> 1)) * NTOK + qt * 16 + ar) + (ag & 1) * 8;
+            char* dst = reinterpret_cast<char*>(Aimg + (h * 4 + dt * 2 + (ag >> 1)) * NTOK + qt * 16 + ar) + (ag & 1) * 8;
             *reinterpret_cast<bf16x4*>(dst) = ob;
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the four query tiles sequential (register pressure)
     }
 #pragma unroll
-    for (int c = 0; c < RING; ++c) stream_load(3 * KC + c, (3 * KC + c) % RING);
+    for (int c = 0; c < RING - 1; ++c) stream_load(3 * KC + c);
     STAMP(7);
     __syncthreads();
     STAMP(8);
 
-    // ---- S3: proj columns [32h, 32h+32) on top of the residual
+    // ---- S3: proj columns [32h, 32h+32) on top of the residual slice (back from LDS) + bias
     {
         const f32x4 bp0 = load4(a.bproj + h * 32 + ag * 4), bp1 = load4(a.bproj + h * 32 + 16 + ag * 4);
+        f32x4 xr[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            xr[m][0] += bp0;
-            xr[m][1] += bp1;
+            xr[m][0] = stash[(h * 8 + m * 2) * 64 + lane] + bp0;
+            xr[m][1] = stash[(h * 8 + m * 2 + 1) * 64 + lane] + bp1;
         }
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int t = 3 * KC + c;
-            const int slot = t % RING;
-            const Frag<bf16>* orow = Oimg + (c * 4 + ag) * NTOK + ar;
+            stream_load(t + RING - 1);
+            const Frag<bf16>* orow = Aimg + (c * 4 + ag) * NTOK + ar;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const Frag<bf16> ov = orow[m * 16];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) mma(wr[slot][n], ov, xr[m][n]);
+                for (int n = 0; n < 2; ++n) mma(wr[t % RING][n], ov, xr[m][n]);
             }
-            stream_load(t + RING, slot);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(10);
+        if constexpr (MLP) {
+            // ================= MLP half of the block on the same 64 tokens: x1 (= xr) never leaves the CU =================
+            // LayerNorm2 statistics of x1 across the 6 column slices (through `red`), then the normalised rows replace the
+            // attention output in the LDS image; the hidden activations replace the parked residual slices (48 KiB).
+            Frag<bf16>* Himg = reinterpret_cast<Frag<bf16>*>(stash);  // [48][64]
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) store4(a.out + (size_t)pix[m] * a.ldx + h * 32 + n * 16 + ag * 4, xr[m][n]);
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool real = h * 32 + n * 16 + ag * 4 + r < a.C;
+                        const float v = real ? xr[m][n][r] : 0.f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 = wave_sum_xor(s1, 16);
+                s1 = wave_sum_xor(s1, 32);
+                s2 = wave_sum_xor(s2, 16);
+                s2 = wave_sum_xor(s2, 32);
+                if (ag == 0) {
+                    red[((m * 16 + ar) * HEADS + h) * 2] = s1;
+                    red[((m * 16 + ar) * HEADS + h) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();  // proj reads of the image are done everywhere + LN2 partials are visible
+            {
+                const float inv = 1.0f / (float)a.C;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < HEADS; ++w) {
+                        s1 += red[((m * 16 + ar) * HEADS + w) * 2];
+                        s2 += red[((m * 16 + ar) * HEADS + w) * 2 + 1];
+                    }
+                    const float mean = s1 * inv;
+                    const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.eps);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 o = (xr[m][n] - mean) * rstd;  // gamma2 / beta2 are folded into w1p / b1
+                        bf16x4 ob;
+                        ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
+                        char* dst = reinterpret_cast<char*>(Aimg + (h * 4 + n * 2 + (ag >> 1)) * NTOK + m * 16 + ar) + (ag & 1) * 8;
+                        *reinterpret_cast<bf16x4*>(dst) = ob;
+                    }
+                }
+            }
+            __syncthreads();
+            STAMP(11);
+            // fc1 (two passes of 32 hidden columns) -> GELU -> hidden image
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 c0 = load4(a.b1 + h * 64 + half * 32 + ag * 4), c1 = load4(a.b1 + h * 64 + half * 32 + 16 + ag * 4);
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4)(0.0f);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const int t = 4 * KC + half * KC + c;
+                    stream_load(t + RING - 1);
+                    const Frag<bf16>* arow = Aimg + (c * 4 + ag) * NTOK + ar;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const Frag<bf16> av = arow[m * 16];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) mma(wr[t % RING][n], av, acc[m][n]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = h * 64 + half * 32 + n * 16 + ag * 4;
+                    char* hbase = reinterpret_cast<char*>(Himg + (col >> 3) * NTOK + ar) + (ag & 1) * 8;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x4 v = acc[m][n] + (n == 0 ? c0 : c1);
+                        bf16x4 hb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hb[r] = (bf16)gelu_bf16(v[r]);
+                        *reinterpret_cast<bf16x4*>(hbase + m * 16 * sizeof(Frag<bf16>)) = hb;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(12 + half);
+            }
+            {
+                const f32x4 d0 = load4(a.b2 + h * 32 + ag * 4), d1 = load4(a.b2 + h * 32 + 16 + ag * 4);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    xr[m][0] += d0;
+                    xr[m][1] += d1;
+                }
+            }
+            __syncthreads();
+            STAMP(14);
+            // fc2 on top of x1
+#pragma unroll
+            for (int c = 0; c < 2 * KC; ++c) {
+                const int t = 6 * KC + c;
+                stream_load(t + RING - 1);
+                const Frag<bf16>* hrow = Himg + (c * 4 + ag) * NTOK + ar;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const Frag<bf16> hv = hrow[m * 16];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) mma(wr[t % RING][n], hv, xr[m][n]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        STAMP(15);
+        int arl = ar;
+        asm volatile("" : "+v"(arl));  // opaque copy: keeps hipcc from hoisting (and spilling) the four store addresses
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int t = m * 16 + arl;
+            int y = wy * WS + (t >> 3) + a.shift;
+            int x = wx * WS + (t & 7) + a.shift;
+            if (y >= a.H) y -= a.H;
+            if (x >= a.W) x -= a.W;
+            float* dst = a.out + (size_t)(((int)bimg * a.H + y) * a.W + x) * a.ldx + h * 32 + ag * 4;
+            if (live) {
+                store4(dst, xr[m][0]);
+                store4(dst + 16, xr[m][1]);
+            }
+        }
     }
     STAMP(9);
 }
@@ -311,14 +479,21 @@ extern "C" int sr_swin_attn_fused(const SrSwinAttn* p, void* stream) {
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
     dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
-    constexpr int lds = 2 * 24 * 64 * 16 + 2 * 64 * 6 * 4;  // 48 KiB + 3 KiB
+    constexpr int lds = 2 * (24 * 64 * 16 + 6 * 8 * 64 * 16 + 64 * 6 * 2 * 4);  // per window: 24 KiB image + 48 KiB residual slices + 3 KiB LN partials
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_swin_attn_kernel, lds);
+        hipError_t e = sr_allow_lds(sr_swin_attn_kernel<false>, lds);
+        if (e == hipSuccess) e = sr_allow_lds(sr_swin_attn_kernel<true>, lds);
         SR_REQUIRE(e == hipSuccess, "sr_swin_attn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(sr_swin_attn_kernel, dim3(a.B * nwx * nwy), dim3(384), lds, reinterpret_cast<hipStream_t>(stream), dv);
+    const dim3 grid((a.B * nwx * nwy + 1) / 2);
+    if (a.w1p) {
+        SR_REQUIRE(a.b1 && a.w2p && a.b2 && a.Hp == 384, "sr_swin_attn_fused: the fused MLP tail needs w1p/b1/w2p/b2 and Hp == 384");
+        hipLaunchKernelGGL(sr_swin_attn_kernel<true>, grid, dim3(768), lds, reinterpret_cast<hipStream_t>(stream), dv);
+    } else {
+        hipLaunchKernelGGL(sr_swin_attn_kernel<false>, grid, dim3(768), lds, reinterpret_cast<hipStream_t>(stream), dv);
+    }
     SR_CHECK_LAUNCH("sr_swin_attn_fused");
     return SR_OK;
 }

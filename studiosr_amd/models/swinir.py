@@ -3,7 +3,7 @@
 Same constructor kwargs, attributes, `state_dict` keys/shapes (official checkpoints load unchanged) and
 `get_model_config` / `get_training_config` / `from_pretrained` surface as the reference class.  `forward`
 is not a torch graph: it is a fixed sequence of C-ABI launches over NHWC buffers
-(2 + 4 per block + 1 per RSTB + 6 kernels):
+(2 + 1 per block (fused) + 1 per RSTB + 6 kernels):
 
   ingest (pad + normalise, swinir.py:249-255,356-359)  -> conv_first (:361)  -> LayerNorm (:28-32)
   per block (:146-174):  [LN1 + QKV GEMM, rows gathered through roll+partition] -> window attention
@@ -126,7 +126,13 @@ def pack_attention(attn: nn.Module, geo: SwinGeometry, dt: torch.dtype, rpi: Opt
     proj_w, proj_b = packing.pack_linear(attn.proj.weight, attn.proj.bias, packing.identity_idx(C, Cp), packing.head_idx(heads, geo.hd, hd_p), dt)
     rpi = attn.relative_position_index if rpi is None else rpi
     bias = packing.gather_bias(attn.relative_position_bias_table, rpi, geo.ntok, geo.ntok)
-    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, bias=bias, bias_frag=packing.bias_fragments(bias))
+    # fused kernel: softmax rows sum to 1, so P (v + b_v) = P v + b_v and proj(o + b_v) = proj(o) + W_proj b_v (exact algebra);
+    # the k bias shifts every logit of a row equally and cancels in the softmax.
+    bv = qb.detach().to(torch.float32)[2 * C :] if qb is not None else torch.zeros(C, device=qw.device)
+    pb = attn.proj.bias.detach().to(torch.float32) if attn.proj.bias is not None else torch.zeros(C, device=qw.device)
+    proj_b_fused = packing.pad_vec(pb + attn.proj.weight.detach().to(torch.float32) @ bv, Cp).contiguous()
+    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, proj_b_fused=proj_b_fused, bias=bias,
+                bias_frag=packing.bias_fragments(bias))
 
 
 def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[nn.LayerNorm] = None) -> Dict:
@@ -136,6 +142,23 @@ def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[
     fc1_w, fc1_b = packing.pack_linear(w1, b1, packing.identity_idx(geo.hidden, geo.hid_p), packing.identity_idx(geo.C, geo.Cp), dt)
     fc2_w, fc2_b = packing.pack_linear(mlp.fc2.weight, mlp.fc2.bias, packing.identity_idx(geo.C, geo.Cp), packing.identity_idx(geo.hidden, geo.hid_p), dt)
     return dict(fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b)
+
+
+def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_, cdt: torch.dtype, shift: int) -> None:
+    """t_out = SwinTransformerBlock(t_in) (swinir.py:146-174): ONE launch when the fused kernel covers the geometry
+    (attention half + MLP half on the same window), otherwise attention and MLP as separate launches."""
+    B, H, W, Cp = t_in.shape
+    sdt = sr_dtype(cdt)
+    if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):
+        ops.swin_attn_fused(
+            x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
+            bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
+            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, w1p=p["fc1_w"].data_ptr(), b1=p["fc1_b"].data_ptr(), w2p=p["fc2_w"].data_ptr(),
+            b2=p["fc2_b"].data_ptr(), Hp=geo.hid_p,
+        )
+        return
+    run_window_msa(p, p["ln1"], geo, t_in, t_out, t_in, ws_, cdt, shift)
+    run_mlp(p, p["ln2"], geo, t_out, ws_, cdt)
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa") -> None:
@@ -148,7 +171,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     if skip is t_in and ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt):  # one kernel per attention half
         ops.swin_attn_fused(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
-            bproj=p["proj_b"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
+            bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
             hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5,
         )
         return
@@ -335,8 +358,7 @@ class SwinIR(Model):
             geo = lp["geo"]
             cur = ta  # RSTB input stays in ta until the closing conv has consumed it as the skip
             for bp in lp["blocks"]:
-                run_window_msa(bp, bp["ln1"], geo, cur, tb, cur, ws_, cdt, bp["shift"])
-                run_mlp(bp, bp["ln2"], geo, tb, ws_, cdt)
+                run_swin_block(bp, geo, cur, tb, ws_, cdt, bp["shift"])
                 cur = tb
             # ta = conv(cur) + ta   (swinir.py:245-246).  Within an RSTB the first block reads `ta` and
             # writes `tb`; later blocks work in place on `tb`; a zero-depth RSTB convolves `ta` itself.

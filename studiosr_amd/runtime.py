@@ -44,17 +44,44 @@ class Workspace:
     """Named device buffers, reused across forwards of the same geometry (graph-capture friendly:
     a captured forward only touches buffers that were allocated before capture)."""
 
+    GUARD_BYTES = 1 << 16  # SR_WS_GUARD=1: every buffer sits between two 64 KiB guard zones (see check_guards)
+
     def __init__(self, device: torch.device) -> None:
+        import os
+
         self.device = device
         self.bufs: Dict[Tuple, Tensor] = {}
+        self.guard = bool(os.environ.get("SR_WS_GUARD"))
+        self._raw: Dict[Tuple, Tensor] = {}
 
     def get(self, name: str, shape, dtype: torch.dtype) -> Tensor:
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
-            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            if self.guard:
+                n = 1
+                for d in shape:
+                    n *= int(d)
+                nbytes = n * torch.empty((), dtype=dtype).element_size()
+                raw = torch.full((nbytes + 2 * self.GUARD_BYTES,), 0x5A, dtype=torch.uint8, device=self.device)
+                raw[self.GUARD_BYTES : self.GUARD_BYTES + nbytes] = 0
+                self._raw[key] = raw
+                t = raw[self.GUARD_BYTES : self.GUARD_BYTES + nbytes].view(dtype).view(tuple(shape))
+            else:
+                t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
             self.bufs[key] = t
         return t
+
+    def check_guards(self):
+        """Debug aid: names of buffers whose guard zones were written (out-of-bounds stores by a kernel)."""
+        bad = []
+        for key, raw in self._raw.items():
+            g = self.GUARD_BYTES
+            if not bool((raw[:g] == 0x5A).all()) or not bool((raw[-g:] == 0x5A).all()):
+                lo = int((raw[:g] != 0x5A).sum())
+                hi = int((raw[-g:] != 0x5A).sum())
+                bad.append((key, lo, hi))
+        return bad
 
 
 class GraphedForward:
@@ -64,6 +91,9 @@ class GraphedForward:
     that already exist (one eager warm-up call is made before capture to allocate them)."""
 
     def __init__(self, fn: Callable[[Tensor], Tensor], example: Tensor, warmup: int = 2) -> None:
+        # The graph records raw device pointers: everything `fn` closes over (model, workspace buffers, packed weights)
+        # must outlive the graph, so the callable itself is kept alive here.
+        self.fn = fn
         self.static_in = example.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())

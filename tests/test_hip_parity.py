@@ -208,6 +208,27 @@ def test_swinir_x4_batch8_invariants(swinir_full):
     m.cpu()
 
 
+def test_graphed_forward_keeps_its_buffers_alive():
+    """A HIP graph records raw device pointers; GraphedForward must own the callable (and through it the model and its
+    workspace).  Regression test: dropping every outside reference and emptying the cache once faulted at replay."""
+    import gc
+
+    from studiosr_amd.runtime import GraphedForward
+
+    g, cfg, sd, m = build("EDSR", "f11_edsr_x2")
+    m.set_precision("bf16")
+    x = torch.from_numpy(g["x_2_12_12"]).to(DEV)
+    with torch.no_grad():
+        ref = m(x).clone()
+        gf = GraphedForward(lambda t, mm=m: mm(t), x)
+    del m
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(8)]  # would land in any memory the graph wrongly gave up
+    assert torch.equal(gf(x), ref)
+    del junk
+
+
 def test_edsr_x4_batch16_invariants():
     """BASELINE config 2 (EDSR x4, batch 16, 64x64): batch independence + eval-pad-free shape; fp32 vs bf16 PSNR."""
     torch.manual_seed(0)

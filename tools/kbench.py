@@ -34,7 +34,7 @@ def main():
     P = m._get_packed(cdt)
     lp = P["layers"][0]
     geo, bp = lp["geo"], lp["blocks"][1]
-    which = sys.argv[1:] or ["mlp", "qkv", "attn", "proj", "msa"]
+    which = sys.argv[1:] or ["mlp", "msa", "blk"]
     for B in (1, 2, 4, 8, 16):
         H = W = 72
         t = torch.randn(B, H, W, geo.Cp, device=dev)
@@ -44,6 +44,8 @@ def main():
         res = {}
         if "mlp" in which:
             res["mlp"] = timeit(lambda: SW.run_mlp(bp, bp["ln2"], geo, t, ws_, cdt))
+        if "blk" in which:
+            res["blk"] = timeit(lambda: SW.run_swin_block(bp, geo, t, t, ws_, cdt, bp["shift"]))
         if "msa" in which:
             res["msa"] = timeit(lambda: SW.run_window_msa(bp, bp["ln1"], geo, t, t, t, ws_, cdt, bp["shift"]))
         print(f"B={B:2d} M={M:6d} WG64={M // 64:5d} " + " ".join(f"{k}={v:8.1f}us" for k, v in res.items()), flush=True)
