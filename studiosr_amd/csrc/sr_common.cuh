@@ -53,6 +53,17 @@ SR_DEV void frag_zero(Frag<float>& f) {
     f.lo = (f32x4)(0.0f);
     f.hi = (f32x4)(0.0f);
 }
+SR_DEV Frag<bf16> frag_keep_if(bool keep, const Frag<bf16>& f) {  // keep ? f : 0 as a vector select (no aggregate select: stays in registers)
+    Frag<bf16> r;
+    r.v = keep ? f.v : (bf16x8)(0.0f);
+    return r;
+}
+SR_DEV Frag<float> frag_keep_if(bool keep, const Frag<float>& f) {
+    Frag<float> r;
+    r.lo = keep ? f.lo : (f32x4)(0.0f);
+    r.hi = keep ? f.hi : (f32x4)(0.0f);
+    return r;
+}
 SR_DEV void frag_set(Frag<bf16>& f, int j, float x) { f.v[j] = (bf16)x; }
 SR_DEV void frag_set(Frag<float>& f, int j, float x) {
     if (j < 4)

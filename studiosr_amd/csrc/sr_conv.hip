@@ -56,19 +56,46 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     {
         const int r8 = lane & 7, kq = lane >> 3;
         const TIn* xin = reinterpret_cast<const TIn*>(c.x);
-        for (int pb = wave * 8; pb < ROWS; pb += 32) {
-            const int p = pb + r8;
-            const int py = p / HALO_W, px = p - py * HALO_W;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            const bool valid = p < HH * HALO_W && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
-            const TIn* src = xin + ((size_t)(b * c.H + (valid ? gy : 0)) * c.W + (valid ? gx : 0)) * c.Cin_p;
-            for (int kg = kq; kg < KG; kg += 8) {
-                Frag<TC> f;
-                if (valid)
-                    f = load_group<TC, TIn>(src + kg * 8);
-                else
-                    frag_zero(f);
-                As[kg * ROWS + p] = f;
+        if constexpr (KCS > 0 && (KCS * 4) % 8 == 0) {
+            // compile-time channel count (multiple of 64): two row passes per step, all of their loads issued before the first LDS write
+            // (out-of-image pixels read a clamped address and are zeroed by a select: no divergent branches)
+            constexpr int KI = KCS * 4 / 8;
+            static_assert(ROWS % 64 == 0, "two row passes per step");
+            for (int pb = wave * 8; pb < ROWS; pb += 64) {
+                Frag<TC> f[2][KI];
+                bool valid[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    const int py = p / HALO_W, px = p - py * HALO_W;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                    valid[u] = p < HH * HALO_W && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                    const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * c.Cin_p;
+#pragma unroll
+                    for (int i = 0; i < KI; ++i) f[u][i] = load_group<TC, TIn>(src + (kq + 8 * i) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = pb + u * 32 + r8;
+#pragma unroll
+                    for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * ROWS + p] = frag_keep_if(valid[u], f[u][i]);
+                }
+            }
+        } else {
+            for (int pb = wave * 8; pb < ROWS; pb += 32) {
+                const int p = pb + r8;
+                const int py = p / HALO_W, px = p - py * HALO_W;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool valid = p < HH * HALO_W && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                const TIn* src = xin + ((size_t)(b * c.H + (valid ? gy : 0)) * c.W + (valid ? gx : 0)) * c.Cin_p;
+                for (int kg = kq; kg < KG; kg += 8) {
+                    Frag<TC> f;
+                    if (valid)
+                        f = load_group<TC, TIn>(src + kg * 8);
+                    else
+                        frag_zero(f);
+                    As[kg * ROWS + p] = f;
+                }
             }
         }
     }
@@ -83,11 +110,22 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     const int KCT = 9 * KC;
     const Frag<TC>* Bp = reinterpret_cast<const Frag<TC>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
 
+    // plain residual convs (no activation / scale, NHWC out): the skip tile is the initial accumulator, fetched now
+    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
     f32x4 acc[MTW][NW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int m = 0; m < MTW; ++m) {
+        const int yy = y0 + wm * MTW + m, xx = x0 + ar;
+        const bool inb0 = (yy < c.H) && (xx < c.W);
 #pragma unroll
-        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4)(0.0f);
+        for (int n = 0; n < NW; ++n) {
+            acc[m][n] = (f32x4)(0.0f);
+            if (acc_from_skip && inb0) {
+                const size_t off = ((size_t)(b * c.H + yy) * c.W + xx) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
+                acc[m][n] = c.skip_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(c.skip) + off) : load4(reinterpret_cast<const float*>(c.skip) + off);
+            }
+        }
+    }
 
     if constexpr (KCS > 0) {
         // Fully unrolled (tap, chunk) walk: K-chunk count is a compile-time constant, so the 3-slot weight ring
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             } else {
                 off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + col;
             }
-            if (c.skip) {
+            if (c.skip && !acc_from_skip) {
                 if (c.skip_dtype == SR_BF16)
                     v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
                 else
