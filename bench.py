@@ -10,7 +10,7 @@ one rank per GPU) every rank processes its own batch of 8 tiles -- tiles are ind
 data-path collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
 
 The JSON line also carries
-  roofline      dominant kernel (the fused window-attention kernel `sr_swin_attn_kernel`) vs the bf16 MFMA peak,
+  roofline      dominant kernel (the one-launch Swin block kernel `sr_swin_attn_kernel<MLP>`) vs the bf16 MFMA peak,
                 timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this
                 host's cores on a bounded sample of the same workload.
@@ -50,11 +50,12 @@ def build_model(device):
 
 
 def time_dominant_kernel(model, x, iters: int = 50):
-    """Average duration of ONE launch of the dominant kernel, `sr_swin_attn_kernel` (LayerNorm1 + QKV + shifted-window
-    attention + proj + residual of one block at the bench shape: 648 windows = 41,472 tokens), timed with HIP events
-    on the launch stream (torch's current stream is the stream the C-ABI call enqueues on), and its ALGORITHMIC FLOPs:
-    2*MAC of qkv (180->540), QK^T + AV (6 heads x 64 x 64 x 30) and proj (180->180) per token = 305,280 FLOP
-    (194,400 + 46,080 + 64,800)."""
+    """Average duration of ONE launch of the dominant kernel, `sr_swin_attn_kernel<MLP=true>` -- one whole Swin block
+    (LayerNorm1 + QKV + shifted-window attention + proj + residual, LayerNorm2 + fc1 + GELU + fc2 + residual) at the
+    bench shape: 648 windows = 41,472 tokens, 36 launches per forward -- timed with HIP events on the launch stream
+    (torch's current stream is the stream the C-ABI call enqueues on), and its ALGORITHMIC FLOPs per token:
+    2*MAC of qkv (180->540) 194,400 + QK^T and AV (6 heads x 64 keys x 30) 46,080 + proj (180->180) 64,800
+    + fc1 (180->360) 129,600 + fc2 (360->180) 129,600 = 564,480 FLOP."""
     from studiosr_amd.models import swinir as SW
 
     cdt = torch.bfloat16
@@ -67,7 +68,7 @@ def time_dominant_kernel(model, x, iters: int = 50):
     o = ws_.get("tb", (B, PADDED, PADDED, geo.Cp), torch.float32)
 
     def launch():
-        SW.run_window_msa(bp, bp["ln1"], geo, t, o, t, ws_, cdt, bp["shift"])
+        SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"])
 
     for _ in range(5):
         launch()
@@ -79,8 +80,33 @@ def time_dominant_kernel(model, x, iters: int = 50):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = float(B * PADDED * PADDED) * 305_280.0
+    flops = float(B * PADDED * PADDED) * 564_480.0
     return ms, flops
+
+
+def profiled_hbm_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_bench_hbm_counters.txt,
+    collected by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KiB per dispatch).  gfx950 correction
+    (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact.
+    Returns None when no profile is present (the counters cannot be read from inside the process)."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_hbm_counters.txt")))
+    if not files:
+        return None
+    vals, key = {}, None
+    for line in open(files[-1]):
+        if line.startswith("("):
+            key = "swin_attn_kernel<true>" in line and ", 324)" in line
+        elif key:
+            m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
+            if m:
+                vals[m.group(1)] = float(m.group(2))
+    if len(vals) != 2:
+        return None
+    return dict(bytes=int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), source=os.path.relpath(files[-1], ROOT),
+                fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"])
 
 
 def cpu_baseline_and_parity(model, device):
@@ -226,10 +252,13 @@ def main() -> None:
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         fwd_flops = BATCH * PADDED * PADDED * FLOP_PER_LR_PIXEL  # per GPU per step, reference semantics (padded tile)
         fwd_tflops = fwd_flops / (ms_per_step * 1e-3) / 1e12
+        traffic = profiled_hbm_traffic()
+        # fp32 residual stream in + out (Cp = 192 channels) + the block's packed bf16 weights and biases, per launch
+        algo_bytes = 2 * BATCH * PADDED * PADDED * 192 * 4 + 2 * (192 * 576 + 192 * 192 + 2 * 192 * 384) + 4 * 6 * 64 * 64
         roof = dict(
-            bound="mfma", kernel="sr_swin_attn_kernel (LN1 + QKV + shifted-window attention + proj + residual, 648 windows x 64 tokens)",
+            bound="mfma", kernel="sr_swin_attn_kernel<MLP> (one whole Swin block: LN1 + QKV + shifted-window attention + proj + residual + LN2 + MLP + residual; 648 windows x 64 tokens, 36 launches per forward)",
             achieved=round(achieved, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-            traffic=None, kernel_ms=round(k_ms, 5),
+            traffic=(traffic or {}).get("bytes"), traffic_detail=traffic, algorithmic_hbm_bytes=algo_bytes, kernel_ms=round(k_ms, 5),
             forward=dict(achieved=round(fwd_tflops, 2), frac=round(fwd_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                          frac_unpadded=round(fwd_tflops * (TILE * TILE) / (PADDED * PADDED) / MFMA_BF16_PEAK_TFLOPS, 4),
                          gflop_per_step=round(fwd_flops / 1e9, 2)),
