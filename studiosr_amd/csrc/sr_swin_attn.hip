@@ -118,9 +118,6 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
             }
         }
     };
-#pragma unroll
-    for (int c = 0; c < RING - 1; ++c) stream_load(c);
-
     // ---- S0: x slice + one-pass LayerNorm1 statistics -> Aimg ; slice parked in LDS
     {
         f32x4 xr[4][2];
@@ -128,6 +125,11 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) xr[m][n] = load4(a.x + (size_t)pixel_row(m) * a.ldx + h * 32 + n * 16 + ag * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // the x tile is the only thing LayerNorm1 waits for: its loads go out first, the weight ring (needed ~3k cycles
+        // later) queues behind them in the CU's memory pipeline
+#pragma unroll
+        for (int c = 0; c < RING - 1; ++c) stream_load(c);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
 #pragma unroll
@@ -164,11 +166,12 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
             const float mean = s1 * inv;
             const float var = fmaxf(s2 * inv - mean * mean, 0.f);
             const float rstd = rsqrtf(var + a.eps);
+            const float nmr = -mean * rstd;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const f32x4 o = (xr[m][n] - mean) * rstd;  // gamma / beta are folded into wqkv / bqkv
-                bf16x4 ob;
-                ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
+                bf16x4 ob;  // gamma / beta are folded into wqkv / bqkv
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[r] = (bf16)__builtin_fmaf(xr[m][n][r], rstd, nmr);
                 char* dst = reinterpret_cast<char*>(Aimg + (h * 4 + n * 2 + (ag >> 1)) * NTOK + m * 16 + ar) + (ag & 1) * 8;
                 *reinterpret_cast<bf16x4*>(dst) = ob;
             }
@@ -192,9 +195,10 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         }
         f32x4 acc[4][2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4)(0.0f);
+        for (int m = 0; m < 4; ++m) {  // the bias is the C operand of the first MFMA: no separate add
+            acc[m][0] = b0;
+            acc[m][1] = b1;
+        }
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int t = part * KC + c;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         STAMP(3 + part);
         if (part == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) qf[m] = pack2(acc[m][0] + b0, acc[m][1] + b1);
+            for (int m = 0; m < 4; ++m) qf[m] = pack2(acc[m][0], acc[m][1]);
         } else if (part == 1) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) kf[m] = pack2(acc[m][0], acc[m][1]);
@@ -234,7 +238,14 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     STAMP(6);
 
     // ---- S2: attention for head h, one 16-query tile at a time; the bias fragments of tile qt+1 are in flight
-    const bool masked = a.shift > 0 && ((int)wy == a.H / WS - 1 || (int)wx == a.W / WS - 1);
+    const bool last_row = (int)wy == a.H / WS - 1, last_col = (int)wx == a.W / WS - 1;
+    const bool masked = a.shift > 0 && (last_row || last_col);
+    f32x4 colneg = (f32x4)(0.0f);  // -100 where the key's column half differs from the query's (same for every query tile)
+    if (masked) {
+        const bool qcol = last_col && (ar & 7) >= WS - a.shift;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colneg[r] = (last_col && 4 * (ag & 1) + r >= WS - a.shift) != qcol ? -100.0f : 0.0f;
+    }
     const f32x4* bias = reinterpret_cast<const f32x4*>(a.bias) + (size_t)h * 16 * 64 + lane;  // [h][qt][kt][lane]
     f32x4 bnext[4];
 #pragma unroll
@@ -251,16 +262,15 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) mma(kf[kt], qf[qt], s[kt]);
         if (masked) {
-            const int qi = qt * 16 + ar;
-            const int qlab = 3 * region3(wy * WS + (qi >> 3), a.H, WS, a.shift) + region3(wx * WS + (qi & 7), a.W, WS, a.shift);
+            // label(q) != label(k)  <=>  the row halves differ (last window row only) or the column halves differ (last
+            // window column only); key row = 2 kt + (ag >> 1), key column = 4 (ag & 1) + r, query row = 2 qt + (ar >> 3)
+            const bool qrow = last_row && 2 * qt + (ar >> 3) >= WS - a.shift;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                const float rowneg = (last_row && 2 * kt + (ag >> 1) >= WS - a.shift) != qrow ? -100.0f : 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ki = kt * 16 + ag * 4 + r;
-                    const int klab = 3 * region3(wy * WS + (ki >> 3), a.H, WS, a.shift) + region3(wx * WS + (ki & 7), a.W, WS, a.shift);
-                    if (klab != qlab) s[kt][r] += -100.0f;
-                }
+                for (int r = 0; r < 4; ++r) s[kt][r] += fminf(rowneg, colneg[r]);
+            }
         }
         float mx = -3.0e38f;
 #pragma unroll
@@ -270,11 +280,12 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
         mx = wave_max_xor(mx, 16);
         mx = wave_max_xor(mx, 32);
         float sum = 0.f;
+        const float nmx = -mx * 1.4426950408889634f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], 1.4426950408889634f, nmx));  // exp(s - max): one fma + v_exp
                 s[kt][r] = e;
                 sum += e;
             }
@@ -335,11 +346,9 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool real = h * 32 + n * 16 + ag * 4 + r < a.C;
-                        const float v = real ? xr[m][n][r] : 0.f;
-                        s1 += v;
-                        s2 += v * v;
+                    for (int r = 0; r < 4; ++r) {  // pad channels of x1 are exactly 0 (zero weight rows / bias / residual pad)
+                        s1 += xr[m][n][r];
+                        s2 += xr[m][n][r] * xr[m][n][r];
                     }
                 s1 = wave_sum_xor(s1, 16);
                 s1 = wave_sum_xor(s1, 32);
@@ -363,11 +372,12 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
                     }
                     const float mean = s1 * inv;
                     const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.eps);
+                    const float nmr = -mean * rstd;
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const f32x4 o = (xr[m][n] - mean) * rstd;  // gamma2 / beta2 are folded into w1p / b1
-                        bf16x4 ob;
-                        ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
+                        bf16x4 ob;  // gamma2 / beta2 are folded into w1p / b1
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ob[r] = (bf16)__builtin_fmaf(xr[m][n][r], rstd, nmr);
                         char* dst = reinterpret_cast<char*>(Aimg + (h * 4 + n * 2 + (ag >> 1)) * NTOK + m * 16 + ar) + (ag & 1) * 8;
                         *reinterpret_cast<bf16x4*>(dst) = ob;
                     }
@@ -381,9 +391,10 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
                 const f32x4 c0 = load4(a.b1 + h * 64 + half * 32 + ag * 4), c1 = load4(a.b1 + h * 64 + half * 32 + 16 + ag * 4);
                 f32x4 acc[4][2];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4)(0.0f);
+                for (int m = 0; m < 4; ++m) {
+                    acc[m][0] = c0;
+                    acc[m][1] = c1;
+                }
 #pragma unroll
                 for (int c = 0; c < KC; ++c) {
                     const int t = 4 * KC + half * KC + c;
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
                     char* hbase = reinterpret_cast<char*>(Himg + (col >> 3) * NTOK + ar) + (ag & 1) * 8;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        const f32x4 v = acc[m][n] + (n == 0 ? c0 : c1);
+                        const f32x4 v = acc[m][n];
                         bf16x4 hb;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) hb[r] = (bf16)gelu_bf16(v[r]);
