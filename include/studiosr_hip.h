@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -28,6 +28,13 @@ enum { SR_PAD_NONE = 0, SR_PAD_EVAL_MIRROR = 1, SR_PAD_REFLECT = 2 };
 enum { SR_MAP_IDENTITY = 0, SR_MAP_WINDOW = 1 };
 enum { SR_EPI_STD = 0, SR_EPI_QKV = 1, SR_EPI_QKV_OCA = 2 };
 enum { SR_OUT_NHWC = 0, SR_OUT_PIXEL_SHUFFLE = 1, SR_OUT_FINAL_NCHW = 2 };
+/* Row half of the cyclic shift (torch.roll over H, swinir.py:154,168) and of the shift mask (common.py:250-274):
+ *   SR_Y_ROLL        whole image on this device: rows are rolled by `shift` in addressing, full mask      (default)
+ *   SR_Y_STRIP       row strip of a larger image whose rows were rolled by the host's halo exchange (the buffer already
+ *                    holds rows [r0+shift, r1+shift) of the image): no row roll in addressing, no row mask
+ *   SR_Y_STRIP_LAST  as SR_Y_STRIP for the strip that ends with the wrapped window row: the row mask applies
+ * The column half (`shift`) is unchanged in every mode. */
+enum { SR_Y_ROLL = 0, SR_Y_STRIP = 1, SR_Y_STRIP_LAST = 2 };
 
 int sr_abi_version(void);
 const char* sr_last_error(void);
@@ -71,6 +78,7 @@ typedef struct SrGemm {
     int oca_pad;          /* SR_EPI_QKV_OCA (HAT OCAB, hat.py:247-264): q -> window order as SR_EPI_QKV; k -> zero-bordered image
                            * [B][H+2p][W+2p][heads][hd_p]; v -> transposed zero-bordered [B][heads][hd_p][(H+2p)*(W+2p)]; p = oca_pad = physical border (multiple of 4).
                            * Rows must be in window order (a_map = SR_MAP_WINDOW, shift 0); the borders are zeroed by the caller. */
+    int y_mode;           /* SR_Y_* (window maps only) */
 } SrGemm;
 int sr_gemm(const SrGemm* a, void* stream);
 
@@ -97,6 +105,7 @@ typedef struct SrSwinAttn {
     const void* w2p;      /* packed fc2 [Cp x Hp] bf16 */
     const float* b2;      /* [Cp] */
     int Hp;               /* 384 */
+    int y_mode;           /* SR_Y_* */
 } SrSwinAttn;
 int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype);
 int sr_swin_attn_fused(const SrSwinAttn* a, void* stream);
@@ -154,6 +163,7 @@ typedef struct SrWindowAttn {
     int n_bwin, heads, hd_p, ntok;
     int H, W, ws, shift;  /* mask geometry (shift == 0 -> no mask) */
     int dtype;
+    int y_mode;           /* SR_Y_* */
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
 

@@ -4,7 +4,7 @@
 the math runs in hand-written HIP kernels behind the C ABI of include/studiosr_hip.h.  GPU only: there
 is no CPU fallback (use the reference for CPU runs).
 """
-from . import _lib, models, ops, packing, runtime  # noqa: F401
+from . import _lib, models, ops, packing, parallel, runtime, strips  # noqa: F401
 from .models import EDSR, HAT, RCAN, SwinIR  # noqa: F401
 
 __version__ = "0.1.0"

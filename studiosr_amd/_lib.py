@@ -20,7 +20,9 @@ PAD_NONE, PAD_EVAL_MIRROR, PAD_REFLECT = 0, 1, 2
 MAP_IDENTITY, MAP_WINDOW = 0, 1
 EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
+Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
+ABI_VERSION = 2
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -35,7 +37,7 @@ class SrGemm(C.Structure):
         ("a_map", _i), ("o_map", _i),
         ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
         ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
-        ("ln_eps", _f), ("ln_norm_only", _i), ("oca_pad", _i),
+        ("ln_eps", _f), ("ln_norm_only", _i), ("oca_pad", _i), ("y_mode", _i),
     ]
 
 
@@ -43,7 +45,7 @@ class SrSwinAttn(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("bias", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
-        ("eps", _f), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("Hp", _i),
+        ("eps", _f), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("Hp", _i), ("y_mode", _i),
     ]
 
 
@@ -69,7 +71,7 @@ class SrWindowAttn(C.Structure):
     _fields_ = [
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
         ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
-        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i),
+        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i), ("y_mode", _i),
     ]
 
 
@@ -143,7 +145,7 @@ def lib() -> C.CDLL:
                 for name, (res, args) in SYMBOLS.items():
                     fn = getattr(handle, name)  # AttributeError if the ABI drifted
                     fn.restype, fn.argtypes = res, args
-                if handle.sr_abi_version() != 1:
+                if handle.sr_abi_version() != ABI_VERSION:
                     raise HipLibraryError("libstudiosr_hip.so ABI version mismatch")
                 _lib = handle
     return _lib

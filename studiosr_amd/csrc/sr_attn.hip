@@ -100,14 +100,15 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
     const int nwy = a.H / a.ws;
     const int win = bwin % (nwx * nwy);
     const int wy = win / nwx, wx = win - wy * nwx;
-    const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+    const bool ymask = a.y_mode != SR_Y_STRIP;  // a middle strip of a larger image has no wrapped window row
+    const bool masked = a.shift > 0 && ((ymask && wy == nwy - 1) || wx == nwx - 1);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qi = (qb * QT + t) * 16 + lr;
         int qlab = 0;
         if (masked) {
             const int i = qi / a.ws, j = qi - i * a.ws;
-            qlab = 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) + region(wx * a.ws + j, a.W, a.ws, a.shift);
+            qlab = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + j, a.W, a.ws, a.shift);
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
                 for (int r = 0; r < 4; ++r) {
                     const int ki = k0 + r;
                     const int i = ki / a.ws, j = ki - i * a.ws;
-                    const int klab = 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) + region(wx * a.ws + j, a.W, a.ws, a.shift);
+                    const int klab = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + j, a.W, a.ws, a.shift);
                     if (klab != qlab) s[kt][t][r] += -100.0f;
                 }
             }

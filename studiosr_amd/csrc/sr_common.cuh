@@ -219,6 +219,7 @@ SR_DEV float gelu_bf16(float x) {
 // window_reverse + roll(+shift) is the same map used as a scatter).
 struct WinMap {
     int H, W, ws, shift, nwx, ntok, hw;
+    int shift_y;  // = shift, or 0 for a row strip that the host already rolled (SR_Y_STRIP*)
     SR_DEV int operator()(int row) const {
         int b = row / hw;
         int rem = row - b * hw;
@@ -226,7 +227,7 @@ struct WinMap {
         int tok = rem - win * ntok;
         int wy = win / nwx, wx = win - wy * nwx;
         int i = tok / ws, j = tok - i * ws;
-        int y = wy * ws + i + shift;
+        int y = wy * ws + i + shift_y;
         int x = wx * ws + j + shift;
         if (y >= H) y -= H;
         if (x >= W) x -= W;

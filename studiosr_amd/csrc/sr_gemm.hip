@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void sr_gemm_kernel(SrGemm g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * GemmCfg<TC>::M_T;
     WinMap wm;
-    wm.H = g.H; wm.W = g.W; wm.ws = g.ws; wm.shift = g.shift;
+    wm.H = g.H; wm.W = g.W; wm.ws = g.ws; wm.shift = g.shift; wm.shift_y = g.y_mode == SR_Y_ROLL ? g.shift : 0;
     wm.nwx = g.ws > 0 ? g.W / g.ws : 1;
     wm.ntok = g.ws * g.ws;
     wm.hw = g.H * g.W;

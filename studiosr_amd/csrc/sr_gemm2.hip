@@ -35,7 +35,7 @@ SR_DEV int win_map(const Gemm2& a, int row) {
     uint32_t wy, wx;
     a.div_nwx.divmod(win, wy, wx);
     const int i = tok >> a.ws_log2, j = tok & ((1 << a.ws_log2) - 1);
-    int y = (wy << a.ws_log2) + i + a.g.shift;
+    int y = (wy << a.ws_log2) + i + (a.g.y_mode == SR_Y_ROLL ? a.g.shift : 0);
     int x = (wx << a.ws_log2) + j + a.g.shift;
     if (y >= a.g.H) y -= a.g.H;
     if (x >= a.g.W) x -= a.g.W;

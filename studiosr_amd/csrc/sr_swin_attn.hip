@@ -75,9 +75,10 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     if (!live) widx = n_windows - 1;
     dv.div_nw.divmod((uint32_t)widx, bimg, win);
     dv.div_nwx.divmod(win, wy, wx);
+    const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;  // strips arrive already rolled in y (halo exchange)
     auto pixel_row = [&](int m) {  // image-order row of token 16m + ar (roll + partition as one gather); recomputed at
         const int t = m * 16 + ar;  // both ends of the kernel instead of holding 4 addresses in registers throughout
-        int y = wy * WS + (t >> 3) + a.shift;
+        int y = wy * WS + (t >> 3) + shift_y;
         int x = wx * WS + (t & 7) + a.shift;
         if (y >= a.H) y -= a.H;
         if (x >= a.W) x -= a.W;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
     STAMP(6);
 
     // ---- S2: attention for head h, one 16-query tile at a time; the bias fragments of tile qt+1 are in flight
-    const bool last_row = (int)wy == a.H / WS - 1, last_col = (int)wx == a.W / WS - 1;
+    const bool last_row = a.y_mode != SR_Y_STRIP && (int)wy == a.H / WS - 1, last_col = (int)wx == a.W / WS - 1;
     const bool masked = a.shift > 0 && (last_row || last_col);
     f32x4 colneg = (f32x4)(0.0f);  // -100 where the key's column half differs from the query's (same for every query tile)
     if (masked) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(768, 3) void sr_swin_attn_kernel(SwinAttnDev dv) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int t = m * 16 + arl;
-            int y = wy * WS + (t >> 3) + a.shift;
+            int y = wy * WS + (t >> 3) + shift_y;
             int x = wx * WS + (t & 7) + a.shift;
             if (y >= a.H) y -= a.H;
             if (x >= a.W) x -= a.W;
@@ -483,7 +484,8 @@ extern "C" int sr_swin_attn_fused(const SrSwinAttn* p, void* stream) {
     SR_REQUIRE(p && p->x && p->out && p->wqkv && p->bqkv && p->wproj && p->bproj && p->bias, "sr_swin_attn_fused: null pointer");
     const SrSwinAttn& a = *p;
     SR_REQUIRE(sr_swin_attn_supported(a.Cp, a.heads, a.hd_p, a.ws, SR_BF16), "sr_swin_attn_fused: unsupported geometry (use sr_gemm + sr_window_attention)");
-    SR_REQUIRE(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp,
+    SR_REQUIRE(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp &&
+                   a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_attn_fused: bad geometry");
     SwinAttnDev dv;
     dv.a = a;

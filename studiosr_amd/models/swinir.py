@@ -144,7 +144,7 @@ def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[
     return dict(fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b)
 
 
-def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_, cdt: torch.dtype, shift: int) -> None:
+def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_, cdt: torch.dtype, shift: int, y_mode: int = L.Y_ROLL) -> None:
     """t_out = SwinTransformerBlock(t_in) (swinir.py:146-174): ONE launch when the fused kernel covers the geometry
     (attention half + MLP half on the same window), otherwise attention and MLP as separate launches."""
     B, H, W, Cp = t_in.shape
@@ -154,14 +154,15 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
             x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
             bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
             hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, w1p=p["fc1_w"].data_ptr(), b1=p["fc1_b"].data_ptr(), w2p=p["fc2_w"].data_ptr(),
-            b2=p["fc2_b"].data_ptr(), Hp=geo.hid_p,
+            b2=p["fc2_b"].data_ptr(), Hp=geo.hid_p, y_mode=y_mode,
         )
         return
-    run_window_msa(p, p["ln1"], geo, t_in, t_out, t_in, ws_, cdt, shift)
+    run_window_msa(p, p["ln1"], geo, t_in, t_out, t_in, ws_, cdt, shift, y_mode=y_mode)
     run_mlp(p, p["ln2"], geo, t_out, ws_, cdt)
 
 
-def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa") -> None:
+def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
+                   y_mode: int = L.Y_ROLL) -> None:
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip)."""
     B, H, W, Cp = t_in.shape
@@ -172,7 +173,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
         ops.swin_attn_fused(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
             bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
-            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5,
+            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode,
         )
         return
     q = ws_.get(name + ".q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
@@ -183,16 +184,16 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
         A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
         ln_beta=None if fold_ln(cdt) else ln[1].data_ptr(), ln_norm_only=int(fold_ln(cdt)), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
         a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
-        H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5,
+        H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5, y_mode=y_mode,
     )
     ops.window_attention(
         q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
-        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt,
+        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode,
     )
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,
-        out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_STD,
+        out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_STD, y_mode=y_mode,
     )
 
 
@@ -382,6 +383,13 @@ class SwinIR(Model):
             wp, b, r, cps_p = P["up"][0]
             conv_call(body, wp, b, out, cdt, out_mode=L.OUT_FINAL_NCHW, ps_r=r, cps_p=cps_p, fin=fin, cout_p=r * r * cps_p)
         return out
+
+    def forward_strips(self, x: Tensor, comm) -> Tensor:
+        """forward() of ONE image, row-strip sharded with per-layer halo exchange (studiosr_amd/strips.py; SURVEY.md
+        section 8e, config 4).  `comm` is a strips.DistStripComm (one strip per process / GPU) or a strips.LocalStripComm."""
+        from ..strips import swinir_forward_strips
+
+        return swinir_forward_strips(self, x, comm)
 
     # ------------------------------------------------------------------ reference API
     def get_model_config(self) -> Dict:

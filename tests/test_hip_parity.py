@@ -245,6 +245,41 @@ def test_edsr_x4_batch16_invariants():
 
 
 # ----------------------------------------------------------------------------- error behaviour
+# ----------------------------------------------------------------------------- one image, row-strip sharded (section 8e, config 4)
+def _randomised(m, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p_ in m.parameters():  # _init_weights zeroes biases / sets LN to identity: make every term count
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.02 if p_.dim() > 1 else 0.1) + (1.0 if p_.dim() == 1 and p_.numel() in (60, 180) else 0.0))
+    return m
+
+
+@pytest.mark.parametrize("cfg,prec", [
+    (dict(scale=4, embed_dim=180, depths=[2, 2], num_heads=[6, 6]), "bf16"),   # fused one-launch block kernel
+    (dict(scale=4, embed_dim=180, depths=[2, 2], num_heads=[6, 6]), "fp32"),   # exact-fp32 GEMM + window-attention path
+    (dict(scale=2, embed_dim=60, depths=[2], num_heads=[6]), "bf16"),          # generic bf16 path
+    (dict(scale=3, embed_dim=60, depths=[2, 2], num_heads=[6, 6], upsampler="pixelshuffledirect"), "fp32"),
+])
+def test_swinir_row_strips_with_halo_exchange_equal_the_unsharded_forward(cfg, prec):
+    """Strips see exactly the operands the unsharded kernels see (same windows, same conv neighbourhoods), so the
+    results must be IDENTICAL, not just close: 1, 2, 3 and 5 strips of uneven height, all in this process."""
+    from studiosr_amd.strips import LocalStripComm
+
+    torch.manual_seed(0)
+    m = _randomised(S.SwinIR(**cfg)).to(DEV).eval().set_precision(prec)
+    x = torch.rand(1, 3, 37, 52, device=DEV)  # eval pad -> 40 x 56: 5 window rows, 7 window columns
+    with torch.no_grad():
+        ref = m(x)
+        for world in (1, 2, 3, 5):
+            out = m.forward_strips(x, LocalStripComm(world))
+            assert out.shape == ref.shape
+            assert torch.equal(out, ref), f"{world} strips: max |diff| = {float((out - ref).abs().max())}"
+    if prec == "fp32":  # and the unsharded forward itself is pinned to the oracle
+        sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+        o = OM.swinir_forward(sd, x.cpu(), m.get_model_config())
+        assert float((ref.cpu() - o).abs().max()) <= FP32_TOL * max(1.0, float(o.abs().max()))
+
+
 def test_errors_are_loud():
     m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).to(DEV).eval()
     with pytest.raises(RuntimeError):
