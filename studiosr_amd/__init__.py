@@ -5,6 +5,8 @@ the math runs in hand-written HIP kernels behind the C ABI of include/studiosr_h
 is no CPU fallback (use the reference for CPU runs).
 """
 from . import _lib, models, ops, packing, parallel, runtime, strips  # noqa: F401
+from .evaluator import Evaluator  # noqa: F401
+from .metrics import compute_psnr, compute_ssim  # noqa: F401
 from .models import EDSR, HAT, RCAN, SwinIR  # noqa: F401
 
 __version__ = "0.1.0"
