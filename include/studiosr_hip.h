@@ -181,6 +181,12 @@ typedef struct SrOcaAttn {
 } SrOcaAttn;
 int sr_oca_attention(const SrOcaAttn* a, void* stream);
 
+/* Model.inference front / back end (common.py:42-45), batched: uint8 HWC [B,H,W,C] -> fp32 NCHW, out = u8 / divisor
+ * (255 iff img_range == 1.0, common.py:39), and fp32 NCHW -> uint8 HWC, out = uint8(clip(round_half_even(x * mult), 0, 255)).
+ * IEEE fp32 division / multiplication: bit-identical to the reference's numpy / torch ops. */
+int sr_u8_to_nchw(const unsigned char* in, float* out, int B, int C, int H, int W, float divisor, void* stream);
+int sr_nchw_to_u8(const float* in, unsigned char* out, int B, int C, int H, int W, float mult, void* stream);
+
 /* nn.PixelShuffle (common.py:129,133,136) standalone: out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w].
  * elem_size 2 or 4 bytes; tensors are plain NCHW. Bit-exact copy. */
 int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, int B, int C_out, int H, int W, int r,

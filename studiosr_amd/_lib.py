@@ -108,6 +108,8 @@ SYMBOLS = {
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
     "sr_oca_attention": (_i, [C.POINTER(SrOcaAttn), _vp]),
     "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_u8_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sr_nchw_to_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),
 }
 

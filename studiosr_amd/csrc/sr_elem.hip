@@ -40,6 +40,25 @@ __global__ __launch_bounds__(256) void sr_ingest_kernel(const float* __restrict_
     }
 }
 
+// ----------------------------------------------------------------------------- uint8 front / back end of Model.inference
+// common.py:42-45: x = u8 / scale, HWC -> CHW ... out * scale, round (half to even), clip(0, 255), uint8, CHW -> HWC.
+// IEEE fp32 division / multiplication and v_rndne, i.e. bit-identical to the numpy / torch ops of the reference.
+__global__ __launch_bounds__(256) void sr_u8_to_nchw_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long total, int C, int HW, float divisor) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {  // i over [B][C][HW]
+        const long p = i % HW, bc = i / HW;
+        const long c = bc % C, b = bc / C;
+        out[i] = __fdiv_rn((float)in[(b * HW + p) * C + c], divisor);
+    }
+}
+__global__ __launch_bounds__(256) void sr_nchw_to_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, long total, int C, int HW, float mult) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {  // i over [B][HW][C]
+        const long c = i % C, bp = i / C;
+        const long p = bp % HW, b = bp / HW;
+        const float v = rintf(__fmul_rn(in[(b * C + c) * HW + p], mult));
+        out[i] = (uint8_t)fminf(fmaxf(v, 0.0f), 255.0f);  // NaN -> 0 like torch's clip + cast on this platform is not relied upon
+    }
+}
+
 // ----------------------------------------------------------------------------- LayerNorm
 // 8 lanes per row (lane kq owns K-groups kq, kq+8, ...), two-pass statistics in registers.
 __global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
@@ -193,6 +212,22 @@ extern "C" int sr_ingest_nchw(const float* x, void* out, int out_dtype, int B, i
         hipLaunchKernelGGL(sr_ingest_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, reinterpret_cast<float*>(out), B, C, H, W, Hp, Wp, Cp, pad_mode,
                            scale, bias);
     SR_CHECK_LAUNCH("sr_ingest_nchw");
+    return SR_OK;
+}
+
+extern "C" int sr_u8_to_nchw(const unsigned char* in, float* out, int B, int C, int H, int W, float divisor, void* stream) {
+    SR_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && divisor > 0.f, "sr_u8_to_nchw: bad arguments");
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(sr_u8_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, total, C, H * W, divisor);
+    SR_CHECK_LAUNCH("sr_u8_to_nchw");
+    return SR_OK;
+}
+
+extern "C" int sr_nchw_to_u8(const float* in, unsigned char* out, int B, int C, int H, int W, float mult, void* stream) {
+    SR_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0, "sr_nchw_to_u8: bad arguments");
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(sr_nchw_to_u8_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, total, C, H * W, mult);
+    SR_CHECK_LAUNCH("sr_nchw_to_u8");
     return SR_OK;
 }
 

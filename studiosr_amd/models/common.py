@@ -73,17 +73,36 @@ class Model(nn.Module):
         return x.detach().to(torch.float32).contiguous()
 
     # ------------------------------------------------------------------ reference API
+    def _io_scale(self) -> float:
+        return 255.0 if self.img_range == 1.0 else 1.0  # common.py:39
+
     @torch.inference_mode()
     def inference(self, image: np.ndarray) -> np.ndarray:
-        """uint8 HWC -> uint8 HWC (studiosr/models/common.py:36-48): /scale, NCHW, forward, *scale,
-        round-half-even, clip, uint8; scale = 255 iff img_range == 1.0."""
+        """uint8 HWC -> uint8 HWC (studiosr/models/common.py:36-48): /scale, NCHW, forward, *scale, round-half-even, clip,
+        uint8; scale = 255 iff img_range == 1.0.  The uint8 image crosses PCIe as uint8; both conversions are HIP kernels
+        with the reference's fp32 arithmetic (sr_u8_to_nchw / sr_nchw_to_u8)."""
+        return self.inference_batch([image])[0]
+
+    @torch.inference_mode()
+    def inference_batch(self, images: List[np.ndarray]) -> List[np.ndarray]:
+        """`inference` of several images at once: images of equal size share one forward (batch items are independent, so
+        every result equals the one-image call); results come back in input order."""
         self.eval()
-        scale = 255.0 if self.img_range == 1.0 else 1.0
+        scale = self._io_scale()
         device = next(self.parameters()).device
-        x = torch.from_numpy(image.astype(np.float32) / scale).to(device)
-        x = x.permute(2, 0, 1).unsqueeze(0).contiguous()
-        out = self.forward(x)[0].permute(1, 2, 0) * scale
-        return out.round().clip(0, 255).to(torch.uint8).cpu().numpy()
+        require_device(torch.empty(0, device=device))
+        outs: List[Optional[np.ndarray]] = [None] * len(images)
+        groups: Dict = {}
+        for i, im in enumerate(images):
+            if im.ndim != 3 or im.shape[2] != self.n_colors:
+                raise RuntimeError(f"expected uint8 image [H,W,{self.n_colors}], got {tuple(im.shape)}")
+            groups.setdefault(tuple(im.shape), []).append(i)
+        for idxs in groups.values():
+            u8 = torch.from_numpy(np.ascontiguousarray(np.stack([images[i] for i in idxs]).astype(np.uint8, copy=False))).to(device)
+            y = ops.nchw_to_u8(self.forward(ops.u8_to_nchw(u8, scale)).contiguous(), scale).cpu().numpy()
+            for j, i in enumerate(idxs):
+                outs[i] = y[j]
+        return outs  # type: ignore[return-value]
 
     @torch.inference_mode()
     def inference_with_self_ensemble(self, image: np.ndarray) -> np.ndarray:
@@ -91,9 +110,9 @@ class Model(nn.Module):
         batched into one forward (the reference runs 8 sequential forwards; results are identical because
         batch items are independent)."""
         self.eval()
-        scale = 255.0 if self.img_range == 1.0 else 1.0
+        scale = self._io_scale()
         device = next(self.parameters()).device
-        img = torch.from_numpy(image.astype(np.float32) / scale).to(device)
+        img = torch.from_numpy(np.ascontiguousarray(image.astype(np.uint8, copy=False))).to(device)  # rot / flip on uint8: exact
         variants = []
         for k in range(4):
             r = torch.rot90(img, k, dims=[0, 1])
@@ -103,7 +122,7 @@ class Model(nn.Module):
         for i, v in enumerate(variants):
             groups.setdefault(tuple(v.shape), []).append(i)
         for idxs in groups.values():
-            xb = torch.stack([variants[i].permute(2, 0, 1) for i in idxs]).contiguous()
+            xb = ops.u8_to_nchw(torch.stack([variants[i] for i in idxs]).contiguous(), scale)
             yb = self.forward(xb)
             for j, i in enumerate(idxs):
                 outs[i] = yb[j].permute(1, 2, 0)
@@ -111,8 +130,8 @@ class Model(nn.Module):
         for i, o in enumerate(outs):
             o = torch.fliplr(o) if i & 1 else o
             merged.append(torch.rot90(o, i // 2, dims=[1, 0]))
-        out = torch.stack(merged).mean(dim=0) * scale
-        return out.round().clip(0, 255).to(torch.uint8).cpu().numpy()
+        out = torch.stack(merged).mean(dim=0)  # converge_images (common.py:19-26)
+        return ops.nchw_to_u8(out.permute(2, 0, 1).unsqueeze(0).contiguous(), scale)[0].cpu().numpy()
 
     def get_model_config(self) -> Dict:
         return dict(scale=self.scale, n_colors=self.n_colors, img_range=self.img_range)

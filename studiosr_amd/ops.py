@@ -114,5 +114,23 @@ def pixel_shuffle(x: Tensor, r: int) -> Tensor:
     return out
 
 
+def u8_to_nchw(img: Tensor, divisor: float) -> Tensor:
+    """uint8 [B,H,W,C] -> fp32 [B,C,H,W] = u8 / divisor (Model.inference front end, common.py:42-43)."""
+    assert img.dtype == torch.uint8 and img.dim() == 4 and img.is_contiguous()
+    B, H, W, Cc = img.shape
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=img.device)
+    L.check(L.lib().sr_u8_to_nchw(_p(img), _p(out), B, Cc, H, W, float(divisor), _stream()), "sr_u8_to_nchw")
+    return out
+
+
+def nchw_to_u8(x: Tensor, mult: float) -> Tensor:
+    """fp32 [B,C,H,W] -> uint8 [B,H,W,C] = clip(round_half_even(x * mult), 0, 255) (common.py:44-45)."""
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().sr_nchw_to_u8(_p(x), _p(out), B, Cc, H, W, float(mult), _stream()), "sr_nchw_to_u8")
+    return out
+
+
 def conv_pool_tiles(H: int, W: int, cout_p: int, compute_dtype: int) -> int:
     return L.lib().sr_conv3x3_pool_tiles(H, W, cout_p, compute_dtype)

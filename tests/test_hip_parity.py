@@ -140,6 +140,26 @@ def test_inference_uint8_and_self_ensemble_against_reference():
     ye = m.inference_with_self_ensemble(g["img"])
     de = np.abs(ye.astype(int) - g["y_ens"].astype(int))
     assert de.max() <= 1 and (de > 0).mean() < 2e-3
+    # batched front end: images of two sizes, results in input order and equal to the one-image calls
+    rng = np.random.default_rng(0)
+    other = rng.integers(0, 256, size=(7, 10, 3), dtype=np.uint8)
+    ys = m.inference_batch([g["img"], other, g["img"][::-1].copy()])
+    assert np.array_equal(ys[0], y) and np.array_equal(ys[1], m.inference(other)) and np.array_equal(ys[2], m.inference(g["img"][::-1].copy()))
+
+
+def test_uint8_front_and_back_end_are_bit_exact():
+    """sr_u8_to_nchw / sr_nchw_to_u8 against the reference's own ops (common.py:42-45) incl. ties, negatives, > 255."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(2, 5, 7, 3), dtype=np.uint8)
+    for div in (255.0, 1.0):
+        got = ops.u8_to_nchw(torch.from_numpy(img).to(DEV), div).cpu()
+        want = torch.from_numpy(img.astype(np.float32) / div).permute(0, 3, 1, 2)
+        assert torch.equal(got, want)
+    x = torch.cat([torch.rand(2, 3, 5, 7) * 1.2 - 0.1, (torch.arange(210).float().view(2, 3, 5, 7) + 0.5) / 255.0])  # incl. exact .5 ties
+    for mult in (255.0, 1.0):
+        got = ops.nchw_to_u8(x.to(DEV).contiguous(), mult).cpu()
+        want = (x.permute(0, 2, 3, 1) * mult).round().clip(0, 255).to(torch.uint8)
+        assert torch.equal(got, want)
 
 
 def test_autocast_selects_bf16_like_the_reference_trainer():
