@@ -143,23 +143,41 @@ SR_DEV f32x4 ld4(const void* p, size_t off, int dtype) {
 
 __global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
     extern __shared__ float sm[];
-    float* mean = sm;           // [C]
-    float* hid = sm + a.C_p;    // [Cr]
-    float* gate = hid + a.Cr;   // [C_p]
+    float* mean = sm;                 // [C_p]
+    float* hid = sm + a.C_p;          // [Cr]
+    float* gate = hid + a.Cr;         // [C_p]
+    float* part = gate + a.C_p;       // [CA_SLICES][C_p] partial channel sums
+    constexpr int CA_SLICES = 8;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / (float)(a.H * a.W);
-    for (int c = tid; c < a.C_p; c += 256) {
+    // The squeeze MLP is recomputed by every workgroup, so it must be short: every step spreads its (independent) loads
+    // over all 256 threads instead of walking n_tiles / C / Cr dependent loads in a few of them.
+    for (int idx = tid; idx < CA_SLICES * a.C_p; idx += 256) {
+        const int sl = idx / a.C_p, c = idx - sl * a.C_p;
         float s = 0.f;
         if (c < a.C)
-            for (int t = 0; t < a.n_tiles; ++t) s += a.pool_partial[((size_t)b * a.n_tiles + t) * a.C_p + c];
+            for (int t = sl; t < a.n_tiles; t += CA_SLICES) s += a.pool_partial[((size_t)b * a.n_tiles + t) * a.C_p + c];
+        part[idx] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C_p; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < CA_SLICES; ++sl) s += part[sl * a.C_p + c];
         mean[c] = s * inv;
     }
     __syncthreads();
-    for (int j = tid; j < a.Cr; j += 256) {
-        float s = a.b1[j];
-        for (int c = 0; c < a.C; ++c) s += a.w1[j * a.C + c] * mean[c];
-        hid[j] = s > 0.f ? s : 0.f;
+    for (int j = wave; j < a.Cr; j += 4) {  // one wave per hidden unit: lanes split the channels
+        float s = 0.f;
+        for (int c = lane; c < a.C; c += 64) s += a.w1[j * a.C + c] * mean[c];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            s += a.b1[j];
+            hid[j] = s > 0.f ? s : 0.f;
+        }
     }
     __syncthreads();
     for (int c = tid; c < a.C_p; c += 256) {
@@ -258,10 +276,11 @@ extern "C" int sr_channel_attention(const SrChannelAttn* p, void* stream) {
     SR_REQUIRE(p && p->y && p->pool_partial && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "sr_channel_attention: null pointer");
     const SrChannelAttn& a = *p;
     SR_REQUIRE(a.B > 0 && a.C > 0 && a.C <= a.C_p && a.C_p % 4 == 0 && a.Cr > 0 && a.n_tiles > 0, "sr_channel_attention: bad geometry");
-    const int lds = (2 * a.C_p + a.Cr) * (int)sizeof(float);
+    const int lds = (2 * a.C_p + a.Cr + 8 * a.C_p) * (int)sizeof(float);
     const long per_img = (long)a.H * a.W * (a.C_p / 4);
-    int gx = (int)((per_img + 255) / 256);
+    int gx = (int)((per_img + 256 * 8 - 1) / (256 * 8));  // >= 8 vector groups per thread: the squeeze prologue is paid per workgroup
     if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(sr_channel_attn_kernel, dim3(gx, a.B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_channel_attention");
     return SR_OK;
