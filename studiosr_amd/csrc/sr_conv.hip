@@ -137,25 +137,29 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         for (int t = 0; t < RING - 1; ++t)
 #pragma unroll
             for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + t) * 64];
+        // activation fragments are double buffered across chunks: the LDS reads of chunk t+1 are issued before the MFMAs of
+        // chunk t, so their latency (the only thing a one-wave-per-SIMD workgroup cannot hide otherwise) is off the critical path
+        const Frag<TC>* abase0 = As + (wm * MTW) * HALO_W + ar + ag * ROWS;
+        Frag<TC> af[2][MTW];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const Frag<TC>* abase = As + (wm * MTW + tap / 3) * HALO_W + (tap % 3) + ar + ag * ROWS;
+        for (int m = 0; m < MTW; ++m) af[0][m] = abase0[m * HALO_W];
 #pragma unroll
-            for (int kc = 0; kc < KCS; ++kc) {
-                const int t = tap * KCS + kc;
-                if (t + RING - 1 < KCTS) {
+        for (int t = 0; t < KCTS; ++t) {
+            if (t + RING - 1 < KCTS) {
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
-                }
-                const Frag<TC>* arow = abase + kc * 4 * ROWS;
-#pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    const Frag<TC> a = arow[m * HALO_W];
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], a, acc[m][n]);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // one fence per chunk: bounds live ranges, keeps the ring order
+                for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
             }
+            if (t + 1 < KCTS) {
+                const int tn = t + 1, tap = tn / KCS, kc = tn - tap * KCS;
+                const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * ROWS;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) af[tn & 1][m] = arow[m * HALO_W];
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) mma(br[t % RING][n], af[t & 1][m], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);  // one fence per chunk: bounds live ranges, keeps the ring order
         }
     } else {
         // generic channel count: run-time loop, weights double-buffered one chunk ahead
@@ -293,9 +297,11 @@ int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
 int launch_conv(const SrConv3x3& c, hipStream_t st) {
     if constexpr (sizeof(TC) == 2) {
+        if constexpr (NW < 4) {  // the 256-wide tile is only dispatched for Cin_p >= 128
+            if (c.Cin_p == 32) return launch_conv_k<TC, TIn, TH, WM, WN, NW, 1>(c, st);
+            if (c.Cin_p == 64) return launch_conv_k<TC, TIn, TH, WM, WN, NW, 2>(c, st);
+        }
         switch (c.Cin_p) {
-            case 32: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 1>(c, st);
-            case 64: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 2>(c, st);
             case 192: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 6>(c, st);
             case 256: return launch_conv_k<TC, TIn, TH, WM, WN, NW, 8>(c, st);
             default: break;
@@ -308,6 +314,9 @@ int launch_conv(const SrConv3x3& c, hipStream_t st) {
 template <typename TC, typename TIn, int TH>
 int dispatch_conv(const SrConv3x3& c, hipStream_t st) {
     const int n = c.Cout_p;
+    if constexpr (sizeof(TC) == 2) {
+        if (n % 256 == 0 && c.Cin_p >= 128) return launch_conv<TC, TIn, TH, 1, 4, 4>(c, st);  // 32 accumulator tiles per wave: one pass over the halo tile
+    }
     if (n % 192 == 0) return launch_conv<TC, TIn, TH, 1, 4, 3>(c, st);
     if (n % 128 == 0) return launch_conv<TC, TIn, TH, 1, 4, 2>(c, st);
     if (n % 64 == 0) return launch_conv<TC, TIn, TH, 2, 2, 2>(c, st);
