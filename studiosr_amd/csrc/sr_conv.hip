@@ -137,29 +137,48 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         for (int t = 0; t < RING - 1; ++t)
 #pragma unroll
             for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + t) * 64];
-        // activation fragments are double buffered across chunks: the LDS reads of chunk t+1 are issued before the MFMAs of
-        // chunk t, so their latency (the only thing a one-wave-per-SIMD workgroup cannot hide otherwise) is off the critical path
         const Frag<TC>* abase0 = As + (wm * MTW) * HALO_W + ar + ag * ROWS;
-        Frag<TC> af[2][MTW];
+        if constexpr (KCS >= 2) {
+            // activation fragments are double buffered across chunks: the LDS reads of chunk t+1 are issued before the MFMAs of
+            // chunk t, so their latency (the only thing a one-wave-per-SIMD workgroup cannot hide otherwise) is off the critical path
+            Frag<TC> af[2][MTW];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) af[0][m] = abase0[m * HALO_W];
+            for (int m = 0; m < MTW; ++m) af[0][m] = abase0[m * HALO_W];
 #pragma unroll
-        for (int t = 0; t < KCTS; ++t) {
-            if (t + RING - 1 < KCTS) {
+            for (int t = 0; t < KCTS; ++t) {
+                if (t + RING - 1 < KCTS) {
 #pragma unroll
-                for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
+                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
+                }
+                if (t + 1 < KCTS) {
+                    const int tn = t + 1, tap = tn / KCS, kc = tn - tap * KCS;
+                    const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * ROWS;
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) af[tn & 1][m] = arow[m * HALO_W];
+                }
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], af[t & 1][m], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);  // one fence per chunk: bounds live ranges, keeps the ring order
             }
-            if (t + 1 < KCTS) {
-                const int tn = t + 1, tap = tn / KCS, kc = tn - tap * KCS;
-                const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * ROWS;
+        } else {
+            // K = 9 x 32 only (RGB ingest conv): store-bound, keep the register count low enough for two workgroups per CU
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) af[tn & 1][m] = arow[m * HALO_W];
+            for (int t = 0; t < KCTS; ++t) {
+                if (t + RING - 1 < KCTS) {
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
+                }
+                const Frag<TC>* arow = abase0 + (t / 3) * HALO_W + (t % 3);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const Frag<TC> a = arow[m * HALO_W];
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], a, acc[m][n]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int n = 0; n < NW; ++n) mma(br[t % RING][n], af[t & 1][m], acc[m][n]);
-            __builtin_amdgcn_sched_barrier(0);  // one fence per chunk: bounds live ranges, keeps the ring order
         }
     } else {
         // generic channel count: run-time loop, weights double-buffered one chunk ahead
