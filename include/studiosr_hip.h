@@ -164,6 +164,8 @@ typedef struct SrWindowAttn {
     int H, W, ws, shift;  /* mask geometry (shift == 0 -> no mask) */
     int dtype;
     int y_mode;           /* SR_Y_* */
+    const float* bias_frag; /* optional: the same bias in accumulator-fragment order [heads][qt][kt][lane][4]
+                             * (element = bias[h][16 qt + (lane & 15)][16 kt + 4 (lane >> 4) + r]); selects the flash-form kernel */
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
 

@@ -180,6 +180,164 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
     }
 }
 
+// ----------------------------------------------------------------------------- flash form (bias in fragment order)
+// Same math, restructured for long windows (ws 16: 256 keys) where the kernel above is latency- and L1-bound (its
+// row-major fp32 bias reads touch 16 cache lines per wave instruction and its 32 S^T tiles leave one wave per SIMD):
+//   * one wave = (window, head, QT*16 queries); keys are walked in blocks of 64 with an online softmax
+//     (running max m, per-lane partial sum l, O rescaled by exp(m_old - m_new)), so only 4 x QT logit tiles are live;
+//   * the relative-position bias arrives in ACCUMULATOR-FRAGMENT order ([head][qt][kt][lane][4], packing.bias_fragments):
+//     each S^T tile is initialised by one coalesced 1 KiB load and the K Q^T MFMAs accumulate on top of it;
+//   * the 4 waves of a workgroup are 4 consecutive windows of the same (head, query block): they read the same bias
+//     tiles, which therefore come from the CU's L1.
+template <typename TC, int KT, int QT, int DC>
+__global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn a) {
+    static_assert(KT % 4 == 0 && KT % QT == 0, "key blocks of 64");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NTOK = KT * 16;
+    constexpr int QB = KT / QT;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n_bwin * a.heads * QB) return;  // wave-uniform; no barriers in this kernel
+    const int bwin = item % a.n_bwin;             // windows fastest: a workgroup shares (head, query block)
+    const int hq = item / a.n_bwin;
+    const int qb = hq % QB, head = hq / QB;
+    const int bh = bwin * a.heads + head;
+    constexpr int hd_p = DC * 32;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const TC* q = reinterpret_cast<const TC*>(a.q) + (size_t)bh * NTOK * hd_p;
+    const TC* k = reinterpret_cast<const TC*>(a.k) + (size_t)bh * NTOK * hd_p;
+    const TC* vt = reinterpret_cast<const TC*>(a.vt) + (size_t)bh * NTOK * hd_p;
+    const f32x4* bfrag = reinterpret_cast<const f32x4*>(a.bias_frag) + ((size_t)(head * KT + qb * QT) * KT) * 64 + lane;  // [qt][kt][lane]
+
+    Frag<TC> qf[QT][DC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
+
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+    const int win = bwin % (nwx * nwy);
+    const int wy = win / nwx, wx = win - wy * nwx;
+    const bool ymask = a.y_mode != SR_Y_STRIP;
+    const bool masked = a.shift > 0 && ((ymask && wy == nwy - 1) || wx == nwx - 1);
+    int qlab[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qlab[t] = 0;
+        if (masked) {
+            const int qi = (qb * QT + t) * 16 + lr;
+            const int i = qi / a.ws, j = qi - i * a.ws;
+            qlab[t] = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + j, a.W, a.ws, a.shift);
+        }
+    }
+
+    float m_run[QT], l_run[QT];
+    f32x4 o[2 * DC][QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -3.0e38f;
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2 * DC; ++dt) o[dt][t] = (f32x4)(0.0f);
+    }
+
+    for (int kb = 0; kb < KT / 4; ++kb) {
+        // ---- S^T tiles of this key block: bias tile + K Q^T
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[j][t] = bfrag[((size_t)t * KT + kb * 4 + j) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const Frag<TC> kf = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) mma(kf, qf[t][c], s[j][t]);
+            }
+        if (masked) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ki = (kb * 4 + j) * 16 + lg * 4 + r;
+                    const int i = ki / a.ws, jj = ki - i * a.ws;
+                    const int klab = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + jj, a.W, a.ws, a.shift);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t)
+                        if (klab != qlab[t]) s[j][t][r] += -100.0f;
+                }
+        }
+        // ---- online softmax update per query tile
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = s[0][t][0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][t][r]);
+            mx = wave_max_xor(mx, 16);
+            mx = wave_max_xor(mx, 32);
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * LOG2E);
+            m_run[t] = m_new;
+            const float nm = -m_new * LOG2E;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][t][r], LOG2E, nm));
+                    s[j][t][r] = e;
+                    sum += e;
+                }
+            l_run[t] = l_run[t] * alpha + sum;  // per-lane partial (this lane group's keys); combined once at the end
+#pragma unroll
+            for (int dt = 0; dt < 2 * DC; ++dt) o[dt][t] *= alpha;
+        }
+        // ---- O^T += V^T P^T  (32-key steps; key order inside a step as in the kernel above)
+#pragma unroll
+        for (int dt = 0; dt < 2 * DC; ++dt) {
+            const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag<TC> vf = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const Frag<TC> pf = pack_p<TC>(s[2 * ks][t], s[2 * ks + 1][t]);
+                    mma(vf, pf, o[dt][t]);
+                }
+            }
+        }
+    }
+
+    TC* out = reinterpret_cast<TC*>(a.out);
+    const int ldo = a.heads * hd_p;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = wave_sum_xor(l_run[t], 16);
+        l = wave_sum_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int qi = (qb * QT + t) * 16 + lr;
+#pragma unroll
+        for (int dt = 0; dt < 2 * DC; ++dt) {
+            f32x4 v = o[dt][t] * inv;
+            store4(out + ((size_t)bwin * NTOK + qi) * ldo + head * hd_p + dt * 16 + lg * 4, v);
+        }
+    }
+}
+
+template <typename TC, int KT, int QT, int DC>
+int launch_flash(const SrWindowAttn& a, hipStream_t st) {
+    const int items = a.n_bwin * a.heads * (KT / QT);
+    hipLaunchKernelGGL((sr_window_attn_flash_kernel<TC, KT, QT, DC>), dim3((items + 3) / 4), dim3(256), 0, st, a);
+    SR_CHECK_LAUNCH("sr_window_attention");
+    return SR_OK;
+}
+
 template <typename TC, int KT, int QT, int DC>
 int launch_attn(const SrWindowAttn& a, hipStream_t st) {
     const int items = a.n_bwin * a.heads * (KT / QT);
@@ -190,6 +348,12 @@ int launch_attn(const SrWindowAttn& a, hipStream_t st) {
 
 template <typename TC>
 int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
+    if (a.bias_frag) {  // fragment-ordered bias available: flash form
+        if (a.ntok == 256 && a.hd_p == 32) return launch_flash<TC, 16, 4, 1>(a, st);
+        if (a.ntok == 64 && a.hd_p == 32) return launch_flash<TC, 4, 4, 1>(a, st);
+        if (a.ntok == 256 && a.hd_p == 64) return launch_flash<TC, 16, 2, 2>(a, st);
+        if (a.ntok == 64 && a.hd_p == 64) return launch_flash<TC, 4, 4, 2>(a, st);
+    }
     if (a.ntok == 64 && a.hd_p == 32) return launch_attn<TC, 4, 4, 1>(a, st);
     if (a.ntok == 256 && a.hd_p == 32) return launch_attn<TC, 16, 2, 1>(a, st);
     if (a.ntok == 64 && a.hd_p == 64) return launch_attn<TC, 4, 4, 2>(a, st);

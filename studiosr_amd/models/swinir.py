@@ -188,7 +188,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     )
     ops.window_attention(
         q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
-        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode,
+        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
     )
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),

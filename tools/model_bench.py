@@ -21,7 +21,8 @@ def main():
     which = sys.argv[1:] or list(CASES)
     dev = torch.device("cuda")
     for kind in which:
-        B = CASES[kind]
+        kind, _, bs = kind.partition(":")  # "HAT:16" overrides the batch size
+        B = int(bs) if bs else CASES[kind]
         torch.manual_seed(0)
         m = getattr(S, kind)(scale=4).eval().to(dev).set_precision("bf16")
         x = torch.rand(B, 3, 64, 64, device=dev)
