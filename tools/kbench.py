@@ -59,9 +59,12 @@ def conv_bench():
     from studiosr_amd import packing
     dev = torch.device("cuda")
     cdt = torch.bfloat16
+    only = os.environ.get("KB_CONV")  # e.g. KB_CONV=16,64,64,256,256 runs that case alone
     for (B, H, W, cin, cout, mode) in [(1, 144, 144, 64, 256, "nhwc"), (2, 144, 144, 64, 256, "nhwc"), (4, 144, 144, 64, 256, "nhwc"), (1, 72, 72, 192, 192, "nhwc"), (8, 144, 144, 64, 256, "ps"), (8, 144, 144, 64, 256, "nhwc"), (8, 72, 72, 64, 256, "ps"), (8, 72, 72, 192, 192, "nhwc"),
                                        (8, 72, 72, 192, 192, "nhwc_f32"), (8, 288, 288, 64, 16, "nhwc"),
                                        (16, 64, 64, 256, 256, "nhwc"), (16, 64, 64, 256, 1024, "ps"), (16, 128, 128, 256, 1024, "ps"), (16, 64, 64, 64, 64, "nhwc")]:
+        if only and only != f"{B},{H},{W},{cin},{cout}":
+            continue
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
         if mode == "ps":
