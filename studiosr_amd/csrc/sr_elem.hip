@@ -117,6 +117,42 @@ __global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restri
 }
 
 // ----------------------------------------------------------------------------- PixelShuffle (NCHW, exact copy)
+// out[b, c, y*r + i, x*r + j] = in[b, c*r*r + i*r + j, y, x].  Pure HBM traffic (2 x tensor bytes).
+// Vector form: one thread owns V = 16 B / sizeof(T) consecutive x of one (b, c, y, i): it loads the r planes j = 0..r-1
+// with one 16-B load each, interleaves them in registers and writes r x 16 B of ONE output row contiguously, so both
+// sides move whole 16-B (per lane) / 1-KiB (per wave) runs.  Needs W % V == 0; other widths take the scalar form.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void sr_pixel_shuffle_vec_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Co, int H, int W) {
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int wv = W / V;
+    const long total = (long)B * Co * H * R * wv;
+    const size_t plane = (size_t)H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int xv = (int)(idx % wv);
+        long p = idx / wv;
+        const int i = (int)(p % R);
+        p /= R;
+        const int y = (int)(p % H);
+        const long bc = p / H;  // b * Co + c
+        const T* src = in + ((size_t)bc * (R * R) + (size_t)i * R) * plane + (size_t)y * W + (size_t)xv * V;
+        vec_t v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = *reinterpret_cast<const vec_t*>(src + (size_t)j * plane);
+        T* dst = out + ((size_t)bc * H * R + (size_t)y * R + i) * ((size_t)W * R) + (size_t)xv * V * R;
+#pragma unroll
+        for (int o = 0; o < R; ++o) {  // output vector o holds elements [o*V, o*V + V) of the interleaved run
+            vec_t w;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int k = o * V + e;  // position in the run: x offset k / R, plane k % R
+                w[e] = v[k % R][k / R];
+            }
+            *reinterpret_cast<vec_t*>(dst + o * V) = w;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sr_pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Co, int H, int W, int r) {
     const int Ho = H * r, Wo = W * r;
@@ -207,6 +243,11 @@ __global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
     }
 }
 
+int vec_grid_for(long nvec) {  // streaming kernels: enough workgroups to fill the chip several times over, grid-stride for the rest
+    long g = (nvec + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -262,7 +303,19 @@ extern "C" int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, i
     SR_REQUIRE(elem_size == 2 || elem_size == 4, "sr_pixel_shuffle_nchw: elem_size %d", elem_size);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)B * C_out * H * r * W * r;
-    if (elem_size == 2)
+    const int V = 16 / elem_size;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (W % V == 0 && aligned && r >= 2 && r <= 4) {
+        const long nvec = total / V;
+        const dim3 grid(vec_grid_for(nvec));
+#define SR_PS_VEC(T, R) hipLaunchKernelGGL((sr_pixel_shuffle_vec_kernel<T, R>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(in), reinterpret_cast<T*>(out), B, C_out, H, W)
+        if (elem_size == 2) {
+            if (r == 2) SR_PS_VEC(uint16_t, 2); else if (r == 3) SR_PS_VEC(uint16_t, 3); else SR_PS_VEC(uint16_t, 4);
+        } else {
+            if (r == 2) SR_PS_VEC(uint32_t, 2); else if (r == 3) SR_PS_VEC(uint32_t, 3); else SR_PS_VEC(uint32_t, 4);
+        }
+#undef SR_PS_VEC
+    } else if (elem_size == 2)
         hipLaunchKernelGGL(sr_pixel_shuffle_kernel<uint16_t>, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(in),
                            reinterpret_cast<uint16_t*>(out), B, C_out, H, W, r);
     else

@@ -44,6 +44,14 @@ def test_pixel_shuffle_kernel_bit_exact(r):
     xb = torch.arange(2 * 4 * r * r * 3 * 5, dtype=torch.int16).reshape(2, 4 * r * r, 3, 5)
     outb = ops.pixel_shuffle(xb.to(DEV).view(torch.bfloat16), r).view(torch.int16).cpu()
     assert torch.equal(outb, OF.pixel_shuffle(xb, r))
+    # widths that are a multiple of 16 bytes take the vector kernel (16-B loads, in-register interleave): same index map
+    for dt, w in ((torch.int16, 24), (torch.int32, 12)):
+        n = 3 * 5 * r * r * 6 * w
+        xv = (torch.arange(n, dtype=torch.int64) % 30011).to(dt).reshape(3, 5 * r * r, 6, w)
+        fdt = torch.bfloat16 if dt == torch.int16 else torch.float32
+        outv = ops.pixel_shuffle(xv.to(DEV).view(fdt), r).view(dt).cpu()
+        want = xv.reshape(3, -1)[:, torch.from_numpy(OF.pixel_shuffle_index_map(5, 6, w, r)).reshape(-1)].reshape(3, 5, 6 * r, w * r)
+        assert torch.equal(outv, want)
 
 
 @pytest.mark.parametrize("r,cps", [(2, 64), (3, 32), (4, 4)])

@@ -85,6 +85,37 @@ def conv_bench():
         print(f"conv B={B} {H}x{W} {cin}->{cout} {mode:9s}: {us:8.1f} us  {gf / us * 1e3:8.1f} TF/s", flush=True)
 
 
+def elem_bench():
+    """HBM-bound helpers in GB/s (bytes = read + written): python tools/kbench.py elem"""
+    from studiosr_amd import ops
+    dev = torch.device("cuda")
+    rows = []
+    for (B, C, H, W, r, dt) in [(8, 64, 144, 144, 2, torch.bfloat16), (16, 256, 128, 128, 2, torch.bfloat16), (8, 64, 72, 72, 2, torch.bfloat16),
+                                (8, 20, 96, 96, 3, torch.float32), (8, 4, 64, 64, 4, torch.float32)]:
+        x = torch.randn(B, C * r * r, H, W, device=dev).to(dt)
+        us = timeit(lambda: ops.pixel_shuffle(x, r))
+        ref = torch.nn.functional.pixel_shuffle(x, r)
+        ok = torch.equal(ops.pixel_shuffle(x, r), ref)
+        nbytes = 2 * x.numel() * x.element_size()
+        rows.append((f"pixel_shuffle [{B},{C * r * r},{H},{W}] r={r} {str(dt)[6:]}", us, nbytes, ok))
+    t = torch.randn(8, 72, 72, 192, device=dev)
+    o = torch.empty_like(t)
+    g, b = torch.ones(192, device=dev), torch.zeros(192, device=dev)
+    rows.append(("layernorm [8,72,72,192] fp32", timeit(lambda: ops.layernorm(t, o, g, b, 180)), 2 * t.numel() * 4, True))
+    x = torch.rand(8, 3, 64, 64, device=dev)
+    xin = torch.empty(8, 72, 72, 32, device=dev, dtype=torch.bfloat16)
+    sc, bi = torch.ones(3, device=dev), torch.zeros(3, device=dev)
+    rows.append(("ingest [8,3,64,64] -> [8,72,72,32] bf16", timeit(lambda: ops.ingest_nchw(x, xin, L.PAD_EVAL_MIRROR, sc, bi)), x.numel() * 4 + xin.numel() * 2, True))
+    y = torch.rand(8, 3, 256, 256, device=dev)
+    rows.append(("nchw_to_u8 [8,3,256,256]", timeit(lambda: ops.nchw_to_u8(y, 255.0)), y.numel() * 5, True))
+    for name, us, nbytes, ok in rows:
+        print(f"{name:54s}: {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  {nbytes / 1e6:8.1f} MB  exact={ok}", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "elem":
+    elem_bench()
+    sys.exit(0)
+
 if len(sys.argv) > 1 and sys.argv[1] == "conv":
     conv_bench()
     sys.exit(0)
