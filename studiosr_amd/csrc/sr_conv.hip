@@ -132,11 +132,18 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         // (chunk t in slot t % 3, fetched 2 chunks = 2*MTW*NW MFMAs ahead) and every accumulator stay in fixed registers.
         constexpr int RING = 3;
         constexpr int KCTS = 9 * KCS;
+        // Walk order of the K-chunks.  256 input channels are summed as two phases of 128 (all nine taps of channels 0..127,
+        // then of 128..255) -- the order sr_conv_big.hip needs for its two-phase halo tile -- so that a pixel gets the SAME
+        // bits whichever of the two kernels the launch size selects; every other channel count is tap-major in both.
+        constexpr int PHS = KCS == 8 ? 2 : 1, KCPH = KCS / PHS;
+        auto tap_of = [](int t) { return (t % (9 * KCPH)) / KCPH; };
+        auto kc_of = [](int t) { return (t / (9 * KCPH)) * KCPH + t % KCPH; };
+        auto chunk_of = [&](int t) { return tap_of(t) * KCS + kc_of(t); };  // index into the packed weights (k = tap * Cin + c)
         Frag<TC> br[RING][NW];
 #pragma unroll
         for (int t = 0; t < RING - 1; ++t)
 #pragma unroll
-            for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + t) * 64];
+            for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + chunk_of(t)) * 64];
         const Frag<TC>* abase0 = As + (wm * MTW) * HALO_W + ar + ag * ROWS;
         if constexpr (KCS >= 2) {
             // activation fragments are double buffered across chunks: the LDS reads of chunk t+1 are issued before the MFMAs of
@@ -148,10 +155,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             for (int t = 0; t < KCTS; ++t) {
                 if (t + RING - 1 < KCTS) {
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + t + RING - 1) * 64];
+                    for (int n = 0; n < NW; ++n) br[(t + RING - 1) % RING][n] = Bp[((size_t)n * KCTS + chunk_of(t + RING - 1)) * 64];
                 }
                 if (t + 1 < KCTS) {
-                    const int tn = t + 1, tap = tn / KCS, kc = tn - tap * KCS;
+                    const int tn = t + 1, tap = tap_of(tn), kc = kc_of(tn);
                     const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * ROWS;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) af[tn & 1][m] = arow[m * HALO_W];
@@ -374,6 +381,7 @@ extern "C" int sr_conv3x3(const SrConv3x3* p, void* stream) {
                        c.fin_w <= c.W * (c.ps_r > 1 ? c.ps_r : 1) && !c.skip,
                    "sr_conv3x3: bad FINAL_NCHW arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sr_conv3x3_big_supported(c)) return sr_conv3x3_big(c, st);
     if (c.compute_dtype == SR_BF16) {
         if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 8>(c, st);
         return dispatch_conv<bf16, bf16, 8>(c, st);

@@ -1,0 +1,225 @@
+// 3x3 convolution, wide-channel variant (Cin_p, Cout_p in {192, 256}; NHWC output): same implicit GEMM on an LDS halo
+// tile as sr_conv.hip, re-tiled for what the SQ counters showed on the 256 -> 256 conv (profiles/r01_conv256_sq_counters.txt):
+// with 8 x 16 pixel tiles every workgroup streams the whole weight set (1.2 MB) for 128 pixels, all 256 CUs pull the same
+// fragments at the same time and L2 -> L1 delivery (32 B/clk/CU) plus one-wave-per-SIMD load latency leave the MFMA
+// pipe 40 % busy.  Here
+//   * one workgroup = 16 (or 12) rows x 16 pixels x ALL output channels: 4 waves split N, each wave holds 16 row tiles x NW column
+//     tiles = 48 / 64 accumulator tiles in AGPRs -> 64 MFMAs per 1 KiB-per-column-tile weight fetch (half the L2 traffic
+//     per MFMA, 16 LDS fragment reads per 48-64 MFMAs);
+//   * the 18 x 18 halo tile does not fit LDS for 256 input channels (166 KB), so K is walked in PH phases of Cin_p / PH
+//     channels (192: one phase, 123 KiB; 256: two phases of 128 channels, 82 KiB); the accumulators live across phases;
+//   * activation fragments are double buffered by half chunks (8 row tiles), weights run through a register ring;
+//   * taps are a run-time loop (9 iterations), the chunks of a tap are unrolled: code stays a few KiB.
+#include "sr_common.cuh"
+#include "sr_host.h"
+
+namespace {
+
+constexpr int BT = 16;                  // tile width (pixels) = one MFMA row tile
+constexpr int BH = BT + 2;              // halo width
+
+// TH = tile height (rows = MFMA row tiles per wave): 16, or 12 where that turns a half-empty second residency round
+// into one full round (72 x 72 images: 8 x 6 x 5 = 240 workgroups of 12 rows instead of 200 of 16)
+template <typename TIn, int TH, int NW, int KC, int PH>
+__global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
+    constexpr int HH = TH + 2;                       // halo height
+    constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
+    constexpr int HALF = TH / 2;                     // row tiles per activation-fragment buffer
+    static_assert(TH % 2 == 0, "two half chunks");
+    constexpr int KCP = KC / PH;                   // 32-channel chunks per phase
+    constexpr int RING = (KCP % 3 == 0) ? 3 : 4;   // divides KCP: ring slots are compile-time inside the tap loop
+    static_assert(KC % PH == 0 && KCP % RING == 0, "phase / ring geometry");
+    constexpr int KGP = KCP * 4;                   // 8-channel groups per phase
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<bf16>* As = reinterpret_cast<Frag<bf16>*>(smem);  // [KGP][BROWS]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_x = (c.W + BT - 1) / BT, tiles_y = (c.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * BT, y0 = ty * TH;
+    const int ar = lane & 15, ag = lane >> 4;
+    const int ntile0 = wave * NW;
+    constexpr int KCT = 9 * KC;
+    const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
+    const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+
+    // plain residual convs: the skip tile is the initial accumulator
+    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f;
+    f32x4 acc[TH][NW];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int yy = y0 + m, xx = x0 + ar;
+        const bool inb0 = (yy < c.H) && (xx < c.W);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            acc[m][n] = (f32x4)(0.0f);
+            if (acc_from_skip && inb0) {
+                const size_t off = ((size_t)(b * c.H + yy) * c.W + xx) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
+                acc[m][n] = c.skip_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(c.skip) + off) : load4(reinterpret_cast<const float*>(c.skip) + off);
+            }
+        }
+    }
+
+    for (int ph = 0; ph < PH; ++ph) {
+        if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
+        // ---- stage channels [ph * KGP * 8, +KGP * 8) of the halo tile: 8 pixels x 8 K-groups per wave instruction
+        {
+            const int r8 = lane & 7, kq = lane >> 3;
+            constexpr int KI = KGP / 8;
+            constexpr int NPASS = 4;  // row passes whose loads are all in flight before the first LDS write
+            for (int pb = wave * 8; pb < BROWS; pb += 32 * NPASS) {
+                Frag<bf16> f[NPASS][KI];
+                bool valid[NPASS];
+#pragma unroll
+                for (int u = 0; u < NPASS; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    const int py = p / BH, px = p - py * BH;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                    valid[u] = p < HH * BH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                    const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * c.Cin_p + ph * KGP * 8;
+#pragma unroll
+                    for (int i = 0; i < KI; ++i) f[u][i] = load_group<bf16, TIn>(src + (kq + 8 * i) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < NPASS; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    if (p < BROWS) {
+#pragma unroll
+                        for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * BROWS + p] = frag_keep_if(valid[u], f[u][i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 9 taps x KCP chunks of this phase; weight chunk index in the packed order = tap * KC + ph * KCP + kc
+        const Frag<bf16>* abase0 = As + ar + ag * BROWS;
+        Frag<bf16> br[RING][NW];
+        auto wload = [&](int slot, int tap, int kc) {  // slot is compile-time at every call site
+            int chunk = tap * KC + ph * KCP + kc;
+            if (kc >= KCP) chunk += KC - KCP;  // look-ahead ran into the next tap
+            if (chunk > KCT - 1) chunk = KCT - 1;  // harmless re-load at the very end
+#pragma unroll
+            for (int n = 0; n < NW; ++n) br[slot][n] = Bp[((size_t)n * KCT + chunk) * 64];
+        };
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) wload(s, 0, s);
+        Frag<bf16> af[2][HALF];
+#pragma unroll
+        for (int m = 0; m < HALF; ++m) af[0][m] = abase0[m * BH];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const Frag<bf16>* abase = abase0 + ky * BH + kx;
+            // first fragment address of the NEXT tap (for the look-ahead at the end of this one)
+            const int tn = tap + 1 < 9 ? tap + 1 : tap;
+            const Frag<bf16>* abase_next = abase0 + (tn / 3) * BH + (tn % 3);
+#pragma unroll
+            for (int kc = 0; kc < KCP; ++kc) {
+                wload((kc + RING - 1) % RING, tap, kc + RING - 1);
+                // half chunk 0: the upper rows are in af[0]; fetch the lower rows of this chunk
+#pragma unroll
+                for (int m = 0; m < HALF; ++m) af[1][m] = abase[(HALF + m) * BH + kc * 4 * BROWS];
+#pragma unroll
+                for (int m = 0; m < HALF; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[kc % RING][n], af[0][m], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+                // half chunk 1: fetch the upper rows of the next chunk (next tap's first chunk after the last one)
+                {
+                    const Frag<bf16>* nb = (kc + 1 < KCP) ? abase + (kc + 1) * 4 * BROWS : abase_next;
+#pragma unroll
+                    for (int m = 0; m < HALF; ++m) af[0][m] = nb[m * BH];
+                }
+#pragma unroll
+                for (int m = 0; m < HALF; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[kc % RING][n], af[1][m], acc[HALF + m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane = pixel (x0 + ar), registers = 4 consecutive output channels
+    const int x = x0 + ar;
+    f32x4 bias_r[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
+    act_dispatch(c.act, [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int m = 0; m < TH; ++m) {
+            const int y = y0 + m;
+            const bool inb = (y < c.H) && (x < c.W);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                f32x4 v = acc[m][n] + bias_r[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
+                v *= c.out_scale;
+                if (!inb) continue;
+                const size_t off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
+                if (c.skip && !acc_from_skip) {
+                    if (c.skip_dtype == SR_BF16)
+                        v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
+                    else
+                        v += load4(reinterpret_cast<const float*>(c.skip) + off);
+                }
+                if (c.out_dtype == SR_BF16)
+                    store4(reinterpret_cast<bf16*>(c.out) + off, v);
+                else
+                    store4(reinterpret_cast<float*>(c.out) + off, v);
+            }
+        }
+    });
+}
+
+template <typename TIn, int TH, int NW, int KC, int PH>
+int launch_big(const SrConv3x3& c, hipStream_t st) {
+    constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
+    constexpr int lds = (KC / PH) * 4 * BROWS * (int)sizeof(Frag<bf16>);
+    static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>, lds);
+        SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
+    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>), dim3(tiles), dim3(256), lds, st, c);
+    SR_CHECK_LAUNCH("sr_conv3x3");
+    return SR_OK;
+}
+
+int big_tiles(const SrConv3x3& c, int th) { return ((c.W + BT - 1) / BT) * ((c.H + th - 1) / th) * c.B; }
+
+// tile height with the smaller (residency rounds on 256 CUs) x (rows per workgroup); ties go to the taller tile
+int big_tile_rows(const SrConv3x3& c) {
+    const int cost16 = ((big_tiles(c, 16) + 255) / 256) * 16, cost12 = ((big_tiles(c, 12) + 255) / 256) * 12;
+    return cost12 < cost16 ? 12 : 16;
+}
+
+template <typename TIn, int TH>
+int dispatch_big(const SrConv3x3& c, hipStream_t st) {
+    if (c.Cin_p == 192 && c.Cout_p == 192) return launch_big<TIn, TH, 3, 6, 1>(c, st);
+    if (c.Cin_p == 256 && c.Cout_p == 256) return launch_big<TIn, TH, 4, 8, 2>(c, st);
+    return SR_EUNSUPPORTED;
+}
+
+}  // namespace
+
+// 1 if sr_conv3x3_big covers this conv (bf16 compute, NHWC output, no pooling side output)
+bool sr_conv3x3_big_supported(const SrConv3x3& c) {
+    if (c.compute_dtype != SR_BF16 || c.out_mode != SR_OUT_NHWC || c.pool_partial) return false;
+    if (!((c.Cin_p == 192 && c.Cout_p == 192) || (c.Cin_p == 256 && c.Cout_p == 256))) return false;
+    return big_tiles(c, big_tile_rows(c)) >= 96;  // small launches keep the 8 x 16 tiles (more workgroups)
+}
+
+int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st) {
+    if (big_tile_rows(c) == 12) return c.x_dtype == SR_F32 ? dispatch_big<float, 12>(c, st) : dispatch_big<bf16, 12>(c, st);
+    return c.x_dtype == SR_F32 ? dispatch_big<float, 16>(c, st) : dispatch_big<bf16, 16>(c, st);
+}

@@ -31,3 +31,9 @@ template <typename K>
 static inline hipError_t sr_allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
+
+// wide-channel 16 x 16-pixel-tile conv (sr_conv_big.hip); sr_conv3x3 routes the shapes it covers there
+struct SrConv3x3;
+bool sr_conv3x3_big_supported(const SrConv3x3& c);
+int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st);
+
