@@ -1,4 +1,5 @@
-// 3x3 convolution, wide-channel variant (Cin_p, Cout_p in {192, 256}; NHWC output): same implicit GEMM on an LDS halo
+// 3x3 convolution, wide-channel variant (Cin_p 192 -> Cout_p 192 k; Cin_p 256 -> Cout_p 256 k; NHWC or PixelShuffle output).
+// (64 input channels were tried and lost: with K = 576 the 64-tile epilogue dominates and 8 x 16 tiles overlap better.): same implicit GEMM on an LDS halo
 // tile as sr_conv.hip, re-tiled for what the SQ counters showed on the 256 -> 256 conv (profiles/r01_conv256_sq_counters.txt):
 // with 8 x 16 pixel tiles every workgroup streams the whole weight set (1.2 MB) for 128 pixels, all 256 CUs pull the same
 // fragments at the same time and L2 -> L1 delivery (32 B/clk/CU) plus one-wave-per-SIMD load latency leave the MFMA
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     constexpr int HALF = TH / 2;                     // row tiles per activation-fragment buffer
     static_assert(TH % 2 == 0, "two half chunks");
     constexpr int KCP = KC / PH;                   // 32-channel chunks per phase
-    constexpr int RING = (KCP % 3 == 0) ? 3 : 4;   // divides KCP: ring slots are compile-time inside the tap loop
+    constexpr int RING = (KCP % 3 == 0) ? 3 : (KCP % 4 == 0 ? 4 : 2);  // divides KCP: ring slots are compile-time inside the tap loop
     static_assert(KC % PH == 0 && KCP % RING == 0, "phase / ring geometry");
     constexpr int KGP = KCP * 4;                   // 8-channel groups per phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,13 +44,13 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     const int b = t / tiles_y;
     const int x0 = tx * BT, y0 = ty * TH;
     const int ar = lane & 15, ag = lane >> 4;
-    const int ntile0 = wave * NW;
+    const int ntile0 = blockIdx.y * (4 * NW) + wave * NW;  // blockIdx.y: slices of 64 * NW output channels (PixelShuffle convs: Cout = r*r*C)
     constexpr int KCT = 9 * KC;
     const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
     const TIn* xin = reinterpret_cast<const TIn*>(c.x);
 
     // plain residual convs: the skip tile is the initial accumulator
-    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f;
+    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC;
     f32x4 acc[TH][NW];
 #pragma unroll
     for (int m = 0; m < TH; ++m) {
@@ -162,7 +163,15 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
                 v *= c.out_scale;
                 if (!inb) continue;
-                const size_t off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
+                const int col = (ntile0 + n) * 16 + ag * 4;
+                size_t off;
+                if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {  // packed channel = (i*r + j)*cps_p + ch: 4 consecutive channels of ONE shuffled pixel
+                    const int sub = col / c.cps_p, ch = col - sub * c.cps_p;
+                    const int i = sub / c.ps_r, j = sub - i * c.ps_r;
+                    off = ((size_t)(b * c.H * c.ps_r + y * c.ps_r + i) * (c.W * c.ps_r) + x * c.ps_r + j) * c.cps_p + ch;
+                } else {
+                    off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + col;
+                }
                 if (c.skip && !acc_from_skip) {
                     if (c.skip_dtype == SR_BF16)
                         v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
@@ -190,12 +199,13 @@ int launch_big(const SrConv3x3& c, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
-    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>), dim3(tiles), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
 }
 
-int big_tiles(const SrConv3x3& c, int th) { return ((c.W + BT - 1) / BT) * ((c.H + th - 1) / th) * c.B; }
+int big_nw(const SrConv3x3& c) { return c.Cout_p % 256 == 0 ? 4 : 3; }
+int big_tiles(const SrConv3x3& c, int th) { return ((c.W + BT - 1) / BT) * ((c.H + th - 1) / th) * c.B * (c.Cout_p / (64 * big_nw(c))); }
 
 // tile height with the smaller (residency rounds on 256 CUs) x (rows per workgroup); ties go to the taller tile
 int big_tile_rows(const SrConv3x3& c) {
@@ -205,17 +215,17 @@ int big_tile_rows(const SrConv3x3& c) {
 
 template <typename TIn, int TH>
 int dispatch_big(const SrConv3x3& c, hipStream_t st) {
-    if (c.Cin_p == 192 && c.Cout_p == 192) return launch_big<TIn, TH, 3, 6, 1>(c, st);
-    if (c.Cin_p == 256 && c.Cout_p == 256) return launch_big<TIn, TH, 4, 8, 2>(c, st);
+    if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<TIn, TH, 3, 6, 1>(c, st);
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<TIn, TH, 4, 8, 2>(c, st);
     return SR_EUNSUPPORTED;
 }
 
 }  // namespace
 
-// 1 if sr_conv3x3_big covers this conv (bf16 compute, NHWC output, no pooling side output)
+// true if sr_conv3x3_big covers this conv (bf16 compute, NHWC or PixelShuffle output, no pooling side output)
 bool sr_conv3x3_big_supported(const SrConv3x3& c) {
-    if (c.compute_dtype != SR_BF16 || c.out_mode != SR_OUT_NHWC || c.pool_partial) return false;
-    if (!((c.Cin_p == 192 && c.Cout_p == 192) || (c.Cin_p == 256 && c.Cout_p == 256))) return false;
+    if (c.compute_dtype != SR_BF16 || (c.out_mode != SR_OUT_NHWC && c.out_mode != SR_OUT_PIXEL_SHUFFLE) || c.pool_partial) return false;
+    if (!((c.Cin_p == 192 && c.Cout_p % 192 == 0 && c.Cout_p % 256 != 0) || (c.Cin_p == 256 && c.Cout_p % 256 == 0))) return false;
     return big_tiles(c, big_tile_rows(c)) >= 96;  // small launches keep the 8 x 16 tiles (more workgroups)
 }
 
