@@ -349,7 +349,7 @@ int launch_attn(const SrWindowAttn& a, hipStream_t st) {
 template <typename TC>
 int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
     if (a.bias_frag) {  // fragment-ordered bias available: flash form
-        if (a.ntok == 256 && a.hd_p == 32) return launch_flash<TC, 16, 4, 1>(a, st);
+        if (a.ntok == 256 && a.hd_p == 32) return launch_flash<TC, 16, 2, 1>(a, st);  // 2 query tiles per wave: ~120 VGPRs, 4 waves per SIMD hide the per-block load latency
         if (a.ntok == 64 && a.hd_p == 32) return launch_flash<TC, 4, 4, 1>(a, st);
         if (a.ntok == 256 && a.hd_p == 64) return launch_flash<TC, 16, 2, 2>(a, st);
         if (a.ntok == 64 && a.hd_p == 64) return launch_flash<TC, 4, 4, 2>(a, st);
