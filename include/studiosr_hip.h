@@ -180,6 +180,9 @@ typedef struct SrOcaAttn {
     void* out;            /* [bwin*ws*ws][heads*hd_p] T (window-order rows) */
     int B, H, W, heads, hd_p, ws, pad, border, nk_pad;
     int dtype;
+    const float* bias_frag; /* optional: the bias in accumulator-fragment order [heads][qt][nk_frag/16][lane][4] with the key dimension
+                             * padded to nk_frag (multiple of 64) by -1e30 columns; selects the flash-form kernel */
+    int nk_frag;
 } SrOcaAttn;
 int sr_oca_attention(const SrOcaAttn* a, void* stream);
 

@@ -79,6 +79,7 @@ class SrOcaAttn(C.Structure):
     _fields_ = [
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("pad", _i), ("border", _i), ("nk_pad", _i), ("dtype", _i),
+        ("bias_frag", _vp), ("nk_frag", _i),
     ]
 
 

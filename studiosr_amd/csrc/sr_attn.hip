@@ -217,20 +217,21 @@ __global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn 
 #pragma unroll
         for (int c = 0; c < DC; ++c) qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
 
+    // shift mask (common.py:250-274): label(q) != label(k)  <=>  the row halves differ (last window row only) or the column
+    // halves differ (last window column only).  ws % 4 == 0, so the 4 keys of a lane group share a window row.
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
     const int win = bwin % (nwx * nwy);
     const int wy = win / nwx, wx = win - wy * nwx;
-    const bool ymask = a.y_mode != SR_Y_STRIP;
-    const bool masked = a.shift > 0 && ((ymask && wy == nwy - 1) || wx == nwx - 1);
-    int qlab[QT];
+    const bool last_row = a.y_mode != SR_Y_STRIP && wy == nwy - 1, last_col = wx == nwx - 1;
+    const bool masked = a.shift > 0 && (last_row || last_col);
+    const float inv_ws = 1.0f / (float)a.ws;
+    bool qrow[QT], qcol[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        qlab[t] = 0;
-        if (masked) {
-            const int qi = (qb * QT + t) * 16 + lr;
-            const int i = qi / a.ws, j = qi - i * a.ws;
-            qlab[t] = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + j, a.W, a.ws, a.shift);
-        }
+        const int qi = (qb * QT + t) * 16 + lr;
+        const int i = (int)(((float)qi + 0.5f) * inv_ws), j = qi - i * a.ws;
+        qrow[t] = last_row && i >= a.ws - a.shift;
+        qcol[t] = last_col && j >= a.ws - a.shift;
     }
 
     float m_run[QT], l_run[QT];
@@ -260,16 +261,20 @@ __global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn 
             }
         if (masked) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const int base = (kb * 4 + j) * 16 + lg * 4;
+                const int i = (int)(((float)base + 0.5f) * inv_ws), j0 = base - i * a.ws;
+                const bool krow = last_row && i >= a.ws - a.shift;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ki = (kb * 4 + j) * 16 + lg * 4 + r;
-                    const int i = ki / a.ws, jj = ki - i * a.ws;
-                    const int klab = (ymask ? 3 * region(wy * a.ws + i, a.H, a.ws, a.shift) : 0) + region(wx * a.ws + jj, a.W, a.ws, a.shift);
+                for (int t = 0; t < QT; ++t) {
+                    const float rowneg = krow != qrow[t] ? -100.0f : 0.0f;
 #pragma unroll
-                    for (int t = 0; t < QT; ++t)
-                        if (klab != qlab[t]) s[j][t][r] += -100.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float colneg = (last_col && j0 + r >= a.ws - a.shift) != qcol[t] ? -100.0f : 0.0f;
+                        s[j][t][r] += fminf(rowneg, colneg);
+                    }
                 }
+            }
         }
         // ---- online softmax update per query tile
 #pragma unroll
@@ -348,7 +353,7 @@ int launch_attn(const SrWindowAttn& a, hipStream_t st) {
 
 template <typename TC>
 int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
-    if (a.bias_frag) {  // fragment-ordered bias available: flash form
+    if (a.bias_frag && a.ws % 4 == 0) {  // fragment-ordered bias available: flash form
         if (a.ntok == 256 && a.hd_p == 32) return launch_flash<TC, 16, 2, 1>(a, st);  // 2 query tiles per wave: ~120 VGPRs, 4 waves per SIMD hide the per-block load latency
         if (a.ntok == 64 && a.hd_p == 32) return launch_flash<TC, 4, 4, 1>(a, st);
         if (a.ntok == 256 && a.hd_p == 64) return launch_flash<TC, 16, 2, 2>(a, st);

@@ -37,3 +37,8 @@ struct SrConv3x3;
 bool sr_conv3x3_big_supported(const SrConv3x3& c);
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st);
 
+// flash-form attention with the bias streamed through LDS (sr_attn_flash.hip)
+struct SrOcaAttn;
+bool sr_oca_attention_flash_supported(const SrOcaAttn& o);
+int sr_oca_attention_flash(const SrOcaAttn& o, hipStream_t st);
+

@@ -235,6 +235,10 @@ class HAT(Model):
             obp = torch.zeros(ob.shape[0], ob.shape[1], nk_pad, dtype=torch.float32, device=ob.device)
             obp[:, :, :nk] = ob
             o["oca_bias"] = obp.contiguous()
+            nk_frag = packing.round_up(nk, 64)  # flash-form kernel: key blocks of 64, pad columns vanish in the softmax
+            obf = torch.full((ob.shape[0], ob.shape[1], nk_frag), -1.0e30, dtype=torch.float32, device=ob.device)
+            obf[:, :, :nk] = ob
+            o["oca_bias_frag"], o["oca_nk_frag"] = packing.bias_fragments(obf), nk_frag
             o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
             conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, ident, dt)
             P["layers"].append(dict(blocks=blocks, ocab=o, conv=conv, geo=geo))
@@ -289,7 +293,8 @@ class HAT(Model):
         )
         ops.oca_attention(
             q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=op["oca_bias"].data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=geo.heads,
-            hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt,
+            hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt, bias_frag=op["oca_bias_frag"].data_ptr(),
+            nk_frag=op["oca_nk_frag"],
         )
         ops.gemm(
             A=o.data_ptr(), Wp=op["proj_w"].data_ptr(), bias=op["proj_b"].data_ptr(), out=t.data_ptr(), skip=t.data_ptr(), M=M, K=geo.HP, N=Cp,
