@@ -277,7 +277,9 @@ def test_edsr_x4_batch16_invariants():
 def _randomised(m, seed=3):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
-        for p_ in m.parameters():  # _init_weights zeroes biases / sets LN to identity: make every term count
+        for name, p_ in m.named_parameters():  # _init_weights zeroes biases / sets LN to identity: make every term count
+            if "sub_mean" in name or "add_mean" in name:  # frozen MeanShift (diagonal by construction, common.py:108-121)
+                continue
             p_.copy_(torch.randn(p_.shape, generator=g) * (0.02 if p_.dim() > 1 else 0.1) + (1.0 if p_.dim() == 1 and p_.numel() in (60, 180) else 0.0))
     return m
 
@@ -306,6 +308,21 @@ def test_swinir_row_strips_with_halo_exchange_equal_the_unsharded_forward(cfg, p
         sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
         o = OM.swinir_forward(sd, x.cpu(), m.get_model_config())
         assert float((ref.cpu() - o).abs().max()) <= FP32_TOL * max(1.0, float(o.abs().max()))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+def test_edsr_full_width_against_oracle(prec, tol):
+    """Default-width EDSR (256 features: the wide-tile conv with its two-phase halo tile, PixelShuffle output, fp32 stream I/O)
+    on an image whose sides are not multiples of the tile, against the CPU oracle."""
+    torch.manual_seed(5)
+    m = _randomised(S.EDSR(scale=2, n_resblocks=2), seed=5).to(DEV).eval().set_precision(prec)
+    x = torch.rand(6, 3, 50, 70)
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+    ref = OM.edsr_forward(sd, x, m.get_model_config())
+    assert y.shape == ref.shape == (6, 3, 100, 140)
+    assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
 def test_errors_are_loud():
