@@ -145,3 +145,11 @@ def test_tile_partition():
         for w in (1, 2, 3, 8):
             parts = tile_partition(n, w)
             assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles (incrementally) and loads the library, checks the ABI version."""
+    import __graft_entry__ as g
+
+    g.build()
+
