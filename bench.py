@@ -33,7 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 TILE = 64
-BATCH = 8
+BATCH = int(os.environ.get("SR_BENCH_BATCH", "8"))  # 8 = the metric's workload; the override is for experiments only
 SCALE = 4
 FLOP_PER_LR_PIXEL = 26_150_616  # 2*MAC over conv/Linear/QK^T/AV, default SwinIR x4
 PADDED = 72  # eval-mode pad 64 -> 72 (swinir.py:249-255)

@@ -23,7 +23,7 @@ namespace {
 
 struct Gemm2 {
     SrGemm g;
-    FastDiv div_hw, div_nwx;
+    FastDiv div_hw, div_nwx, div_w;
     int ws_log2, ntok_log2, hdp_log2;
     int acc_from_skip;  // acc = skip + bias before the MFMA loop (act NONE, scale 1)
 };
@@ -239,7 +239,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
             f32x4 bias = (f32x4)(0.0f);
             if (g.bias) bias = load4(g.bias + col);
             int part = 0, head = 0, d0 = 0;
-            if (g.epi == SR_EPI_QKV) {
+            if (g.epi != SR_EPI_STD) {
                 part = (col >= HP) ? 1 : 0;
                 const int rem = col - part * HP;
                 head = rem >> a.hdp_log2;
@@ -255,10 +255,16 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
                         v[r] = g.act == SR_ACT_GELU ? gelu_fast(v[r]) : (v[r] > 0.f ? v[r] : (g.act == SR_ACT_LRELU ? 0.01f * v[r] : 0.f));
                 }
                 if (g.out_scale != 1.0f) v *= g.out_scale;
-                if (g.epi == SR_EPI_QKV) {
+                if (g.epi != SR_EPI_STD) {
                     const int row = m0 + m * 16 + ar;
                     const int bwin = row >> a.ntok_log2, tok = row & (g.ntok - 1);
-                    const size_t off = ((((size_t)bwin * g.heads + head) << a.ntok_log2) + tok) * g.hd_p + d0;
+                    size_t off = ((((size_t)bwin * g.heads + head) << a.ntok_log2) + tok) * g.hd_p + d0;
+                    if (g.epi == SR_EPI_QKV_OCA && part == 1) {  // k -> zero-bordered image order (hat.py:255: the border is Unfold's padding)
+                        uint32_t bb, rem2, yy, xx;
+                        a.div_hw.divmod((uint32_t)win_map(a, row), bb, rem2);
+                        a.div_w.divmod(rem2, yy, xx);
+                        off = ((((size_t)bb * (g.H + 2 * g.oca_pad) + yy + g.oca_pad) * (g.W + 2 * g.oca_pad) + xx + g.oca_pad) * g.heads + head) * g.hd_p + d0;
+                    }
                     store4(reinterpret_cast<bf16*>(part == 0 ? g.out : g.out_k) + off, v);
                 } else {
                     if (g.skip && !a.acc_from_skip) v += load4(g.skip + (size_t)orow[m] * g.ldskip + col);
@@ -284,7 +290,14 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
                 const int row0 = m0 + m * 16 + ag * 4;
                 if (row0 >= g.M) continue;
                 const int bwin = row0 >> a.ntok_log2, tok0 = row0 & (g.ntok - 1);
-                const size_t off = ((((size_t)bwin * g.heads + head) * g.hd_p + d) << a.ntok_log2) + tok0;
+                size_t off = ((((size_t)bwin * g.heads + head) * g.hd_p + d) << a.ntok_log2) + tok0;
+                if (g.epi == SR_EPI_QKV_OCA) {  // v -> transposed zero-bordered planes (4 consecutive tokens = 4 consecutive x)
+                    uint32_t bb, rem2, yy, xx;
+                    a.div_hw.divmod((uint32_t)win_map(a, row0), bb, rem2);
+                    a.div_w.divmod(rem2, yy, xx);
+                    const size_t plane = (size_t)(g.H + 2 * g.oca_pad) * (g.W + 2 * g.oca_pad);
+                    off = (((size_t)bb * g.heads + head) * g.hd_p + d) * plane + (size_t)(yy + g.oca_pad) * (g.W + 2 * g.oca_pad) + xx + g.oca_pad;
+                }
                 store4(reinterpret_cast<bf16*>(g.out_vt) + off, acc[m][n] + bias);
             }
         }
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void sr_gemm2_kernel(Gemm2 a) {
     __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * MT * 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool vpart = (a.g.epi == SR_EPI_QKV) && ((int)blockIdx.y * 192 >= 2 * a.g.heads * a.g.hd_p);
+    const bool vpart = (a.g.epi != SR_EPI_STD) && ((int)blockIdx.y * 192 >= 2 * a.g.heads * a.g.hd_p);
     if (vpart)
         gemm2_body<TIn, MT, KC, false>(a, As, lane, wave);
     else
@@ -321,13 +334,14 @@ int launch2(const Gemm2& a, hipStream_t st) {
 
 // returns 1 when the shape is not one of the specialised ones (caller falls back to the generic kernel)
 int sr_gemm_v2_try(const SrGemm& g, hipStream_t st) {
-    if (g.compute_dtype != SR_BF16 || g.N % 192 != 0 || g.epi == SR_EPI_QKV_OCA) return 1;
+    if (g.compute_dtype != SR_BF16 || g.N % 192 != 0) return 1;
     if (!(g.K == 192 || (g.K == 384 && g.a_dtype == SR_BF16))) return 1;
     Gemm2 a;
     a.g = g;
     a.ws_log2 = a.ntok_log2 = a.hdp_log2 = 0;
     a.div_hw = make_fastdiv(1);
     a.div_nwx = make_fastdiv(1);
+    a.div_w = make_fastdiv(1);
     const bool windowed = g.a_map == SR_MAP_WINDOW || g.o_map == SR_MAP_WINDOW;
     if (windowed) {
         a.ws_log2 = ilog2_exact(g.ws);
@@ -335,8 +349,10 @@ int sr_gemm_v2_try(const SrGemm& g, hipStream_t st) {
         a.ntok_log2 = 2 * a.ws_log2;
         a.div_hw = make_fastdiv((uint32_t)(g.H * g.W));
         a.div_nwx = make_fastdiv((uint32_t)(g.W / g.ws));
+        a.div_w = make_fastdiv((uint32_t)g.W);
     }
-    if (g.epi == SR_EPI_QKV) {
+    if (g.epi == SR_EPI_QKV_OCA && (g.a_map != SR_MAP_WINDOW || g.shift != 0 || g.oca_pad % 4 != 0)) return 1;
+    if (g.epi != SR_EPI_STD) {
         a.hdp_log2 = ilog2_exact(g.hd_p);
         a.ntok_log2 = ilog2_exact(g.ntok);
         if (a.hdp_log2 < 0 || a.ntok_log2 < 0 || (g.heads * g.hd_p) % 192 != 0 || g.out_dtype != SR_BF16) return 1;
