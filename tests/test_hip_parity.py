@@ -325,6 +325,22 @@ def test_edsr_full_width_against_oracle(prec, tol):
     assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("ws", [16, 8])
+@pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+def test_hat_full_width_against_oracle(prec, tol, ws):
+    """Default-width HAT (embed 180: the K = 192 GEMMs incl. the OCA epilogue, flash window attention with 256 keys and the
+    shift mask, flash overlapping cross attention with 576 keys, CAB convs + channel attention) against the CPU oracle."""
+    torch.manual_seed(7)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=7).to(DEV).eval().set_precision(prec)
+    x = torch.rand(2, 3, 3 * ws, 2 * ws)  # 3 x 2 windows per image: border and interior windows
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+    ref = OM.hat_forward(sd, x, m.get_model_config())
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
 def test_errors_are_loud():
     m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).to(DEV).eval()
     with pytest.raises(RuntimeError):
