@@ -87,8 +87,9 @@ SR_DEV Frag<bf16> raw_to_frag(const Raw<float>& r) {
 }
 
 // MT: 16-row tiles per workgroup; KC: K/32.  NW = 3 (N tile 192), 4 waves split N.
-template <typename TIn, int MT, int KC, bool SWAPPED>
-SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
+// STAGE = false: the activation tile is already in LDS (single-pass QKV: the q, k and v column slices reuse one staged tile)
+template <typename TIn, int MT, int KC, bool SWAPPED, bool STAGE = true>
+SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int yblk) {
     constexpr int NW = 3;
     constexpr int M_T = MT * 16;
     constexpr int RING = KC < 6 ? KC : 6;
@@ -98,7 +99,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
     const int m0 = blockIdx.x * M_T;
     const int ar = lane & 15, ag = lane >> 4;
     const int r8 = lane & 7, kq = lane >> 3;
-    const int ntile0 = blockIdx.y * (4 * NW) + wave * NW;
+    const int ntile0 = yblk * (4 * NW) + wave * NW;
 
     // ---- t0: weight fragments for the first RING chunks
     const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(g.Wp) + (size_t)ntile0 * KC * 64 + lane;
@@ -109,8 +110,9 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
         for (int n = 0; n < NW; ++n) bfr[c][n] = Bp[((size_t)n * KC + c) * 64];
 
     // ---- t0: all activation rows of this wave
-    Raw<TIn> raw[NP][KI];
+    Raw<TIn> raw[STAGE ? NP : 1][KI];
     bool rvalid[NP];
+    if constexpr (STAGE) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int row = m0 + wave * (M_T / 4) + p * 8 + r8;
@@ -120,6 +122,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
         const TIn* src = reinterpret_cast<const TIn*>(g.A) + (size_t)srow * g.lda + kq * 8;
 #pragma unroll
         for (int i = 0; i < KI; ++i) raw[p][i] = raw_load(src + i * 64);
+    }
     }
 
     // ---- t0: accumulators (optionally pre-loaded with residual + bias)
@@ -150,7 +153,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
 
     __builtin_amdgcn_sched_barrier(0);  // every global load above is issued before any LayerNorm math
     // ---- t1: (LayerNorm) -> bf16 -> LDS
-    {
+    if constexpr (STAGE) {
         const bool ln = g.ln_gamma != nullptr || g.ln_norm_only;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -205,7 +208,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave) {
         }
     }
     if constexpr (!EARLY_ACC) init_acc();
-    __syncthreads();
+    if constexpr (STAGE) __syncthreads();
 
     // ---- t2: MFMA loop (LDS + registers only; weight ring refilled for K > 6 chunks)
 #pragma unroll
@@ -311,9 +314,21 @@ __global__ __launch_bounds__(256, 2) void sr_gemm2_kernel(Gemm2 a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool vpart = (a.g.epi != SR_EPI_STD) && ((int)blockIdx.y * 192 >= 2 * a.g.heads * a.g.hd_p);
     if (vpart)
-        gemm2_body<TIn, MT, KC, false>(a, As, lane, wave);
+        gemm2_body<TIn, MT, KC, false>(a, As, lane, wave, blockIdx.y);
     else
-        gemm2_body<TIn, MT, KC, true>(a, As, lane, wave);
+        gemm2_body<TIn, MT, KC, true>(a, As, lane, wave, blockIdx.y);
+}
+
+// QKV projection with heads * hd_p == 192 (N = 576): the q, k and v column slices in ONE workgroup, so the 128-row tile
+// is fetched, normalised and staged once instead of three times (the projection is bound by that, not by its MFMAs).
+template <typename TIn, int MT, int KC>
+__global__ __launch_bounds__(256, 2) void sr_gemm2_qkv_kernel(Gemm2 a) {
+    __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * MT * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gemm2_body<TIn, MT, KC, true, true>(a, As, lane, wave, 0);
+    gemm2_body<TIn, MT, KC, true, false>(a, As, lane, wave, 1);
+    gemm2_body<TIn, MT, KC, false, false>(a, As, lane, wave, 2);
 }
 
 int ilog2_exact(int v) {
@@ -325,6 +340,12 @@ int ilog2_exact(int v) {
 template <typename TIn, int MT, int KC>
 int launch2(const Gemm2& a, hipStream_t st) {
     dim3 grid((a.g.M + MT * 16 - 1) / (MT * 16), a.g.N / 192);
+    if (a.g.epi != SR_EPI_STD && a.g.N == 576 && a.g.heads * a.g.hd_p == 192) {
+        grid.y = 1;
+        hipLaunchKernelGGL((sr_gemm2_qkv_kernel<TIn, MT, KC>), grid, dim3(256), 0, st, a);
+        SR_CHECK_LAUNCH("sr_gemm(v2 qkv)");
+        return SR_OK;
+    }
     hipLaunchKernelGGL((sr_gemm2_kernel<TIn, MT, KC>), grid, dim3(256), 0, st, a);
     SR_CHECK_LAUNCH("sr_gemm(v2)");
     return SR_OK;
