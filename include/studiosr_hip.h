@@ -49,6 +49,8 @@ int sr_ingest_nchw(const float* x, void* out, int out_dtype, int B, int C, int H
 /* nn.LayerNorm over the channel axis (swinir.py:26,313; hat.py:460): fp32 rows [M, Cp] -> [M, Cp]. */
 int sr_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, int Cp,
                  float eps, void* stream);
+/* the same with a bf16 or fp32 result (y_dtype = SR_*): the consumer is a conv that rounds to bf16 anyway (hat.py:165-170) */
+int sr_layernorm_to(const float* x, void* y, int y_dtype, const float* gamma, const float* beta, int M, int C, int Cp, float eps, void* stream);
 
 typedef struct SrGemm {
     /* y = epilogue( prologue(A) @ W^T ): nn.Linear qkv/proj/fc1/fc2 with fused LayerNorm prologue,

@@ -99,6 +99,7 @@ SYMBOLS = {
     "sr_last_error": (C.c_char_p, []),
     "sr_ingest_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "sr_layernorm_to": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sr_gemm": (_i, [C.POINTER(SrGemm), _vp]),
     "sr_swin_attn_supported": (_i, [_i, _i, _i, _i, _i]),
     "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void sr_nchw_to_u8_kernel(const float* __restr
 
 // ----------------------------------------------------------------------------- LayerNorm
 // 8 lanes per row (lane kq owns K-groups kq, kq+8, ...), two-pass statistics in registers.
-__global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+template <typename TOut>
+__global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restrict__ x, TOut* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int M, int C, int Cp, float eps) {
     const int lane = threadIdx.x & 63;
     const int r8 = lane & 7, kq = lane >> 3;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void sr_layernorm_kernel(const float* __restri
             float gm[8], bt[8];
             load8f(gamma + kg * 8, gm);
             load8f(beta + kg * 8, bt);
-            float* o = y + (size_t)row * Cp + kg * 8;
+            TOut* o = y + (size_t)row * Cp + kg * 8;
             store4(o, f32x4{(v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1], (v[i][2] - mean) * rstd * gm[2] + bt[2],
                             (v[i][3] - mean) * rstd * gm[3] + bt[3]});
             store4(o + 4, f32x4{(v[i][4] - mean) * rstd * gm[4] + bt[4], (v[i][5] - mean) * rstd * gm[5] + bt[5], (v[i][6] - mean) * rstd * gm[6] + bt[6],
@@ -290,12 +291,20 @@ extern "C" int sr_nchw_to_u8(const float* in, unsigned char* out, int B, int C, 
     return SR_OK;
 }
 
-extern "C" int sr_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, int Cp, float eps, void* stream) {
+extern "C" int sr_layernorm_to(const float* x, void* y, int y_dtype, const float* gamma, const float* beta, int M, int C, int Cp, float eps, void* stream) {
     SR_REQUIRE(x && y && gamma && beta, "sr_layernorm: null pointer");
     SR_REQUIRE(M > 0 && C > 0 && C <= Cp && Cp % 8 == 0 && Cp <= 384, "sr_layernorm: bad geometry M=%d C=%d Cp=%d", M, C, Cp);
-    hipLaunchKernelGGL(sr_layernorm_kernel, dim3((M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, gamma, beta, M, C, Cp, eps);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (y_dtype == SR_BF16)
+        hipLaunchKernelGGL(sr_layernorm_kernel<bf16>, dim3((M + 31) / 32), dim3(256), 0, st, x, reinterpret_cast<bf16*>(y), gamma, beta, M, C, Cp, eps);
+    else
+        hipLaunchKernelGGL(sr_layernorm_kernel<float>, dim3((M + 31) / 32), dim3(256), 0, st, x, reinterpret_cast<float*>(y), gamma, beta, M, C, Cp, eps);
     SR_CHECK_LAUNCH("sr_layernorm");
     return SR_OK;
+}
+
+extern "C" int sr_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, int Cp, float eps, void* stream) {
+    return sr_layernorm_to(x, y, SR_F32, gamma, beta, M, C, Cp, eps, stream);
 }
 
 extern "C" int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, int B, int C_out, int H, int W, int r, void* stream) {

@@ -258,11 +258,11 @@ class HAT(Model):
         B, H, W, Cp = t_in.shape
         f32 = torch.float32
         # conv branch on LayerNorm1(x)  (hat.py:165-170)
-        n1 = ws_.get("hab.n1", (B, H, W, Cp), f32)
+        n1 = ws_.get("hab.n1", (B, H, W, Cp), cdt)  # consumed only by the conv, which rounds to the compute dtype anyway
         ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
         conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
-        y = ws_.get("hab.y", (B, H, W, Cp), f32)
+        y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
         n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt))
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
