@@ -333,9 +333,10 @@ class HAT(Model):
                 tb.copy_(ta)
             self._run_ocab(lp["ocab"], geo, P, tb, ws_, cdt)
             conv_call(tb, *lp["conv"], ta, cdt, skip=ta)  # ta = conv(group(ta)) + ta  (hat.py:385)
-        ops.layernorm(ta, tb, *P["norm"], self.embed_dim)
+        normed = ws_.get("normed", (B, Hp, Wp, Cp), cdt)  # read only by the conv, which rounds to the compute dtype anyway
+        ops.layernorm(ta, normed, *P["norm"], self.embed_dim)
         body = ws_.get("body", (B, Hp, Wp, Cp), cdt)
-        conv_call(tb, *P["after_body"], body, cdt, skip=first)
+        conv_call(normed, *P["after_body"], body, cdt, skip=first)
         feat = ws_.get("feat", (B, Hp, Wp, 64), cdt)
         conv_call(body, *P["before_up"], feat, cdt, act=L.ACT_LRELU)
         up = run_upsampler(P["up"], feat, ws_, cdt, "hat")

@@ -367,9 +367,10 @@ class SwinIR(Model):
                 cur = ws_.get("tc", (B, Hp, Wp, Cp), torch.float32)
                 cur.copy_(ta)
             conv_call(cur, *lp["conv"], ta, cdt, skip=ta)
-        ops.layernorm(ta, tb, *P["norm"], self.embed_dim)
+        normed = ws_.get("normed", (B, Hp, Wp, Cp), cdt)  # read only by the conv, which rounds to the compute dtype anyway
+        ops.layernorm(ta, normed, *P["norm"], self.embed_dim)
         body = ws_.get("body", (B, Hp, Wp, Cp), cdt)
-        conv_call(tb, *P["after_body"], body, cdt, skip=first)  # conv_after_body(features) + x  (swinir.py:362)
+        conv_call(normed, *P["after_body"], body, cdt, skip=first)  # conv_after_body(features) + x  (swinir.py:362)
 
         s = self.scale
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)

@@ -248,10 +248,11 @@ def swinir_forward_strips(model, x: Tensor, comm: StripComm) -> Tensor:
         ext = [t.view(-1, t.rows + 1) for t in ta]
         _conv_strips(comm, cur, ext, *lp["conv"], cdt, skip=ext)  # ta = conv(cur) + ta   (swinir.py:245-246)
 
+    normed = strips("normed", Cp, cdt)
     for i in range(len(ranks)):
-        ops.layernorm(ta[i].own, tb[i].own, *P["norm"], C)
+        ops.layernorm(ta[i].own, normed[i].own, *P["norm"], C)
     body = strips("body", Cp, cdt)
-    _conv_strips(comm, tb, [b_.view(-1, b_.rows + 1) for b_ in body], *P["after_body"], cdt, skip=[f.view(-1, f.rows + 1) for f in first])
+    _conv_strips(comm, normed, [b_.view(-1, b_.rows + 1) for b_ in body], *P["after_body"], cdt, skip=[f.view(-1, f.rows + 1) for f in first])
 
     fin_scale, fin_bias = P["fin"]
     hr: List[Tensor] = []
