@@ -340,7 +340,7 @@ int ilog2_exact(int v) {
 template <typename TIn, int MT, int KC>
 int launch2(const Gemm2& a, hipStream_t st) {
     dim3 grid((a.g.M + MT * 16 - 1) / (MT * 16), a.g.N / 192);
-    if (a.g.epi != SR_EPI_STD && a.g.N == 576 && a.g.heads * a.g.hd_p == 192) {
+    if (a.g.epi != SR_EPI_STD && a.g.N == 576 && a.g.heads * a.g.hd_p == 192 && grid.x >= 256) {  // fewer row tiles than CUs: three column blocks in parallel win
         grid.y = 1;
         hipLaunchKernelGGL((sr_gemm2_qkv_kernel<TIn, MT, KC>), grid, dim3(256), 0, st, a);
         SR_CHECK_LAUNCH("sr_gemm(v2 qkv)");
