@@ -154,6 +154,23 @@ typedef struct SrConv3x3 {
 int sr_conv3x3(const SrConv3x3* a, void* stream);
 int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype); /* n_tiles of pool_partial for this geometry */
 
+typedef struct SrRcab {
+    /* y = conv2(ReLU(conv1(x))): the conv-ReLU-conv body of an RCAB (rcan.py:11-24, common.py:140-153 without the residual) for 64
+     * (padded) channels in ONE launch -- the intermediate stays in LDS -- plus per-tile channel sums of y for the channel-attention
+     * gate (sr_channel_attention).  bf16 operands / fp32 accumulate; same bits as two sr_conv3x3 launches. */
+    const void* x;        /* NHWC [B,H,W,64] x_dtype */
+    const void* w1p;      /* packed conv1 weights (sr_conv3x3 layout), bf16 */
+    const float* b1;      /* [64] */
+    const void* w2p;      /* packed conv2 weights */
+    const float* b2;      /* [64] */
+    void* y;              /* NHWC [B,H,W,64] y_dtype */
+    float* pool_partial;  /* optional [B, sr_rcab_pool_tiles(H, W), 64] */
+    int B, H, W, C_p;     /* C_p must be 64 */
+    int x_dtype, y_dtype;
+} SrRcab;
+int sr_rcab_conv_pair(const SrRcab* a, void* stream);
+int sr_rcab_pool_tiles(int H, int W); /* n_tiles of pool_partial */
+
 typedef struct SrWindowAttn {
     /* softmax(q k^T + bias[head] + shift mask) v per (window, head)
      * (swinir.py:83-102; common.py:250-274; hat.py:90-107).  q is pre-scaled (scale folded into Wq). */

@@ -67,6 +67,13 @@ class SrConv3x3(C.Structure):
     ]
 
 
+class SrRcab(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C_p", _i), ("x_dtype", _i), ("y_dtype", _i),
+    ]
+
+
 class SrWindowAttn(C.Structure):
     _fields_ = [
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
@@ -110,6 +117,8 @@ SYMBOLS = {
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
     "sr_oca_attention": (_i, [C.POINTER(SrOcaAttn), _vp]),
     "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_rcab_conv_pair": (_i, [C.POINTER(SrRcab), _vp]),
+    "sr_rcab_pool_tiles": (_i, [_i, _i]),
     "sr_u8_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_nchw_to_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),

@@ -1,0 +1,226 @@
+// Fused body of a 64-channel residual channel-attention block (rcan.py:11-24): y = conv2(ReLU(conv1(x))) in ONE launch,
+// plus the per-tile channel sums the channel-attention gate needs (common.py:156-170).
+//
+// Why: at RCAN's shapes (64 channels, K = 576) a 3x3 conv is ~1 us of MFMAs wrapped in ~10 us of launch, halo-load and store
+// latency; 400 of them per forward made the model launch-latency bound (profiles/r01_model_bench.jsonl).  Here the ReLU'd
+// intermediate never leaves the CU:
+//   * one workgroup (4 waves) owns a 14 x 14 output tile; it stages the 18 x 18 input halo (all 64 channels, bf16,
+//     K-group-major image as in sr_conv.hip), computes the 16 x 16 intermediate tile (conv1 + bias + ReLU; positions
+//     outside the image are ZERO: they are conv2's padding) into a second LDS image, then the 14 x 14 outputs from it;
+//   * an MFMA row tile is 16 horizontally adjacent pixels in both convs (conv2 evaluates 16 columns per row and keeps the
+//     inner 14); waves split 2 x 2 over (rows, output channels); weights stream L2 -> registers through a 3-slot ring;
+//   * K is walked tap-major exactly like sr_conv3x3, so y has the same bits as the two-launch path.
+// 76 KiB LDS -> two workgroups per CU.
+#include "sr_common.cuh"
+#include "sr_host.h"
+
+namespace {
+
+constexpr int RC = 64;             // channels (padded)
+constexpr int RKG = RC / 8;        // K-groups
+constexpr int RKC = RC / 32;       // 32-channel chunks per tap
+constexpr int RKCT = 9 * RKC;      // chunks per conv
+constexpr int TO = 14;             // output tile edge
+constexpr int TI = 16;             // intermediate tile edge (= one MFMA row tile)
+constexpr int TIN = 18;            // input halo edge
+constexpr int IN_ROWS = 328;       // 18 * 18 = 324 halo pixels, padded to a multiple of 8
+constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 1 margin cell, padded to a multiple of 8
+constexpr int RRING = 3;
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [RKG][IN_ROWS]
+    Frag<bf16>* Amid = Ain + RKG * IN_ROWS;                   // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ar = lane & 15, ag = lane >> 4;
+    const int tiles_x = (c.W + TO - 1) / TO, tiles_y = (c.H + TO - 1) / TO;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TO, y0 = ty * TO;  // output tile origin; intermediate tile origin = (y0 - 1, x0 - 1), halo origin = (y0 - 2, x0 - 2)
+
+    const Frag<bf16>* W1 = reinterpret_cast<const Frag<bf16>*>(c.w1p) + (size_t)(wn * 2) * RKCT * 64 + lane;
+    const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wn * 2) * RKCT * 64 + lane;
+    Frag<bf16> br[RRING][2];
+#pragma unroll
+    for (int s = 0; s < RRING - 1; ++s)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) br[s][n] = W1[((size_t)n * RKCT + s) * 64];
+
+    // ---- stage the input halo (8 pixels x 8 K-groups per wave instruction: full 256-byte pixel rows), all loads of 3 passes in flight
+    {
+        const int r8 = lane & 7, kq = lane >> 3;
+        const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+        constexpr int NPASS = 3;
+        for (int pb = wave * 8; pb < IN_ROWS; pb += 32 * NPASS) {
+            Frag<bf16> f[NPASS];
+            bool valid[NPASS];
+#pragma unroll
+            for (int u = 0; u < NPASS; ++u) {
+                const int p = pb + u * 32 + r8;
+                const int py = p / TIN, px = p - py * TIN;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                valid[u] = p < TIN * TIN && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * RC + kq * 8;
+                f[u] = load_group<bf16, TIn>(src);
+            }
+#pragma unroll
+            for (int u = 0; u < NPASS; ++u) {
+                const int p = pb + u * 32 + r8;
+                if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], f[u]);
+            }
+        }
+        if (threadIdx.x < 2 * RKG) {  // margin cells of the intermediate image (read by discarded edge columns only; keep them finite)
+            Frag<bf16> z;
+            frag_zero(z);
+            Amid[(threadIdx.x >> 1) * MID_ROWS + ((threadIdx.x & 1) ? 1 + TI * TI : 0)] = z;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv1 + bias + ReLU -> intermediate image.  Wave (wm, wn): rows [8 wm, 8 wm + 8) x channels [32 wn, 32 wn + 32)
+    {
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            acc[m][0] = (f32x4)(0.0f);
+            acc[m][1] = (f32x4)(0.0f);
+        }
+        const Frag<bf16>* abase0 = Ain + (wm * 8) * TIN + ar + ag * IN_ROWS;
+#pragma unroll
+        for (int tt = 0; tt < RKCT; ++tt) {
+            const int tap = tt / RKC, kc = tt - tap * RKC;
+            if (tt + RRING - 1 < RKCT) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W1[((size_t)n * RKCT + tt + RRING - 1) * 64];
+            } else {  // tail of conv1: start conv2's weight stream
+#pragma unroll
+                for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W2[((size_t)n * RKCT + tt + RRING - 1 - RKCT) * 64];
+            }
+            const Frag<bf16>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_ROWS;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const Frag<bf16> a = arow[m * TIN];
+                mma(br[tt % RRING][0], a, acc[m][0]);
+                mma(br[tt % RRING][1], a, acc[m][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 bias0 = load4(c.b1 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b1 + (wn * 2 + 1) * 16 + ag * 4);
+        const int gx = x0 - 1 + ar;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int iy = wm * 8 + m, gy = y0 - 1 + iy;
+            const bool inside = gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;  // outside the image the intermediate is conv2's zero padding
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? fmaxf(v[r], 0.0f) : 0.0f);
+                const int kg = (wn * 2 + n) * 2 + (ag >> 1);
+                char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TI + ar) + (ag & 1) * 8;
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 + bias on output rows oy = 1 + 7 wm .. 7 wm + 7 of the intermediate tile; 16 columns per row, the inner 14 are kept
+    {
+        f32x4 acc[7][2];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            acc[m][0] = (f32x4)(0.0f);
+            acc[m][1] = (f32x4)(0.0f);
+        }
+        // tap (ky, kx) of output (oy, ox) reads intermediate (oy + ky - 1, ox + kx - 1) = cell 1 + (oy + ky - 1) * 16 + ox + kx - 1
+        const Frag<bf16>* abase0 = Amid + (wm * 7) * TI + ar + ag * MID_ROWS;
+#pragma unroll
+        for (int tt = 0; tt < RKCT; ++tt) {
+            const int tap = tt / RKC, kc = tt - tap * RKC;
+            if (tt + RRING - 1 < RKCT) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W2[((size_t)n * RKCT + tt + RRING - 1) * 64];
+            }
+            const Frag<bf16>* arow = abase0 + (tap / 3) * TI + (tap % 3) + kc * 4 * MID_ROWS;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const Frag<bf16> a = arow[m * TI];
+                mma(br[tt % RRING][0], a, acc[m][0]);
+                mma(br[tt % RRING][1], a, acc[m][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 bias0 = load4(c.b2 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b2 + (wn * 2 + 1) * 16 + ag * 4);
+        const int gx = x0 - 1 + ar;
+        const bool xin_tile = ar >= 1 && ar <= TO && gx < c.W;
+        f32x4 pool[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+        TOut* y = reinterpret_cast<TOut*>(c.y);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const int gy = y0 + wm * 7 + m;
+            const bool ok = xin_tile && gy < c.H;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+                if (ok) {
+                    pool[n] += v;
+                    store4(y + ((size_t)(b * c.H + gy) * c.W + gx) * RC + (wn * 2 + n) * 16 + ag * 4, v);
+                }
+            }
+        }
+        if (c.pool_partial) {  // per (tile, row half) channel sums over the valid pixels: deterministic, no atomics
+            const int n_slots = tiles_x * tiles_y * 2;
+            const int slot = (ty * tiles_x + tx) * 2 + wm;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 p = pool[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = p[r];
+                    s += __shfl_xor(s, 1, 64);
+                    s += __shfl_xor(s, 2, 64);
+                    s += __shfl_xor(s, 4, 64);
+                    s += __shfl_xor(s, 8, 64);
+                    p[r] = s;
+                }
+                if (ar == 0) store4(c.pool_partial + ((size_t)b * n_slots + slot) * RC + (wn * 2 + n) * 16 + ag * 4, p);
+            }
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+int launch_rcab(const SrRcab& c, hipStream_t st) {
+    constexpr int lds = (RKG * IN_ROWS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = sr_allow_lds(sr_rcab_kernel<TIn, TOut>, lds);
+        SR_REQUIRE(e == hipSuccess, "sr_rcab_conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int tiles = ((c.W + TO - 1) / TO) * ((c.H + TO - 1) / TO) * c.B;
+    hipLaunchKernelGGL((sr_rcab_kernel<TIn, TOut>), dim3(tiles), dim3(256), lds, st, c);
+    SR_CHECK_LAUNCH("sr_rcab_conv_pair");
+    return SR_OK;
+}
+
+}  // namespace
+
+extern "C" int sr_rcab_pool_tiles(int H, int W) { return ((W + TO - 1) / TO) * ((H + TO - 1) / TO) * 2; }
+
+extern "C" int sr_rcab_conv_pair(const SrRcab* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->w1p && p->b1 && p->w2p && p->b2 && p->y, "sr_rcab_conv_pair: null pointer");
+    const SrRcab& c = *p;
+    SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.C_p == RC, "sr_rcab_conv_pair: bad geometry (64 padded channels only)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c.x_dtype == SR_F32) return c.y_dtype == SR_F32 ? launch_rcab<float, float>(c, st) : launch_rcab<float, bf16>(c, st);
+    return c.y_dtype == SR_F32 ? launch_rcab<bf16, float>(c, st) : launch_rcab<bf16, bf16>(c, st);
+}

@@ -102,7 +102,9 @@ class RCAN(Model):
         ops.ingest_nchw(x, xin, L.PAD_NONE, *P["ing"])
         h = ws_.get("head", (B, H, W, Fp), f32)
         conv_call(xin, *P["head"], h, cdt)
-        n_tiles = ops.conv_pool_tiles(H, W, Fp, sr_dtype(cdt))
+        # bf16, 64 (padded) channels: conv-ReLU-conv of an RCAB is ONE launch (sr_rcab_conv_pair, the intermediate stays in LDS)
+        fused_pair = cdt == torch.bfloat16 and Fp == 64
+        n_tiles = ops.rcab_pool_tiles(H, W) if fused_pair else ops.conv_pool_tiles(H, W, Fp, sr_dtype(cdt))
         pool = ws_.get("pool", (B, n_tiles, Fp), f32)
         mid = ws_.get("mid", (B, H, W, Fp), cdt)
         y = ws_.get("y", (B, H, W, Fp), f32)
@@ -112,8 +114,13 @@ class RCAN(Model):
         for blocks, gconv in P["groups"]:
             r = g
             for (c1, c2, ca) in blocks:  # RCAB: r = CA(conv2(relu(conv1(r)))) + r
-                conv_call(r, *c1, mid, cdt, act=L.ACT_RELU)
-                conv_call(mid, *c2, y, cdt, pool=pool)
+                if fused_pair:
+                    ops.rcab_conv_pair(x=r.data_ptr(), w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(),
+                                       y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, C_p=Fp, x_dtype=sr_dtype(r.dtype),
+                                       y_dtype=sr_dtype(y.dtype))
+                else:
+                    conv_call(r, *c1, mid, cdt, act=L.ACT_RELU)
+                    conv_call(mid, *c2, y, cdt, pool=pool)
                 nxt = ra if (r is not ra) else rb
                 run_channel_attention(ca, y, pool, n_tiles, self.n_feats, nxt, skip=r)
                 r = nxt

@@ -83,6 +83,17 @@ def conv3x3(**kw) -> None:
     L.check(L.lib().sr_conv3x3(C.byref(c), _stream()), "sr_conv3x3")
 
 
+def rcab_conv_pair(**kw) -> None:
+    a = L.SrRcab()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_rcab_conv_pair(C.byref(a), _stream()), "sr_rcab_conv_pair")
+
+
+def rcab_pool_tiles(H: int, W: int) -> int:
+    return int(L.lib().sr_rcab_pool_tiles(H, W))
+
+
 def window_attention(**kw) -> None:
     a = L.SrWindowAttn()
     for k, v in kw.items():

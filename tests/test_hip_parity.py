@@ -341,6 +341,44 @@ def test_hat_full_width_against_oracle(prec, tol, ws):
     assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+def test_rcan_full_width_against_oracle(prec, tol):
+    """Default-width RCAN (64 features: in bf16 the conv-ReLU-conv of every RCAB is the one-launch sr_rcab_conv_pair with its
+    14 x 14 tiles, zero-padded intermediate and per-tile pooling) on an image that is not a multiple of the tile."""
+    torch.manual_seed(9)
+    m = _randomised(S.RCAN(scale=2, n_resblocks=2, n_resgroups=2), seed=9).to(DEV).eval().set_precision(prec)
+    x = torch.rand(3, 3, 33, 45)
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+    ref = OM.rcan_forward(sd, x, m.get_model_config())
+    assert y.shape == ref.shape == (3, 3, 66, 90)
+    assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+def test_rcab_pair_equals_two_conv_launches_bit_for_bit():
+    """sr_rcab_conv_pair against conv3x3(ReLU) + conv3x3 through the same packed weights: identical bits, and the pooled
+    channel sums equal the sum of y."""
+    torch.manual_seed(11)
+    B, H, W, Cc = 2, 30, 41, 64
+    w1, w2 = torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05, torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(Cc, device=DEV) * 0.1, torch.randn(Cc, device=DEV) * 0.1
+    ident = packing.identity_idx(Cc, Cc)
+    c1, c2 = packing.pack_conv3x3(w1, b1, Cc, ident, torch.bfloat16), packing.pack_conv3x3(w2, b2, Cc, ident, torch.bfloat16)
+    x = torch.randn(B, H, W, Cc, device=DEV)
+    mid = torch.empty(B, H, W, Cc, device=DEV, dtype=torch.bfloat16)
+    want = torch.empty(B, H, W, Cc, device=DEV)
+    conv_call(x, *c1, mid, torch.bfloat16, act=L.ACT_RELU)
+    conv_call(mid, *c2, want, torch.bfloat16)
+    got = torch.full_like(want, float("nan"))
+    n_tiles = ops.rcab_pool_tiles(H, W)
+    pool = torch.zeros(B, n_tiles, Cc, device=DEV)
+    ops.rcab_conv_pair(x=x.data_ptr(), w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(), y=got.data_ptr(),
+                       pool_partial=pool.data_ptr(), B=B, H=H, W=W, C_p=Cc, x_dtype=L.SR_F32, y_dtype=L.SR_F32)
+    assert torch.equal(got, want)
+    torch.testing.assert_close(pool.sum(dim=1), want.sum(dim=(1, 2)), rtol=1e-4, atol=1e-2)
+
+
 def test_errors_are_loud():
     m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).to(DEV).eval()
     with pytest.raises(RuntimeError):
