@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Forward throughput of every model family at the BASELINE.json single-GPU shapes (default architectures, bf16 operands,
 synthetic weights / inputs, HIP-graph replay): EDSR x4 b16 (config 2), SwinIR x4 b8 (config 3), RCAN x4 b16, HAT x4 b4.
-Prints one JSON line per model: ms per forward, HR-Mpix/s, achieved TFLOP/s against the 2.5 PFLOP/s bf16 MFMA peak."""
+Prints one JSON line per model: ms per forward, HR-Mpix/s, achieved TFLOP/s against the 2.5 PFLOP/s bf16 MFMA peak.
+`KIND:B` overrides the batch, `KIND:B:N` also keeps N independent batches in flight (own graph / stream / workspace each, as
+bench.py does): what a serving loop gets out of the launch-latency-bound models."""
 import json
 import os
 import sys
@@ -21,26 +23,44 @@ def main():
     which = sys.argv[1:] or list(CASES)
     dev = torch.device("cuda")
     for kind in which:
-        kind, _, bs = kind.partition(":")  # "HAT:16" overrides the batch size
-        B = int(bs) if bs else CASES[kind]
+        parts = kind.split(":")  # "HAT:16" overrides the batch size, "HAT:4:2" also runs 2 batches in flight
+        kind = parts[0]
+        B = int(parts[1]) if len(parts) > 1 and parts[1] else CASES[kind]
+        inflight = int(parts[2]) if len(parts) > 2 else 1
         torch.manual_seed(0)
         m = getattr(S, kind)(scale=4).eval().to(dev).set_precision("bf16")
         x = torch.rand(B, 3, 64, 64, device=dev)
         with torch.no_grad():
-            g = GraphedForward(m, x)
-            for _ in range(3):
-                g(x)
+            pipes = []
+            for _ in range(inflight):
+                ws_i = S.runtime.Workspace(dev)
+
+                def fwd(inp, ws_i=ws_i):
+                    m._ws = ws_i
+                    return m(inp)
+
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    pipes.append((GraphedForward(fwd, x), st, ws_i))
             torch.cuda.synchronize()
-            n = 20
+
+            def run(n):
+                for i in range(n):
+                    g, st, _ = pipes[i % len(pipes)]
+                    with torch.cuda.stream(st):
+                        g.replay()
+
+            run(3 * inflight)
+            torch.cuda.synchronize()
+            n = 20 * inflight
             t0 = time.perf_counter()
-            for _ in range(n):
-                g(x)
+            run(n)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
         tf = B * GFLOP_PER_TILE[kind] / dt / 1e3
-        print(json.dumps({"model": f"{kind} x4", "batch": B, "ms": round(dt * 1e3, 3), "hr_mpix_per_s": round(B * 256 * 256 / 1e6 / dt, 1),
+        print(json.dumps({"model": f"{kind} x4", "batch": B, "in_flight": inflight, "ms": round(dt * 1e3, 3), "hr_mpix_per_s": round(B * 256 * 256 / 1e6 / dt, 1),
                           "tflops": round(tf, 1), "frac_bf16_mfma_peak": round(tf / 2500.0, 4)}), flush=True)
-        del g, m
+        del pipes, m
         torch.cuda.empty_cache()
 
 
