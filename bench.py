@@ -180,7 +180,14 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
 
+    from studiosr_amd import _lib
     from studiosr_amd.runtime import GraphedForward
+
+    if not os.path.exists(_lib.LIB_PATH):  # a fresh checkout: the library is a (git-ignored) build artefact
+        if rank == 0:
+            _lib.build()
+        if world > 1:
+            dist.barrier()
 
     model = build_model(device)
     g = torch.Generator().manual_seed(1234 + rank)

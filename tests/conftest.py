@@ -35,3 +35,13 @@ def golden_cfg(g):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is a build artefact (git-ignored): compile it once if this checkout does not have it yet."""
+    from studiosr_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+
