@@ -83,6 +83,14 @@ def conv_bench():
         us = timeit(fn)
         gf = 2.0 * B * H * W * 9 * cin * cout / 1e9
         print(f"conv B={B} {H}x{W} {cin}->{cout} {mode:9s}: {us:8.1f} us  {gf / us * 1e3:8.1f} TF/s", flush=True)
+        if os.environ.get("KB_STAMPS"):  # needs a `make STAMPS=1` build: s_memtime stamps of workgroup 7, wave 0 (sr_conv.hip only)
+            import ctypes
+            buf = (ctypes.c_ulonglong * 16)()
+            f = L.lib().sr_debug_conv_stamps
+            f.argtypes = [ctypes.c_void_p]
+            f(buf)
+            v = [buf[i] for i in range(5)]
+            print("   stamps: stage", v[1] - v[0], "barrier", v[2] - v[1], "mfma", v[3] - v[2], "epilogue", v[4] - v[3], "total", v[4] - v[0], flush=True)
 
 
 def elem_bench():
