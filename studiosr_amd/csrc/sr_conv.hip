@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         }
     }
 
+    f32x4 bias_r[NW];  // requested before the MFMA loop: in the epilogue its L2 round trip would be fully exposed
+#pragma unroll
+    for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
+
     if constexpr (KCS > 0) {
         // Fully unrolled (tap, chunk) walk: K-chunk count is a compile-time constant, so the 3-slot weight ring
         // (chunk t in slot t % 3, fetched 2 chunks = 2*MTW*NW MFMAs ahead) and every accumulator stay in fixed registers.
@@ -220,18 +224,31 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
 #pragma unroll
     for (int n = 0; n < NW; ++n) pool[n] = (f32x4)(0.0f);
 
-    f32x4 bias_r[NW];  // fetched before the first store: stores may alias, so later loads would serialise behind them
+    // per column tile: channel inside the (shuffled) pixel and, for PixelShuffle, the sub-pixel -- divisions by run-time values,
+    // done ONCE per tile column here (hipcc re-did them for every row tile: ~4.5 k of the 14.5 k epilogue cycles of the 64 -> 256 convs)
+    int nch[NW], ps_i[NW], ps_j[NW];
 #pragma unroll
-    for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
+    for (int n = 0; n < NW; ++n) {
+        const int col = (ntile0 + n) * 16 + ag * 4;
+        nch[n] = col;
+        ps_i[n] = ps_j[n] = 0;
+        if (c.out_mode == SR_OUT_PIXEL_SHUFFLE || (c.out_mode == SR_OUT_FINAL_NCHW && c.ps_r > 1)) {
+            const int sub = col / c.cps_p;
+            nch[n] = col - sub * c.cps_p;
+            ps_i[n] = sub / c.ps_r;
+            ps_j[n] = sub - ps_i[n] * c.ps_r;
+        }
+    }
     act_dispatch(c.act, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int y = y0 + wm * MTW + m;
         const bool inb = (y < c.H) && (x < c.W);
+        const size_t pix_nhwc = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p;          // NHWC pixel base
+        const size_t ps_row = (size_t)(b * c.H + y) * c.ps_r, ps_col = (size_t)x * c.ps_r;  // PixelShuffle: top-left sub-pixel
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            const int col = (ntile0 + n) * 16 + ag * 4;
             f32x4 v = acc[m][n] + bias_r[n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
@@ -239,32 +256,20 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             v *= c.out_scale;
             if (!inb) continue;
             if (c.out_mode == SR_OUT_FINAL_NCHW) {
-                int chb = col, yy = y, xx = x;
-                if (c.ps_r > 1) {  // "pixelshuffledirect": shuffle straight into the final image
-                    const int sub = col / c.cps_p;
-                    chb = col - sub * c.cps_p;
-                    const int i = sub / c.ps_r, j = sub - i * c.ps_r;
-                    yy = y * c.ps_r + i;
-                    xx = x * c.ps_r + j;
-                }
+                const int yy = c.ps_r > 1 ? y * c.ps_r + ps_i[n] : y;  // "pixelshuffledirect": shuffle straight into the final image
+                const int xx = c.ps_r > 1 ? x * c.ps_r + ps_j[n] : x;
                 if (yy < c.fin_h && xx < c.fin_w) {
                     float* o = reinterpret_cast<float*>(c.out);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int ch = chb + r;
+                        const int ch = nch[n] + r;
                         if (ch < c.fin_c) o[((size_t)(b * c.fin_c + ch) * c.fin_h + yy) * c.fin_w + xx] = v[r] * c.fin_scale[ch] + c.fin_bias[ch];
                     }
                 }
                 continue;
             }
-            size_t off;
-            if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {
-                const int sub = col / c.cps_p, ch = col - sub * c.cps_p;
-                const int i = sub / c.ps_r, j = sub - i * c.ps_r;
-                off = ((size_t)(b * c.H * c.ps_r + y * c.ps_r + i) * (c.W * c.ps_r) + x * c.ps_r + j) * c.cps_p + ch;
-            } else {
-                off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + col;
-            }
+            const size_t off = c.out_mode == SR_OUT_PIXEL_SHUFFLE ? ((ps_row + ps_i[n]) * ((size_t)c.W * c.ps_r) + ps_col + ps_j[n]) * c.cps_p + nch[n]
+                                                                 : pix_nhwc + nch[n];
             if (c.skip && !acc_from_skip) {
                 if (c.skip_dtype == SR_BF16)
                     v += load4(reinterpret_cast<const bf16*>(c.skip) + off);

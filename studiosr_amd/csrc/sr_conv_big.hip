@@ -150,12 +150,27 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     f32x4 bias_r[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
+    int nch[NW], ps_i[NW], ps_j[NW];  // channel inside the (shuffled) pixel, sub-pixel: the run-time divisions once per column tile
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int col = (ntile0 + n) * 16 + ag * 4;
+        nch[n] = col;
+        ps_i[n] = ps_j[n] = 0;
+        if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {  // packed channel = (i*r + j)*cps_p + ch: 4 consecutive channels of ONE shuffled pixel
+            const int sub = col / c.cps_p;
+            nch[n] = col - sub * c.cps_p;
+            ps_i[n] = sub / c.ps_r;
+            ps_j[n] = sub - ps_i[n] * c.ps_r;
+        }
+    }
     act_dispatch(c.act, [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int m = 0; m < TH; ++m) {
             const int y = y0 + m;
             const bool inb = (y < c.H) && (x < c.W);
+            const size_t pix_nhwc = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p;
+            const size_t ps_row = (size_t)(b * c.H + y) * c.ps_r, ps_col = (size_t)x * c.ps_r;
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 f32x4 v = acc[m][n] + bias_r[n];
@@ -163,15 +178,8 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
                 v *= c.out_scale;
                 if (!inb) continue;
-                const int col = (ntile0 + n) * 16 + ag * 4;
-                size_t off;
-                if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {  // packed channel = (i*r + j)*cps_p + ch: 4 consecutive channels of ONE shuffled pixel
-                    const int sub = col / c.cps_p, ch = col - sub * c.cps_p;
-                    const int i = sub / c.ps_r, j = sub - i * c.ps_r;
-                    off = ((size_t)(b * c.H * c.ps_r + y * c.ps_r + i) * (c.W * c.ps_r) + x * c.ps_r + j) * c.cps_p + ch;
-                } else {
-                    off = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p + col;
-                }
+                const size_t off = c.out_mode == SR_OUT_PIXEL_SHUFFLE ? ((ps_row + ps_i[n]) * ((size_t)c.W * c.ps_r) + ps_col + ps_j[n]) * c.cps_p + nch[n]
+                                                                     : pix_nhwc + nch[n];
                 if (c.skip && !acc_from_skip) {
                     if (c.skip_dtype == SR_BF16)
                         v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
