@@ -239,12 +239,14 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             ps_j[n] = sub - ps_i[n] * c.ps_r;
         }
     }
+    const bool scaled = c.out_scale != 1.0f;
     act_dispatch(c.act, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int y = y0 + wm * MTW + m;
         const bool inb = (y < c.H) && (x < c.W);
+        if (!inb) continue;  // ONE exec-mask branch per row tile (not one per accumulator tile)
         const size_t pix_nhwc = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p;          // NHWC pixel base
         const size_t ps_row = (size_t)(b * c.H + y) * c.ps_r, ps_col = (size_t)x * c.ps_r;  // PixelShuffle: top-left sub-pixel
 #pragma unroll
@@ -252,9 +254,8 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
             f32x4 v = acc[m][n] + bias_r[n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
-            if (c.pool_partial && inb) pool[n] += v;
-            v *= c.out_scale;
-            if (!inb) continue;
+            if (c.pool_partial) pool[n] += v;
+            if (scaled) v *= c.out_scale;
             if (c.out_mode == SR_OUT_FINAL_NCHW) {
                 const int yy = c.ps_r > 1 ? y * c.ps_r + ps_i[n] : y;  // "pixelshuffledirect": shuffle straight into the final image
                 const int xx = c.ps_r > 1 ? x * c.ps_r + ps_j[n] : x;

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             ps_j[n] = sub - ps_i[n] * c.ps_r;
         }
     }
+    const bool scaled = c.out_scale != 1.0f;
     act_dispatch(c.act, [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int m = 0; m < TH; ++m) {
             const int y = y0 + m;
             const bool inb = (y < c.H) && (x < c.W);
+            if (!inb) continue;  // one exec-mask branch per row tile
             const size_t pix_nhwc = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p;
             const size_t ps_row = (size_t)(b * c.H + y) * c.ps_r, ps_col = (size_t)x * c.ps_r;
 #pragma unroll
@@ -176,8 +178,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 f32x4 v = acc[m][n] + bias_r[n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
-                v *= c.out_scale;
-                if (!inb) continue;
+                if (scaled) v *= c.out_scale;
                 const size_t off = c.out_mode == SR_OUT_PIXEL_SHUFFLE ? ((ps_row + ps_i[n]) * ((size_t)c.W * c.ps_r) + ps_col + ps_j[n]) * c.cps_p + nch[n]
                                                                      : pix_nhwc + nch[n];
                 if (c.skip && !acc_from_skip) {
