@@ -156,6 +156,60 @@ def cpu_baseline_and_parity(model, device):
     return cpu, par
 
 
+def run_strips(args, model, device, rank, world) -> None:
+    """BASELINE configs[3]: SwinIR x4 on ONE size x size LR image, one window-aligned row strip per GPU, per-layer halo exchange
+    between strip neighbours (RCCL send/recv; studiosr_amd/strips.py).  value = HR megapixels of the whole image / time per
+    image (strong scaling: the image is fixed, N strips).  With one GPU the strips run in this process (LocalStripComm) and the
+    result is compared bit for bit with the unsharded forward; with N > 1 rank 0 checks its gathered image against the unsharded
+    forward it computes itself."""
+    import torch.distributed as dist
+
+    from studiosr_amd.strips import DistStripComm, LocalStripComm
+
+    comm = DistStripComm() if world > 1 else LocalStripComm(int(os.environ.get("SR_BENCH_STRIPS", "8")))
+    size = args.size
+    x = torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(0)).to(device)
+    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = model.forward_strips(x, comm)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.forward_strips(x, comm)
+        torch.cuda.synchronize()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            ref = model(x)
+            equal = bool(torch.equal(out, ref))
+            maxdiff = float((out - ref).abs().max())
+            dt = elapsed / steps
+            hp = (size // 8 + 1) * 8
+            flops = hp * hp * FLOP_PER_LR_PIXEL
+            print(json.dumps({
+                "metric": "HR megapixels/sec at SwinIR x4, one large LR image, row strips with halo exchange", "value": round((size * SCALE) ** 2 / 1e6 / dt, 3),
+                "unit": "HR-Mpix/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"SwinIR x4 eval forward, ONE {size}x{size} LR image, {comm.world} row strips, halo exchange per layer + gather of the HR strips",
+                           "strips": comm.world, "launch": "eager"},
+                "equals_unsharded": equal, "max_abs_diff": maxdiff,
+                "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": round(flops / dt / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4), "traffic": None},
+                "cpu_baseline": None,
+            }), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,14 +218,29 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU baseline / parity leg")
     ap.add_argument("--inflight", type=int, default=2, help="independent batches in flight per GPU (one HIP graph + stream + workspace each)")
+    ap.add_argument("--mode", choices=["tiles", "strips"], default="tiles",
+                    help="tiles: the headline metric (independent 64x64 tiles); strips: BASELINE config 4, ONE large LR image cut into one row strip per GPU with per-layer halo exchange")
+    ap.add_argument("--size", type=int, default=2048, help="--mode strips: LR image side")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) through
+        # torch.distributed.run and relay rank 0's JSON line.  This parent has not touched the GPU (importing torch does not
+        # initialise HIP) and never execs: the ranks are ordinary child processes.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import torch.distributed as dist
 
     device = torch.device("cuda", local_rank)
@@ -190,6 +259,12 @@ def main() -> None:
             dist.barrier()
 
     model = build_model(device)
+    if args.mode == "strips":
+        run_strips(args, model, device, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(BATCH, 3, TILE, TILE, generator=g).to(device)
 
@@ -259,6 +334,22 @@ def main() -> None:
     hr_mpix_per_step = world * BATCH * (TILE * SCALE) ** 2 / 1e6
     value = hr_mpix_per_step / (elapsed / args.steps)
 
+    # the same K steps with ONE batch in flight (every step waits for nothing but its own predecessor on one stream)
+    one = pipes[:1]
+    pipes_all, pipes[:] = list(pipes), one
+    run_steps(min(args.warmup, 3))
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed1 = time.perf_counter() - t0
+    pipes[:] = pipes_all
+    if world > 1:
+        t = torch.tensor([elapsed1], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed1 = float(t.item())
+
     if rank == 0:
         k_ms, k_flops = time_dominant_kernel(model, x)
         achieved = k_flops / (k_ms * 1e-3) / 1e12
@@ -290,6 +381,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": "SwinIR x4 (embed 180, 6x6 blocks, ws 8) eval forward, 64x64 LR tiles, batch 8 per GPU",
                        "tiles_per_step": world * BATCH, "launch": "eager" if args.no_graph else "hipGraph replay", "batches_in_flight": len(pipes)},
+            "one_batch_in_flight": {"ms_per_step": round(elapsed1 / args.steps * 1e3, 4), "value": round(hr_mpix_per_step / (elapsed1 / args.steps), 3),
+                                    "forward_frac": round(BATCH * PADDED * PADDED * FLOP_PER_LR_PIXEL / (elapsed1 / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "roofline": roof,
         }
         if not args.skip_cpu and world == 1:

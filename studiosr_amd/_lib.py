@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstudiosr_hip.so")
+# SR_LIB_PATH selects an experimental build (tools/variants.sh) without touching the shipped library.
+LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "lib", "libstudiosr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SR_F32, SR_BF16 = 0, 1

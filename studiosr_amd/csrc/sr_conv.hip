@@ -311,11 +311,10 @@ int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
     constexpr int ROWS = ConvGeo<TH>::ROWS;
     const int lds = c.Cin_p * ROWS * (int)sizeof(TC);
     SR_REQUIRE(lds <= 160 * 1024, "sr_conv3x3: Cin_p=%d needs %d B of LDS", c.Cin_p, lds);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>, 160 * 1024);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>, 160 * 1024); });
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     const int tiles = ((c.W + 15) / 16) * ((c.H + TH - 1) / TH) * c.B;
     dim3 grid(tiles, c.Cout_p / (WN * NW * 16));

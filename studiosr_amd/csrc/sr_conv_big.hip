@@ -201,11 +201,10 @@ int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
     constexpr int lds = (KC / PH) * 4 * BROWS * (int)sizeof(Frag<bf16>);
     static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>, lds);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
     hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);

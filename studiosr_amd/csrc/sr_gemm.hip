@@ -245,11 +245,10 @@ int launch_gemm(const SrGemm& g, hipStream_t st) {
     constexpr int M_T = GemmCfg<TC>::M_T;
     const int lds = g.K * M_T * (int)sizeof(TC);
     SR_REQUIRE(lds <= 160 * 1024, "sr_gemm: K=%d needs %d B of LDS", g.K, lds);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_gemm_kernel<TC, TIn, NW>, 160 * 1024);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_gemm_kernel<TC, TIn, NW>, 160 * 1024); });
         SR_REQUIRE(e == hipSuccess, "sr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     dim3 grid((g.M + M_T - 1) / M_T, g.N / (64 * NW));
     hipLaunchKernelGGL((sr_gemm_kernel<TC, TIn, NW>), grid, dim3(256), lds, st, g);

@@ -32,6 +32,24 @@ static inline hipError_t sr_allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// hipFuncSetAttribute is per device: run `f` once on every device a launcher is used on (bit d of the mask = done on device d).
+// Thread-safe; hipFuncSetAttribute itself is idempotent, so a lost race only repeats the call.
+#include <atomic>
+struct SrDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+};
+template <typename F>
+static inline hipError_t sr_once_per_device(SrDeviceOnce& o, F&& f) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (o.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = f();
+    if (e == hipSuccess) o.done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 // wide-channel 16 x 16-pixel-tile conv (sr_conv_big.hip); sr_conv3x3 routes the shapes it covers there
 struct SrConv3x3;
 bool sr_conv3x3_big_supported(const SrConv3x3& c);

@@ -234,11 +234,10 @@ extern "C" int sr_mlp_fused(const SrMlp* p, void* stream) {
     SR_REQUIRE(a.M > 0 && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp, "sr_mlp_fused: bad geometry");
     SR_REQUIRE(sr_mlp_fused_supported(a.Cp, a.Hp, SR_BF16), "sr_mlp_fused: unsupported Cp=%d Hp=%d (use two sr_gemm calls)", a.Cp, a.Hp);
     constexpr int lds = (6 + 12) * 4 * 64 * 16;  // 72 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_mlp_kernel<6, 12>, lds);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_mlp_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL((sr_mlp_kernel<6, 12>), dim3((a.M + 63) / 64), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_mlp_fused");

@@ -200,11 +200,10 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 template <typename TIn, typename TOut>
 int launch_rcab(const SrRcab& c, hipStream_t st) {
     constexpr int lds = (RKG * IN_ROWS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_rcab_kernel<TIn, TOut>, lds);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TIn, TOut>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_rcab_conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     const int tiles = ((c.W + TO - 1) / TO) * ((c.H + TO - 1) / TO) * c.B;
     hipLaunchKernelGGL((sr_rcab_kernel<TIn, TOut>), dim3(tiles), dim3(256), lds, st, c);

@@ -493,12 +493,10 @@ extern "C" int sr_swin_attn_fused(const SrSwinAttn* p, void* stream) {
     dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
     constexpr int lds = 2 * (24 * 64 * 16 + 6 * 8 * 64 * 16 + 64 * 6 * 2 * 4);  // per window: 24 KiB image + 48 KiB residual slices + 3 KiB LN partials
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = sr_allow_lds(sr_swin_attn_kernel<false>, lds);
-        if (e == hipSuccess) e = sr_allow_lds(sr_swin_attn_kernel<true>, lds);
+    static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { hipError_t e2 = sr_allow_lds(sr_swin_attn_kernel<false>, lds); return e2 != hipSuccess ? e2 : sr_allow_lds(sr_swin_attn_kernel<true>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_attn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     const dim3 grid((a.B * nwx * nwy + 1) / 2);
     if (a.w1p) {

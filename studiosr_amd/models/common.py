@@ -39,8 +39,46 @@ class Model(nn.Module):
         self.precision = precision
         return self
 
-    def _param_version(self) -> int:
-        return sum(p._version + (p.data_ptr() & 0xFFFF) for p in self.parameters())
+    def _param_version(self):
+        """(data_ptr, _version) of every parameter and buffer: in-place updates through autograd-visible ops (optimizer.step,
+        copy_, load_state_dict) bump _version, .to()/.cuda() change data_ptr.  Edits through `.data` are invisible to both:
+        call repack() after them."""
+
+        def ver(t):
+            try:
+                return t._version
+            except RuntimeError:  # inference tensors do not track versions
+                return -1
+
+        return tuple((t.data_ptr(), ver(t)) for t in list(self.parameters()) + list(self.buffers()))
+
+    def repack(self) -> "Model":
+        """Drop the fragment-packed weight cache (needed only after editing parameters through `.data`)."""
+        self._packed = {}
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = {}
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .half(): parameters are replaced
+        self._packed = {}
+        self._ws = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):  # deepcopy / pickle: derived device state (workspace, packed weights) is rebuilt on demand
+        state = dict(self.__dict__)
+        state["_packed"], state["_ws"] = {}, None
+        return state
+
+    def __call__(self, *args, **kwargs):
+        """Launches go to the CURRENT device's current stream: make the input's device current for the whole forward
+        (model.to('cuda:1') with device 0 current is the standard multi-GPU idiom)."""
+        x = args[0] if args else None
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return super().__call__(*args, **kwargs)
+        return super().__call__(*args, **kwargs)
 
     def _get_packed(self, dt: torch.dtype) -> Dict:
         """Fragment-ordered weights for compute dtype dt, rebuilt when a parameter changes."""
@@ -59,10 +97,14 @@ class Model(nn.Module):
     def _workspace(self, device: torch.device) -> Workspace:
         if self._ws is None or self._ws.device != device:
             self._ws = Workspace(device)
+        self._ws.begin_forward()
         return self._ws
 
     def _check_input(self, x: Tensor) -> Tensor:
         require_device(x)
+        pdev = next(self.parameters()).device
+        if pdev != x.device:
+            raise RuntimeError(f"input is on {x.device} but the model parameters are on {pdev}")
         if x.dim() != 4 or x.shape[1] != self.n_colors:
             raise RuntimeError(f"expected input [B,{self.n_colors},H,W], got {tuple(x.shape)}")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:

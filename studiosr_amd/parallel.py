@@ -3,7 +3,7 @@
 Super-resolution tiles are independent (first row): the batch of tiles is cut into contiguous,
 balanced slices, every rank runs the HIP forward on its slice, and the HR tiles are collected with ONE all_gather of
 equally padded slices.  There is no collective on the data path itself.  (Sharding a single huge image with
-per-layer halo exchange -- BASELINE config 4 -- is the next row of the scope table, not implemented here.)
+per-layer halo exchange -- BASELINE config 4 -- lives in studiosr_amd/strips.py.)
 """
 from __future__ import annotations
 

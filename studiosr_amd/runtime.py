@@ -1,6 +1,6 @@
 """Small host-side runtime shared by the model drivers: workspace buffers, precision policy,
-HIP-graph capture of a whole forward pass (the launch-bound regime: ~170 kernels per SwinIR
-forward at ~3 us each would otherwise be host-bound)."""
+HIP-graph capture of a whole forward pass (the launch-bound regime: 51 kernels per SwinIR
+forward at ~3 us of host time each would otherwise be host-bound)."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Tuple
@@ -42,35 +42,79 @@ def sr_dtype(dt: torch.dtype) -> int:
 
 class Workspace:
     """Named device buffers, reused across forwards of the same geometry (graph-capture friendly:
-    a captured forward only touches buffers that were allocated before capture)."""
+    a captured forward only touches buffers that were allocated before capture).
+
+    The cache is bounded: an evaluation loop over images of many sizes (Set14, Urban100, DIV2K) asks for a new buffer set
+    per size, so buffers are kept least-recently-used under a byte budget (SR_WS_BUDGET_MB, default 16 GiB of the 288 GB)
+    and the rest is released.  Buffers used by the forward in progress (same epoch) and buffers a HIP graph recorded
+    (requested while the stream was capturing: the graph holds their raw pointers) are never evicted."""
 
     GUARD_BYTES = 1 << 16  # SR_WS_GUARD=1: every buffer sits between two 64 KiB guard zones (see check_guards)
 
-    def __init__(self, device: torch.device) -> None:
+    def __init__(self, device: torch.device, budget_bytes: int = 0) -> None:
         import os
 
         self.device = device
         self.bufs: Dict[Tuple, Tensor] = {}
         self.guard = bool(os.environ.get("SR_WS_GUARD"))
         self._raw: Dict[Tuple, Tensor] = {}
+        self.budget = budget_bytes or int(os.environ.get("SR_WS_BUDGET_MB", str(16 * 1024))) << 20
+        self.epoch = 0
+        self._used: Dict[Tuple, int] = {}    # key -> epoch of the last request
+        self._pinned: set = set()            # keys recorded by a HIP graph
+        self.bytes = 0
+
+    def begin_forward(self) -> None:
+        """Called once at the start of every forward: buffers requested from here on belong to this forward."""
+        self.epoch += 1
+
+    @staticmethod
+    def _nbytes(shape, dtype) -> int:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return n * torch.empty((), dtype=dtype).element_size()
+
+    def _evict(self, need: int) -> None:
+        if self.bytes + need <= self.budget:
+            return
+        for key in sorted((k for k in self.bufs if k not in self._pinned and self._used.get(k, 0) < self.epoch), key=lambda k: self._used.get(k, 0)):
+            self.bytes -= self._nbytes(key[1], key[2])
+            del self.bufs[key]
+            self._raw.pop(key, None)
+            self._used.pop(key, None)
+            if self.bytes + need <= self.budget:
+                break
 
     def get(self, name: str, shape, dtype: torch.dtype) -> Tensor:
-        key = (name, tuple(shape), dtype)
+        key = (name, tuple(int(d) for d in shape), dtype)
         t = self.bufs.get(key)
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if t is None:
+            nbytes = self._nbytes(key[1], dtype)
+            if not capturing:
+                self._evict(nbytes)
             if self.guard:
-                n = 1
-                for d in shape:
-                    n *= int(d)
-                nbytes = n * torch.empty((), dtype=dtype).element_size()
                 raw = torch.full((nbytes + 2 * self.GUARD_BYTES,), 0x5A, dtype=torch.uint8, device=self.device)
                 raw[self.GUARD_BYTES : self.GUARD_BYTES + nbytes] = 0
                 self._raw[key] = raw
-                t = raw[self.GUARD_BYTES : self.GUARD_BYTES + nbytes].view(dtype).view(tuple(shape))
+                t = raw[self.GUARD_BYTES : self.GUARD_BYTES + nbytes].view(dtype).view(key[1])
             else:
-                t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+                t = torch.zeros(key[1], dtype=dtype, device=self.device)
             self.bufs[key] = t
+            self.bytes += nbytes
+        self._used[key] = self.epoch
+        if capturing:
+            self._pinned.add(key)
         return t
+
+    def release(self) -> None:
+        """Drop every buffer no HIP graph depends on (the reference's empty_cache() after inference, common.py:47)."""
+        for key in [k for k in self.bufs if k not in self._pinned]:
+            self.bytes -= self._nbytes(key[1], key[2])
+            del self.bufs[key]
+            self._raw.pop(key, None)
+            self._used.pop(key, None)
 
     def check_guards(self):
         """Debug aid: names of buffers whose guard zones were written (out-of-bounds stores by a kernel)."""

@@ -1,0 +1,62 @@
+"""Multi-GPU paths on real devices (skipped on a one-GPU box): `bench.py --gpus 2` starts its own ranks (one per GPU, RCCL),
+--mode tiles = independent tile batches (no data-path collective), --mode strips = ONE image in row strips with per-layer halo
+exchange over `DistStripComm` (nccl p2p), checked bit for bit against the unsharded forward on rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 visible GPUs")
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@needs2
+def test_bench_self_launches_two_ranks_tiles():
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", "--skip-cpu")
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["tiles_per_step"] == 16 and r["value"] > 0
+
+
+@needs2
+def test_strips_two_ranks_nccl_equal_the_unsharded_forward():
+    r = _bench("--gpus", "2", "--mode", "strips", "--size", "200", "--steps", "2", "--warmup", "1")
+    assert r["n_gpus"] == 2 and r["config"]["strips"] == 2
+    assert r["equals_unsharded"] is True and r["max_abs_diff"] == 0.0
+
+
+@needs2
+def test_tile_parallel_with_the_hip_forward_on_nccl(tmp_path):
+    script = tmp_path / "tp.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import studiosr_amd as S\n"
+        "from studiosr_amd.parallel import TileParallel\n"
+        "lr = int(os.environ['LOCAL_RANK']); torch.cuda.set_device(lr); dev = torch.device('cuda', lr)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "torch.manual_seed(0)\n"
+        "m = S.SwinIR(scale=2, embed_dim=60, depths=[2], num_heads=[6]).to(dev).eval().set_precision('bf16')\n"
+        "x = torch.rand(5, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev)\n"
+        "with torch.no_grad():\n"
+        "    ref = m(x)\n"
+        "    out = TileParallel(lambda t: m(t))(x)\n"
+        "assert torch.equal(out, ref), float((out - ref).abs().max())\n"
+        "dist.barrier(); dist.destroy_process_group(); print('OK')\n"
+    )
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", str(script)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.count("OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]
