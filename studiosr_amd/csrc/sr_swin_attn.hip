@@ -487,6 +487,9 @@ extern "C" int sr_swin_attn_fused(const SrSwinAttn* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_attn_fused: bad geometry");
+    if (a.w1p) SR_REQUIRE(a.b1 && a.w2p && a.b2 && a.Hp == 384, "sr_swin_attn_fused: the fused MLP tail needs w1p/b1/w2p/b2 and Hp == 384");
+    // the one-window-per-workgroup kernel keeps the softmax denominator in the first pad channel of every head: needs hd = 30 of 32
+    if (sr_swin_block_v2_enabled() && a.C == 180) return sr_swin_block_v2(a, reinterpret_cast<hipStream_t>(stream));
     SwinAttnDev dv;
     dv.a = a;
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
@@ -500,7 +503,6 @@ extern "C" int sr_swin_attn_fused(const SrSwinAttn* p, void* stream) {
     }
     const dim3 grid((a.B * nwx * nwy + 1) / 2);
     if (a.w1p) {
-        SR_REQUIRE(a.b1 && a.w2p && a.b2 && a.Hp == 384, "sr_swin_attn_fused: the fused MLP tail needs w1p/b1/w2p/b2 and Hp == 384");
         hipLaunchKernelGGL(sr_swin_attn_kernel<true>, grid, dim3(768), lds, reinterpret_cast<hipStream_t>(stream), dv);
     } else {
         hipLaunchKernelGGL(sr_swin_attn_kernel<false>, grid, dim3(768), lds, reinterpret_cast<hipStream_t>(stream), dv);
