@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 2
+#define SR_ABI_VERSION 3
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -234,6 +234,69 @@ typedef struct SrChannelAttn {
     int skip2_dtype;
 } SrChannelAttn;
 int sr_channel_attention(const SrChannelAttn* a, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training engine (ABI v3): the kernels behind studiosr_amd/autograd.py, i.e. forward + backward of every op the
+ * reference's training step reaches (studiosr/engine/trainer.py:97-109: autocast forward, L1 loss, backward, Adam).
+ * All tensors fp32, UNPADDED and in the reference's own layouts (parameters / gradients exactly as in the state_dict).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct SrBgemm {
+    /* C[b1,b2][m,n] (=, += or atomic +=) alpha * sum_k A[b1,b2][m,k] * B[b1,b2][k,n] + bias[n] on the exact-fp32 matrix
+     * cores.  Every operand is addressed through element strides, so transposes, head slices of a packed qkv tensor and
+     * NCHW / NHWC outputs are free.  Replaces torch's addmm / bmm / mkldnn_convolution (over an sr_im2col3x3 buffer) and their
+     * autograd adjoints: nn.Linear (swinir.py:69-71, common.py:184-195), q k^T and attn v (swinir.py:85,102; hat.py:92,107,
+     * 268,283), nn.Conv2d 3x3 / 1x1 (common.py:104-105,140-153,156-170; hat.py:25-52).
+     * ksplit > 1 splits K over workgroups and accumulates with fp32 atomics (weight gradients: K = tokens); C must then hold
+     * the value to accumulate onto (zeros for a fresh gradient). */
+    const float* A; const float* B; float* C;
+    const float* bias;                /* [N] or NULL */
+    int M, N, K;
+    long long sa_m, sa_k, sb_k, sb_n, sc_m, sc_n;                 /* element strides */
+    int nb1, nb2;                                                 /* two batch levels (e.g. windows x heads) */
+    long long sa_b1, sa_b2, sb_b1, sb_b2, sc_b1, sc_b2;
+    float alpha;
+    int accumulate;                   /* ksplit == 1: C += instead of C = */
+    int ksplit;
+} SrBgemm;
+int sr_bgemm(const SrBgemm* g, void* stream);
+
+/* col[m, c*9 + tap] = x[b, y + tap/3 - 1, x + tap%3 - 1, c] (zero outside), m = (b*H + y)*W + x: the column order is OIHW's,
+ * so conv(x, w) = col @ w.view(Cout, Cin*9)^T (common.py:104-105).  x is addressed by element strides (NCHW or NHWC).
+ * sr_col2im3x3 is the adjoint written as a gather: dx[m, c] = sum_tap dcol[m - tap offset, c*9 + tap]. */
+int sr_im2col3x3(const float* x, float* col, int B, int H, int W, int C, long long sb, long long sy, long long sx, long long sc, void* stream);
+int sr_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
+
+/* rows r = (bw*heads + h)*Nq + i of S [.., Nk]: S <- softmax(S + bias[h,i,:] + mask[bw % nW, i, :]) in place
+ * (swinir.py:92-100, hat.py:97-106,276-281; bias / mask may be NULL); backward: dP <- P * (dP - sum_j dP_j P_j). */
+int sr_softmax_fwd(float* S, const float* bias, const float* mask, long long rows, int heads, int Nq, int Nk, int nW, void* stream);
+int sr_softmax_bwd(const float* P, float* dP, long long rows, int Nk, void* stream);
+
+/* nn.LayerNorm(C) forward saving (mean, rstd) per row, and its backward; dgamma / dbeta are ACCUMULATED (atomics). */
+int sr_layernorm_fwd_train(const float* x, const float* gamma, const float* beta, float* y, float* stats, long long M, int C, float eps, void* stream);
+int sr_layernorm_bwd(const float* x, const float* stats, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, long long M, int C, void* stream);
+
+/* out[b][c] += alpha * sum_p x[b][p][c] (bias gradients, AdaptiveAvgPool2d(1): common.py:160, hat.py:31);
+ * out[i] = sum_b x[b*stride_b + i] (relative-position-bias gradient summed over windows, deterministic). */
+int sr_colsum(const float* x, float* out, int nb, long long P, int C, float alpha, void* stream);
+int sr_batch_sum(const float* x, float* out, long long nb, long long n, long long stride_b, void* stream);
+
+/* flat elementwise ops (forward and backward of GELU / ReLU / LeakyReLU / sigmoid, a x + b y, x*y, DropPath's per-sample scale
+ * (swinir.py:137,171-172), the channel-attention gate x[b,p,c] * s[b,c] and its broadcast adjoint, per-channel affine) */
+enum { SR_EW_GELU_FWD = 0, SR_EW_GELU_BWD = 1, SR_EW_RELU_FWD = 2, SR_EW_RELU_BWD = 3, SR_EW_LRELU_FWD = 4, SR_EW_LRELU_BWD = 5, SR_EW_AXPBY = 6,
+       SR_EW_MUL = 7, SR_EW_SIGMOID_FWD = 8, SR_EW_SIGMOID_BWD = 9, SR_EW_SCALE_SAMPLE = 10, SR_EW_MUL_BC = 11, SR_EW_BCAST_BC = 12, SR_EW_AFFINE_C = 13 };
+int sr_eltwise(int op, const float* x, const float* y, const float* s, float* out, long long n, long long inner, int C, float a, float b, void* stream);
+
+/* index maps, each usable in both directions (the adjoint of a permutation is its inverse; overlapping OCA windows fold by gather):
+ * window_partition(roll(x, -shift)) <-> image (swinir.py:154-158,164-168); nn.Unfold of OCAB (hat.py:217-221,255-263);
+ * nn.PixelShuffle on NHWC (common.py:129,133,136); relative_position_bias_table[rpi] with python-style negative wrap
+ * (swinir.py:86-91, hat.py:93-96,276-279; the adjoint scatter-adds into dtable); the model's NCHW output with Normalizer.unnormalize /
+ * MeanShift(add) and the crop to [H*s, W*s] (common.py:232-233, swinir.py:372). */
+int sr_window_copy(const float* src, float* dst, int B, int H, int W, int C, int ws, int shift, int to_windows, void* stream);
+int sr_oca_unfold(const float* img, float* win, int B, int H, int W, int C, int ws, int wse, int forward, void* stream);
+int sr_pixel_shuffle_nhwc(const float* src, float* dst, int B, int H, int W, int C, int r, int forward, void* stream);
+int sr_bias_gather(const float* table, const long long* rpi, float* bias, float* dtable, int T, int heads, long long NN, int forward, void* stream);
+int sr_nhwc_out(const float* src, float* dst, const float* scale, const float* shift, int B, int Hs, int Ws, int C, int Ho, int Wo, int forward, void* stream);
 
 #ifdef __cplusplus
 }

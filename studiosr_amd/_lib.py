@@ -23,7 +23,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -101,6 +101,21 @@ class SrChannelAttn(C.Structure):
     ]
 
 
+_ll = C.c_longlong
+
+
+class SrBgemm(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("M", _i), ("N", _i), ("K", _i),
+        ("sa_m", _ll), ("sa_k", _ll), ("sb_k", _ll), ("sb_n", _ll), ("sc_m", _ll), ("sc_n", _ll),
+        ("nb1", _i), ("nb2", _i), ("sa_b1", _ll), ("sa_b2", _ll), ("sb_b1", _ll), ("sb_b2", _ll), ("sc_b1", _ll), ("sc_b2", _ll),
+        ("alpha", _f), ("accumulate", _i), ("ksplit", _i),
+    ]
+
+
+EW_GELU_FWD, EW_GELU_BWD, EW_RELU_FWD, EW_RELU_BWD, EW_LRELU_FWD, EW_LRELU_BWD, EW_AXPBY, EW_MUL = range(8)
+EW_SIGMOID_FWD, EW_SIGMOID_BWD, EW_SCALE_SAMPLE, EW_MUL_BC, EW_BCAST_BC, EW_AFFINE_C = range(8, 14)
+
 # every symbol include/studiosr_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sr_abi_version": (_i, []),
@@ -123,6 +138,22 @@ SYMBOLS = {
     "sr_u8_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_nchw_to_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),
+    # training engine (ABI v3)
+    "sr_bgemm": (_i, [C.POINTER(SrBgemm), _vp]),
+    "sr_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp]),
+    "sr_col2im3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sr_softmax_fwd": (_i, [_vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "sr_softmax_bwd": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "sr_layernorm_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
+    "sr_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
+    "sr_colsum": (_i, [_vp, _vp, _i, _ll, _i, _f, _vp]),
+    "sr_batch_sum": (_i, [_vp, _vp, _ll, _ll, _ll, _vp]),
+    "sr_eltwise": (_i, [_i, _vp, _vp, _vp, _vp, _ll, _ll, _i, _f, _f, _vp]),
+    "sr_window_copy": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_oca_unfold": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_pixel_shuffle_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_bias_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp]),
+    "sr_nhwc_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

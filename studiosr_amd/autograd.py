@@ -1,0 +1,534 @@
+"""Differentiable ops of the training path: every forward AND backward is a launch of the HIP training engine
+(studiosr_amd/csrc/sr_train.hip through the C ABI); torch supplies device memory, the autograd graph and the RNG stream.
+
+The op set is the closed set the reference's training step reaches (studiosr/engine/trainer.py:97-109):
+nn.Linear, 3x3 / 1x1 nn.Conv2d, nn.LayerNorm, GELU / ReLU / LeakyReLU / Sigmoid, window partition / reverse with the cyclic
+shift, (shifted-)window attention with the relative-position bias table and the -100 mask, HAT's overlapping cross attention
+(nn.Unfold), AdaptiveAvgPool2d(1) + the channel-attention gate, nn.PixelShuffle, DropPath, residual adds and the final
+un-normalise + crop.  Tensors are fp32, NHWC / token-major and unpadded; parameters are used and their gradients produced in the
+reference's state_dict layouts, so torch.optim and DistributedDataParallel see ordinary `.grad`s.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+Fn = torch.autograd.Function
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Tensor) -> Tensor:
+    if not t.is_cuda:
+        raise L.HipLibraryError("studiosr_amd training ops need ROCm device tensors (there is no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"training ops are fp32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- raw launches
+def bgemm(A: Tensor, B: Tensor, Cc: Tensor, M: int, N: int, K: int, sa: Tuple[int, int], sb: Tuple[int, int], sc: Tuple[int, int], *,
+          a_off: int = 0, b_off: int = 0, c_off: int = 0, bias: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False, ksplit: int = 1,
+          nb: Tuple[int, int] = (1, 1), sab=(0, 0), sbb=(0, 0), scb=(0, 0)) -> None:
+    """C[b][m,n] (=|+=) alpha * sum_k A[b][m,k] B[b][k,n] + bias[n]; strides in elements, offsets in elements from data_ptr."""
+    g = L.SrBgemm()
+    g.A, g.B, g.C = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cc.data_ptr() + 4 * c_off
+    g.bias = None if bias is None else bias.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.sa_m, g.sa_k = sa
+    g.sb_k, g.sb_n = sb
+    g.sc_m, g.sc_n = sc
+    g.nb1, g.nb2 = nb
+    g.sa_b1, g.sa_b2 = sab
+    g.sb_b1, g.sb_b2 = sbb
+    g.sc_b1, g.sc_b2 = scb
+    g.alpha, g.accumulate, g.ksplit = float(alpha), int(accumulate), int(ksplit)
+    L.check(L.lib().sr_bgemm(C.byref(g), _st()), "sr_bgemm")
+
+
+def _ksplit(rows: int, cols: int, K: int) -> int:
+    """Workgroups for a weight-gradient GEMM whose contraction runs over K tokens: enough slices to fill 256 CUs, each >= 256 long."""
+    tiles = ((rows + 63) // 64) * ((cols + 63) // 64)
+    return max(1, min(1024 // max(tiles, 1), (K + 255) // 256, 512))
+
+
+def eltwise(op: int, x: Optional[Tensor], out: Tensor, *, y: Optional[Tensor] = None, s: Optional[Tensor] = None, inner: int = 1, Cn: int = 1, a: float = 0.0, b: float = 0.0) -> Tensor:
+    L.check(L.lib().sr_eltwise(op, None if x is None else x.data_ptr(), None if y is None else y.data_ptr(), None if s is None else s.data_ptr(), out.data_ptr(),
+                               out.numel(), inner, Cn, float(a), float(b), _st()), "sr_eltwise")
+    return out
+
+
+def colsum(x: Tensor, out: Tensor, nb: int, P: int, Cn: int, alpha: float = 1.0) -> Tensor:
+    """out[b][c] += alpha * sum_p x[b][p][c]"""
+    L.check(L.lib().sr_colsum(x.data_ptr(), out.data_ptr(), nb, P, Cn, float(alpha), _st()), "sr_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------- nn.Linear / conv
+class _Linear(Fn):
+    """y[M,N] = x[M,K] @ w[N,K]^T + b (swinir.py:69-71, common.py:184-195; 1x1 convs of the channel attention, common.py:161-167)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _chk(x), _chk(w)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        bgemm(x, w, y, M, N, K, (K, 1), (1, K), (N, 1), bias=None if b is None else _chk(b))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            bgemm(dy, x, dw, N, K, M, (1, N), (K, 1), (K, 1), ksplit=_ksplit(N, K, M))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, torch.zeros(N, device=dy.device), 1, M, N)
+        return dx, dw, db
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    return _Linear.apply(x, w.reshape(w.shape[0], -1), b)
+
+
+def _im2col(x: Tensor, strides=None, Cn: Optional[int] = None) -> Tensor:
+    B, H, W = x.shape[:3]
+    Cn = x.shape[3] if Cn is None else Cn
+    sb, sy, sx, sc = strides if strides is not None else (H * W * Cn, W * Cn, Cn, 1)
+    col = torch.empty(B * H * W, 9 * Cn, device=x.device, dtype=torch.float32)
+    L.check(L.lib().sr_im2col3x3(x.data_ptr(), col.data_ptr(), B, H, W, Cn, sb, sy, sx, sc, _st()), "sr_im2col3x3")
+    return col
+
+
+class _Conv3x3(Fn):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) on NHWC (common.py:104-105): y = im2col(x) @ w.view(Cout, Cin*9)^T + b.  The column buffer
+    is rebuilt in backward instead of being kept (a 256x256 conv_last buffer is 0.6 GB)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cin):
+        x, w = _chk(x), _chk(w)
+        B, H, W = x.shape[:3]
+        ld = x.shape[3]  # cin < ld: the input is a channel-padded buffer (the ingest kernel's NHWC-32 image)
+        Cout = w.shape[0]
+        col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
+        y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+        bgemm(col, w, y, B * H * W, Cout, 9 * cin, (9 * cin, 1), (1, 9 * cin), (Cout, 1), bias=None if b is None else _chk(b))
+        ctx.save_for_backward(x, w)
+        ctx.cin, ctx.has_bias = cin, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy)
+        B, H, W = x.shape[:3]
+        ld, cin = x.shape[3], ctx.cin
+        Cout, M, K = w.shape[0], B * H * W, 9 * cin
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            assert ld == cin, "no input gradient through a channel-padded input buffer"
+            dcol = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            bgemm(dy, w, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
+            dx = torch.empty_like(x)
+            L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
+        if ctx.needs_input_grad[1]:
+            col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
+            dw = torch.zeros_like(w)
+            bgemm(dy, col, dw, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, torch.zeros(Cout, device=dy.device), 1, M, Cout)
+        return dx, dw, db, None
+
+
+def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], cin: Optional[int] = None) -> Tensor:
+    """x [B,H,W,C] -> [B,H,W,Cout]; w is the nn.Conv2d weight [Cout, Cin, 3, 3]."""
+    cin = w.shape[1] if cin is None else cin
+    return _Conv3x3.apply(x, w.reshape(w.shape[0], -1), b, cin)
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(Fn):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = _chk(x)
+        Cn = x.shape[-1]
+        M = x.numel() // Cn
+        y = torch.empty_like(x)
+        stats = torch.empty(M, 2, device=x.device, dtype=torch.float32)
+        L.check(L.lib().sr_layernorm_fwd_train(x.data_ptr(), _chk(g).data_ptr(), _chk(b).data_ptr(), y.data_ptr(), stats.data_ptr(), M, Cn, float(eps), _st()), "sr_layernorm_fwd_train")
+        ctx.save_for_backward(x, g, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, stats = ctx.saved_tensors
+        dy = _chk(dy)
+        Cn = x.shape[-1]
+        M = x.numel() // Cn
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        L.check(L.lib().sr_layernorm_bwd(x.data_ptr(), stats.data_ptr(), g.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, Cn, _st()), "sr_layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    return _LayerNorm.apply(x, g, b, eps)
+
+
+# --------------------------------------------------------------------------- elementwise
+class _Act(Fn):
+    FWD = {"gelu": L.EW_GELU_FWD, "relu": L.EW_RELU_FWD, "lrelu": L.EW_LRELU_FWD, "sigmoid": L.EW_SIGMOID_FWD}
+    BWD = {"gelu": L.EW_GELU_BWD, "relu": L.EW_RELU_BWD, "lrelu": L.EW_LRELU_BWD, "sigmoid": L.EW_SIGMOID_BWD}
+
+    @staticmethod
+    def forward(ctx, x, kind, slope):
+        x = _chk(x)
+        y = eltwise(_Act.FWD[kind], x, torch.empty_like(x), a=slope)
+        ctx.save_for_backward(x if kind in ("gelu", "lrelu", "relu") else y)  # sigmoid's derivative is written in its output
+        ctx.kind, ctx.slope = kind, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (t,) = ctx.saved_tensors
+        dy = _chk(dy)
+        return eltwise(_Act.BWD[ctx.kind], dy, torch.empty_like(dy), y=t, a=ctx.slope), None, None
+
+
+def gelu(x):
+    return _Act.apply(x, "gelu", 0.0)
+
+
+def relu(x):
+    return _Act.apply(x, "relu", 0.0)
+
+
+def leaky_relu(x, slope: float = 0.01):
+    return _Act.apply(x, "lrelu", slope)
+
+
+def sigmoid(x):
+    return _Act.apply(x, "sigmoid", 0.0)
+
+
+class _Axpby(Fn):
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        x, y = _chk(x), _chk(y)
+        assert x.shape == y.shape
+        ctx.a, ctx.b = a, b
+        return eltwise(L.EW_AXPBY, x, torch.empty_like(x), y=y, a=a, b=b)
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _chk(d)
+        dx = eltwise(L.EW_AXPBY, d, torch.empty_like(d), a=ctx.a) if ctx.needs_input_grad[0] else None
+        dy = eltwise(L.EW_AXPBY, d, torch.empty_like(d), a=ctx.b) if ctx.needs_input_grad[1] else None
+        return dx, dy, None, None
+
+
+def add(x: Tensor, y: Tensor, a: float = 1.0, b: float = 1.0) -> Tensor:
+    """a*x + b*y (residual adds, res_scale: common.py:152, hat.py:192)."""
+    return _Axpby.apply(x, y, a, b)
+
+
+class _ScaleSample(Fn):
+    @staticmethod
+    def forward(ctx, x, s):
+        x = _chk(x)
+        ctx.save_for_backward(s)
+        return eltwise(L.EW_SCALE_SAMPLE, x, torch.empty_like(x), s=s, inner=x.numel() // x.shape[0])
+
+    @staticmethod
+    def backward(ctx, d):
+        (s,) = ctx.saved_tensors
+        d = _chk(d)
+        return eltwise(L.EW_SCALE_SAMPLE, d, torch.empty_like(d), s=s, inner=d.numel() // d.shape[0]), None
+
+
+def drop_path(x: Tensor, p: float, training: bool) -> Tensor:
+    """timm's DropPath(drop_prob, scale_by_keep=True) (swinir.py:7,137,171-172; hat.py:148,192-193): per-sample Bernoulli(keep) / keep
+    in training, identity otherwise.  The mask comes from torch's device RNG (same distribution as the reference's bernoulli_)."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return _ScaleSample.apply(x, mask)
+
+
+# --------------------------------------------------------------------------- index maps
+class _WindowCopy(Fn):
+    @staticmethod
+    def forward(ctx, x, ws, shift, to_windows, shape):
+        x = _chk(x)
+        B, H, W, Cn = shape
+        ctx.meta = (ws, shift, to_windows, shape)
+        out = torch.empty((B * (H // ws) * (W // ws) * ws * ws, Cn) if to_windows else (B, H, W, Cn), device=x.device, dtype=torch.float32)
+        L.check(L.lib().sr_window_copy(x.data_ptr(), out.data_ptr(), B, H, W, Cn, ws, shift, int(to_windows), _st()), "sr_window_copy")
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        ws, shift, to_windows, shape = ctx.meta
+        return _WindowCopy.apply(d, ws, shift, not to_windows, shape), None, None, None, None
+
+
+def window_partition(x: Tensor, ws: int, shift: int) -> Tensor:
+    """[B,H,W,C] -> window-order tokens [B*nW*ws*ws, C] = window_partition(roll(x, (-shift, -shift))) (swinir.py:154-158)."""
+    return _WindowCopy.apply(x, ws, shift, True, tuple(x.shape))
+
+
+def window_reverse(t: Tensor, ws: int, shift: int, shape) -> Tensor:
+    """inverse of window_partition: roll(window_reverse(t), (+shift, +shift)) (swinir.py:164-168)."""
+    return _WindowCopy.apply(t, ws, shift, False, tuple(shape))
+
+
+class _OcaUnfold(Fn):
+    @staticmethod
+    def forward(ctx, x, ws, wse):
+        x = _chk(x)
+        B, H, W, Cn = x.shape
+        ctx.meta = (ws, wse, tuple(x.shape))
+        out = torch.empty(B * (H // ws) * (W // ws) * wse * wse, Cn, device=x.device, dtype=torch.float32)
+        L.check(L.lib().sr_oca_unfold(x.data_ptr(), out.data_ptr(), B, H, W, Cn, ws, wse, 1, _st()), "sr_oca_unfold")
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        ws, wse, (B, H, W, Cn) = ctx.meta
+        d = _chk(d)
+        dx = torch.empty(B, H, W, Cn, device=d.device, dtype=torch.float32)
+        L.check(L.lib().sr_oca_unfold(dx.data_ptr(), d.data_ptr(), B, H, W, Cn, ws, wse, 0, _st()), "sr_oca_unfold")
+        return dx, None, None
+
+
+def oca_unfold(x: Tensor, ws: int, wse: int) -> Tensor:
+    """nn.Unfold(kernel=wse, stride=ws, padding=(wse-ws)//2) as window-order tokens [B*nW*wse*wse, C] (hat.py:217-221,255-263)."""
+    return _OcaUnfold.apply(x, ws, wse)
+
+
+class _PixelShuffle(Fn):
+    @staticmethod
+    def forward(ctx, x, r, forward_dir):
+        x = _chk(x)
+        B, H, W, Cn = x.shape
+        ctx.r, ctx.fwd = r, forward_dir
+        if forward_dir:
+            out = torch.empty(B, H * r, W * r, Cn // (r * r), device=x.device, dtype=torch.float32)
+            L.check(L.lib().sr_pixel_shuffle_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cn // (r * r), r, 1, _st()), "sr_pixel_shuffle_nhwc")
+        else:
+            out = torch.empty(B, H // r, W // r, Cn * r * r, device=x.device, dtype=torch.float32)
+            L.check(L.lib().sr_pixel_shuffle_nhwc(x.data_ptr(), out.data_ptr(), B, H // r, W // r, Cn, r, 0, _st()), "sr_pixel_shuffle_nhwc")
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return _PixelShuffle.apply(d, ctx.r, not ctx.fwd), None, None
+
+
+def pixel_shuffle(x: Tensor, r: int) -> Tensor:
+    """nn.PixelShuffle(r) on NHWC: out[b, y*r+i, x*r+j, c] = in[b, y, x, c*r*r + i*r + j] (common.py:129,133,136)."""
+    return _PixelShuffle.apply(x, r, True)
+
+
+# --------------------------------------------------------------------------- attention
+def _gather_bias(table: Tensor, rpi: Tensor, heads: int) -> Tensor:
+    NN = rpi.numel()
+    bias = torch.empty(heads, NN, device=table.device, dtype=torch.float32)
+    L.check(L.lib().sr_bias_gather(table.data_ptr(), rpi.data_ptr(), bias.data_ptr(), None, table.shape[0], heads, NN, 1, _st()), "sr_bias_gather")
+    return bias
+
+
+class _Attention(Fn):
+    """softmax(scale * q k^T + table[rpi] + mask) v per (window, head) (swinir.py:83-102; hat.py:90-107; OCAB hat.py:266-283).
+    q is the column slice [q_off, q_off + C) of the token-major tensor `qs` (Nq consecutive rows per window), k and v are slices of
+    `kvs` (Nk rows per window); `qs` and `kvs` may be ONE packed qkv tensor (`same`), which then gets ONE packed gradient."""
+
+    @staticmethod
+    def forward(ctx, qs, kvs, table, rpi, mask, meta):
+        heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = meta
+        qs = _chk(qs)
+        kvs = qs if same else _chk(kvs)
+        table = _chk(table)
+        hd = Cn // heads
+        ldq, ldk = qs.shape[-1], kvs.shape[-1]
+        nbw = qs.numel() // ldq // Nq
+        dev = qs.device
+        P = torch.empty(nbw, heads, Nq, Nk, device=dev, dtype=torch.float32)
+        nbh = (nbw, heads)
+        bgemm(qs, kvs, P, Nq, Nk, hd, (ldq, 1), (1, ldk), (Nk, 1), a_off=q_off, b_off=k_off, alpha=scale, nb=nbh,
+              sab=(Nq * ldq, hd), sbb=(Nk * ldk, hd), scb=(heads * Nq * Nk, Nq * Nk))
+        bias = _gather_bias(table, rpi, heads)
+        nW = mask.shape[0] if mask is not None else 0
+        L.check(L.lib().sr_softmax_fwd(P.data_ptr(), bias.data_ptr(), None if mask is None else mask.data_ptr(), nbw * heads * Nq, heads, Nq, Nk, nW, _st()), "sr_softmax_fwd")
+        O = torch.empty(nbw * Nq, Cn, device=dev, dtype=torch.float32)
+        bgemm(P, kvs, O, Nq, hd, Nk, (Nk, 1), (ldk, 1), (Cn, 1), b_off=v_off, nb=nbh, sab=(heads * Nq * Nk, Nq * Nk), sbb=(Nk * ldk, hd), scb=(Nq * Cn, hd))
+        ctx.save_for_backward(qs, kvs, P, rpi, table)
+        ctx.meta = meta
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qs, kvs, P, rpi, table = ctx.saved_tensors
+        heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = ctx.meta
+        dO = _chk(dO)
+        hd = Cn // heads
+        ldq, ldk = qs.shape[-1], kvs.shape[-1]
+        nbw = qs.numel() // ldq // Nq
+        nbh = (nbw, heads)
+        sP = (heads * Nq * Nk, Nq * Nk)
+        dev = dO.device
+        # columns outside the q / k / v slices receive no gradient: zero-filled unless the three slices tile the packed tensor
+        dq = torch.empty_like(qs) if (same and ldq == 3 * Cn) else torch.zeros_like(qs)
+        dkv = dq if same else torch.zeros_like(kvs)
+        # dP = dO v^T
+        dP = torch.empty_like(P)
+        bgemm(dO, kvs, dP, Nq, Nk, hd, (Cn, 1), (1, ldk), (Nk, 1), b_off=v_off, nb=nbh, sab=(Nq * Cn, hd), sbb=(Nk * ldk, hd), scb=sP)
+        # dv = P^T dO
+        bgemm(P, dO, dkv, Nk, hd, Nq, (1, Nk), (Cn, 1), (ldk, 1), c_off=v_off, nb=nbh, sab=sP, sbb=(Nq * Cn, hd), scb=(Nk * ldk, hd))
+        # dS = P * (dP - rowsum(dP * P))
+        L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), nbw * heads * Nq, Nk, _st()), "sr_softmax_bwd")
+        dtable = None
+        if ctx.needs_input_grad[2]:
+            dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
+            L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
+            dtable = torch.zeros_like(table)
+            L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
+        # dq = scale * dS k ; dk = scale * dS^T q
+        bgemm(dP, kvs, dq, Nq, hd, Nk, (Nk, 1), (ldk, 1), (ldq, 1), b_off=k_off, c_off=q_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nk * ldk, hd), scb=(Nq * ldq, hd))
+        bgemm(dP, qs, dkv, Nk, hd, Nq, (1, Nk), (ldq, 1), (ldk, 1), b_off=q_off, c_off=k_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nq * ldq, hd), scb=(Nk * ldk, hd))
+        return dq, (None if same else dkv), dtable, None, None, None
+
+
+def window_attention_packed(qkv: Tensor, table: Tensor, rpi: Tensor, mask: Optional[Tensor], heads: int, N: int, Cn: int) -> Tensor:
+    """qkv [nbw*N, 3C] window-order tokens -> attention output [nbw*N, C] (heads concatenated, swinir.py:102)."""
+    hd = Cn // heads
+    return _Attention.apply(qkv, None, table, rpi, mask, (heads, N, N, Cn, hd ** -0.5, 0, Cn, 2 * Cn, True))
+
+
+def cross_window_attention(q_win: Tensor, kv_win: Tensor, table: Tensor, rpi: Tensor, heads: int, Nq: int, Nk: int, Cn: int) -> Tensor:
+    """OCAB (hat.py:266-283): q = columns [0, C) of q_win [nbw*Nq, 3C] (window-partitioned qkv), k / v = columns [C, 2C) / [2C, 3C) of
+    kv_win [nbw*Nk, 3C] (unfolded qkv)."""
+    hd = Cn // heads
+    return _Attention.apply(q_win, kv_win, table, rpi, None, (heads, Nq, Nk, Cn, hd ** -0.5, 0, Cn, 2 * Cn, False))
+
+
+# --------------------------------------------------------------------------- channel attention pieces
+class _AvgPool(Fn):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, H, W, Cn = x.shape
+        ctx.shape = tuple(x.shape)
+        return colsum(x, torch.zeros(B, Cn, device=x.device), B, H * W, Cn, 1.0 / (H * W))
+
+    @staticmethod
+    def backward(ctx, d):
+        B, H, W, Cn = ctx.shape
+        out = torch.empty(B, H, W, Cn, device=d.device, dtype=torch.float32)
+        return eltwise(L.EW_BCAST_BC, None, out, s=_chk(d), inner=H * W * Cn, Cn=Cn, a=1.0 / (H * W))
+
+
+def avg_pool(x: Tensor) -> Tensor:
+    """nn.AdaptiveAvgPool2d(1) on NHWC -> [B, C] (common.py:160, hat.py:31)."""
+    return _AvgPool.apply(x)
+
+
+class _MulBC(Fn):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _chk(x), _chk(s)
+        ctx.save_for_backward(x, s)
+        B, H, W, Cn = x.shape
+        return eltwise(L.EW_MUL_BC, x, torch.empty_like(x), s=s, inner=H * W * Cn, Cn=Cn)
+
+    @staticmethod
+    def backward(ctx, d):
+        x, s = ctx.saved_tensors
+        d = _chk(d)
+        B, H, W, Cn = x.shape
+        dx = eltwise(L.EW_MUL_BC, d, torch.empty_like(d), s=s, inner=H * W * Cn, Cn=Cn)
+        prod = eltwise(L.EW_MUL, d, torch.empty_like(d), y=x)
+        ds = colsum(prod, torch.zeros(B, Cn, device=d.device), B, H * W, Cn)
+        return dx, ds
+
+
+def mul_bc(x: Tensor, s: Tensor) -> Tensor:
+    """x [B,H,W,C] * s [B,C] (the channel-attention gate, common.py:169-170, hat.py:38-39)."""
+    return _MulBC.apply(x, s)
+
+
+def channel_attention(y: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """y * sigmoid(conv1x1(relu(conv1x1(avgpool(y))))) (common.py:156-170; hat.py:25-39)."""
+    s = sigmoid(linear(relu(linear(avg_pool(y), w1, b1)), w2, b2))
+    return mul_bc(y, s)
+
+
+# --------------------------------------------------------------------------- model output
+class _NhwcOut(Fn):
+    @staticmethod
+    def forward(ctx, y, scale, shift, Ho, Wo):
+        y = _chk(y)
+        B, Hs, Ws, Cn = y.shape
+        out = torch.empty(B, Cn, Ho, Wo, device=y.device, dtype=torch.float32)
+        L.check(L.lib().sr_nhwc_out(y.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, Hs, Ws, Cn, Ho, Wo, 1, _st()), "sr_nhwc_out")
+        ctx.save_for_backward(scale, shift)
+        ctx.shape = (B, Hs, Ws, Cn, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        scale, shift = ctx.saved_tensors
+        B, Hs, Ws, Cn, Ho, Wo = ctx.shape
+        d = _chk(d)
+        dy = torch.empty(B, Hs, Ws, Cn, device=d.device, dtype=torch.float32)
+        L.check(L.lib().sr_nhwc_out(d.data_ptr(), dy.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, Hs, Ws, Cn, Ho, Wo, 0, _st()), "sr_nhwc_out")
+        return dy, None, None, None, None
+
+
+def nhwc_out(y: Tensor, scale: Tensor, shift: Tensor, Ho: int, Wo: int) -> Tensor:
+    """NHWC features -> the model's NCHW output: y * scale[c] + shift[c], cropped to [Ho, Wo] (common.py:232-233, swinir.py:372)."""
+    return _NhwcOut.apply(y, scale, shift, Ho, Wo)
+
+
+# --------------------------------------------------------------------------- host-side index logic
+_MASKS = {}
+
+
+def shift_mask(H: int, W: int, ws: int, shift: int, device) -> Tensor:
+    """calculate_mask (common.py:250-274): [nW, N, N] with -100 where the two tokens of a window carry different region labels."""
+    key = (H, W, ws, shift, str(device))
+    m = _MASKS.get(key)
+    if m is None:
+        img = torch.zeros(H, W)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        win = img.reshape(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+        diff = win[:, None, :] - win[:, :, None]
+        m = torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff)).contiguous().to(device)
+        _MASKS[key] = m
+    return m

@@ -107,12 +107,21 @@ class Model(nn.Module):
             raise RuntimeError(f"input is on {x.device} but the model parameters are on {pdev}")
         if x.dim() != 4 or x.shape[1] != self.n_colors:
             raise RuntimeError(f"expected input [B,{self.n_colors},H,W], got {tuple(x.shape)}")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            raise NotImplementedError(
-                "studiosr_amd round 1 implements the inference forward only; call under torch.no_grad()/inference_mode() "
-                "(training backward is row (f)3 of SURVEY.md section 8)."
-            )
         return x.detach().to(torch.float32).contiguous()
+
+    def _train_forward(self, x: Tensor) -> Optional[Tensor]:
+        """The differentiable path (studiosr_amd/models/train.py: a graph of HIP forward / backward ops) whenever autograd is recording
+        -- in train() AND eval() mode, so gradients never silently vanish -- and whenever DropPath is active (train() with
+        drop_path_rate > 0, swinir.py:137,171-172 / hat.py:148,192-193), also under no_grad.  None = take the inference path."""
+        recording = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        stochastic = self.training and getattr(self, "drop_path_rate", 0.0) > 0.0
+        if not (recording or stochastic):
+            return None
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("the HIP training path provides parameter gradients only (the reference Trainer never differentiates w.r.t. the LR image)")
+        from . import train
+
+        return train.FORWARDS[type(self).__name__](self, self._check_input(x))
 
     # ------------------------------------------------------------------ reference API
     def _io_scale(self) -> float:

@@ -305,6 +305,9 @@ class HAT(Model):
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor) -> Tensor:
+        y = self._train_forward(x)
+        if y is not None:
+            return y
         x = self._check_input(x)
         cdt = compute_dtype(self.precision)
         P = self._get_packed(cdt)

@@ -1,0 +1,197 @@
+"""Differentiable forwards (the training path): the same modules / parameters as the inference drivers, executed as a graph of
+studiosr_amd.autograd ops so that `loss.backward()` reaches every parameter through HIP backward kernels.
+
+Each function restates one reference forward on NHWC / token-major fp32 tensors and cites it:
+  SwinIR  studiosr/models/swinir.py:146-174 (block), :245-246 (RSTB), :342-372 (model)
+  HAT     studiosr/models/hat.py:153-195 (HAB), :239-293 (OCAB), :385 (RHAG), :519-554 (model)
+  EDSR    studiosr/models/edsr.py:39-48, ResBlock common.py:150-153
+  RCAN    studiosr/models/rcan.py:21-24,33-36,68-77
+Used whenever autograd is recording (Model.forward dispatches here), in train() and in eval() mode alike; DropPath follows the
+module's `training` flag exactly as timm's does.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from .. import _lib as L
+from .. import autograd as A
+from .. import ops
+
+Tensor = torch.Tensor
+RGB_MEAN = (0.4488, 0.4371, 0.4040)
+
+
+def _ingest(x: Tensor, Hp: int, Wp: int, pad_mode: int, scale: Tensor, bias: Tensor) -> Tensor:
+    """NCHW image -> normalised, padded NHWC image in a 32-channel buffer (channels 3.. are zero); no gradient flows to the image."""
+    B = x.shape[0]
+    xin = torch.empty(B, Hp, Wp, 32, device=x.device, dtype=torch.float32)
+    ops.ingest_nchw(x.detach().to(torch.float32).contiguous(), xin, pad_mode, scale, bias)
+    return xin
+
+
+def _affines(img_range: float, n_colors: int, device):
+    mean = torch.tensor(RGB_MEAN[:n_colors], dtype=torch.float32, device=device)
+    ing = (torch.full((n_colors,), 1.0 / float(img_range), dtype=torch.float32, device=device), (-mean).contiguous())  # x / range - mean
+    fin = (torch.full((n_colors,), float(img_range), dtype=torch.float32, device=device), (mean * img_range).contiguous())  # (x + mean) * range
+    return ing, fin
+
+
+def _conv(x: Tensor, m: torch.nn.Conv2d, cin=None) -> Tensor:
+    return A.conv3x3(x, m.weight, m.bias, cin)
+
+
+def _upsampler(up, x: Tensor) -> Tensor:
+    """conv -> PixelShuffle stages (common.py:124-137)."""
+    for idx, r, _ in up.stages:
+        x = A.pixel_shuffle(_conv(x, up[idx]), r)
+    return x
+
+
+def _mlp(mlp, x: Tensor) -> Tensor:
+    return A.linear(A.gelu(A.linear(x, mlp.fc1.weight, mlp.fc1.bias)), mlp.fc2.weight, mlp.fc2.bias)
+
+
+def _check_dropout(model) -> None:
+    if model.training and (getattr(model, "drop_rate", 0.0) > 0.0 or getattr(model, "attn_drop_rate", 0.0) > 0.0):
+        raise NotImplementedError("drop_rate / attn_drop_rate > 0 (nn.Dropout inside attention / MLP) is not part of the HIP training path; the reference defaults are 0")
+
+
+def _drop_rates(model) -> List[float]:
+    n = sum(model.depths)
+    return [float(v) for v in torch.linspace(0, model.drop_path_rate, n)] if n else []  # swinir.py:296, hat.py:440
+
+
+# --------------------------------------------------------------------------- SwinIR
+def _window_msa(attn, t: Tensor, ws: int, shift: int, heads: int, rpi: Tensor) -> Tensor:
+    B, H, W, Cn = t.shape
+    win = A.window_partition(t, ws, shift)
+    qkv = A.linear(win, attn.qkv.weight, attn.qkv.bias)
+    mask = A.shift_mask(H, W, ws, shift, t.device) if shift > 0 else None  # the reference adds an all-zero mask when shift == 0
+    o = A.window_attention_packed(qkv, attn.relative_position_bias_table, rpi, mask, heads, ws * ws, Cn)
+    return A.window_reverse(A.linear(o, attn.proj.weight, attn.proj.bias), ws, shift, t.shape)
+
+
+def swinir_forward(model, x: Tensor) -> Tensor:
+    _check_dropout(model)
+    B, _, H, W = x.shape
+    ws, s = model.window_size, model.scale
+    if model.training:  # check_image_size: reflect pad to the next multiple (swinir.py:356, common.py:277-282)
+        Hp, Wp = H + (ws - H % ws) % ws, W + (ws - W % ws) % ws
+        pad_mode = L.PAD_REFLECT if (Hp != H or Wp != W) else L.PAD_NONE
+        if Hp - H >= H or Wp - W >= W:
+            raise RuntimeError("Padding size should be less than the corresponding input dimension (reflect pad)")
+    else:  # check_image_size_for_eval (swinir.py:249-255)
+        Hp, Wp, pad_mode = (H // ws + 1) * ws, (W // ws + 1) * ws, L.PAD_EVAL_MIRROR
+    ing, fin = _affines(model.img_range, model.n_colors, x.device)
+    first = _conv(_ingest(x, Hp, Wp, pad_mode, *ing), model.conv_first, cin=model.n_colors)
+    t = A.layer_norm(first, model.patch_embed.norm.weight, model.patch_embed.norm.bias)
+    dpr = _drop_rates(model)
+    k = 0
+    for li, layer in enumerate(model.layers):
+        tin = t
+        heads = model.num_heads[li]
+        for blk in layer.residual_group.blocks:
+            a = _window_msa(blk.attn, A.layer_norm(t, blk.norm1.weight, blk.norm1.bias), ws, blk.shift_size, heads, blk.attn.relative_position_index)
+            t = A.add(t, A.drop_path(a, dpr[k], model.training))
+            m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
+            t = A.add(t, A.drop_path(m, dpr[k], model.training))
+            k += 1
+        t = A.add(_conv(t, layer.conv), tin)  # swinir.py:245-246
+    t = A.layer_norm(t, model.norm.weight, model.norm.bias)
+    body = A.add(_conv(t, model.conv_after_body), first)
+    if model.upsampler == "pixelshuffle":
+        f = A.leaky_relu(_conv(body, model.conv_before_upsample[0]), 0.01)
+        y = _conv(_upsampler(model.upsample, f), model.conv_last)
+    else:  # pixelshuffledirect (swinir.py:367-369)
+        y = _upsampler(model.upsample, body)
+    return A.nhwc_out(y, *fin, H * s, W * s)
+
+
+# --------------------------------------------------------------------------- HAT
+def _cab(cab, x: Tensor) -> Tensor:
+    seq = cab.cab
+    y = _conv(A.gelu(_conv(x, seq[0])), seq[2])
+    att = seq[3].attention
+    return A.channel_attention(y, att[1].weight, att[1].bias, att[3].weight, att[3].bias)
+
+
+def hat_forward(model, x: Tensor) -> Tensor:
+    _check_dropout(model)
+    B, _, H, W = x.shape
+    ws, s, Cn = model.window_size, model.scale, model.embed_dim
+    Hp, Wp = H + (ws - H % ws) % ws, W + (ws - W % ws) % ws  # check_image_size: reflect pad (hat.py:544)
+    if Hp - H >= H or Wp - W >= W:
+        raise RuntimeError("Padding size should be less than the corresponding input dimension (reflect pad)")
+    ing, fin = _affines(model.img_range, model.n_colors, x.device)
+    first = _conv(_ingest(x, Hp, Wp, L.PAD_REFLECT if (Hp != H or Wp != W) else L.PAD_NONE, *ing), model.conv_first, cin=model.n_colors)
+    t = A.layer_norm(first, model.patch_embed.norm.weight, model.patch_embed.norm.bias)
+    dpr = _drop_rates(model)
+    rpi_sa, rpi_oca = model.relative_position_index_SA, model.relative_position_index_OCA
+    k = 0
+    for li, layer in enumerate(model.layers):
+        tin = t
+        heads = model.num_heads[li]
+        grp = layer.residual_group
+        for blk in grp.blocks:  # HAB (hat.py:153-195)
+            n1 = A.layer_norm(t, blk.norm1.weight, blk.norm1.bias)
+            conv_x = _cab(blk.conv_block, n1)
+            a = _window_msa(blk.attn, n1, ws, blk.shift_size, heads, rpi_sa)
+            t = A.add(A.add(t, A.drop_path(a, dpr[k], model.training)), conv_x, 1.0, blk.conv_scale)
+            m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
+            t = A.add(t, A.drop_path(m, dpr[k], model.training))
+            k += 1
+        oc = grp.overlap_attn  # OCAB (hat.py:239-293): no DropPath
+        wse = oc.overlap_win_size
+        qkv = A.linear(A.layer_norm(t, oc.norm1.weight, oc.norm1.bias), oc.qkv.weight, oc.qkv.bias)  # [B,H,W,3C]
+        o = A.cross_window_attention(A.window_partition(qkv, ws, 0), A.oca_unfold(qkv, ws, wse), oc.relative_position_bias_table, rpi_oca, heads, ws * ws, wse * wse, Cn)
+        t = A.add(A.linear(A.window_reverse(o, ws, 0, t.shape), oc.proj.weight, oc.proj.bias), t)
+        t = A.add(t, _mlp(oc.mlp, A.layer_norm(t, oc.norm2.weight, oc.norm2.bias)))
+        t = A.add(_conv(t, layer.conv), tin)  # hat.py:385
+    t = A.layer_norm(t, model.norm.weight, model.norm.bias)
+    body = A.add(_conv(t, model.conv_after_body), first)
+    f = A.leaky_relu(_conv(body, model.conv_before_upsample[0]), 0.01)
+    y = _conv(_upsampler(model.upsample, f), model.conv_last)
+    return A.nhwc_out(y, *fin, H * s, W * s)
+
+
+# --------------------------------------------------------------------------- EDSR / RCAN
+def _mean_shift(ms):
+    w = ms.weight.detach().reshape(3, 3)
+    return torch.diagonal(w).to(torch.float32).contiguous(), ms.bias.detach().to(torch.float32).contiguous()
+
+
+def edsr_forward(model, x: Tensor) -> Tensor:
+    B, _, H, W = x.shape
+    s = model.scale
+    h = _conv(_ingest(x, H, W, L.PAD_NONE, *_mean_shift(model.sub_mean)), model.head[0], cin=model.n_colors)
+    r = h
+    for i in range(model.n_resblocks):  # ResBlock: body(x) * res_scale + x (common.py:150-153)
+        rb = model.body[i]
+        r = A.add(_conv(A.relu(_conv(r, rb.body[0])), rb.body[2]), r, rb.res_scale, 1.0)
+    r = A.add(_conv(r, model.body[model.n_resblocks]), h)
+    y = _conv(_upsampler(model.tail[0], r), model.tail[1])
+    return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
+
+
+def rcan_forward(model, x: Tensor) -> Tensor:
+    B, _, H, W = x.shape
+    s = model.scale
+    h = _conv(_ingest(x, H, W, L.PAD_NONE, *_mean_shift(model.sub_mean)), model.head[0], cin=model.n_colors)
+    g = h
+    for gi in range(model.n_resgroups):
+        grp = model.body[gi]
+        r = g
+        for bi in range(model.n_resblocks):  # RCAB (rcan.py:21-24)
+            b = grp.body[bi].body
+            du = b[3].conv_du
+            y = _conv(A.relu(_conv(r, b[0])), b[2])
+            r = A.add(A.channel_attention(y, du[0].weight, du[0].bias, du[2].weight, du[2].bias), r)
+        g = A.add(_conv(r, grp.body[model.n_resblocks]), g)  # rcan.py:33-36
+    r = A.add(_conv(g, model.body[model.n_resgroups]), h)
+    y = _conv(_upsampler(model.tail[0], r), model.tail[1])
+    return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
+
+
+FORWARDS = {"SwinIR": swinir_forward, "HAT": hat_forward, "EDSR": edsr_forward, "RCAN": rcan_forward}

@@ -266,7 +266,42 @@ def main() -> None:
         y=MT.to_y(a),
     )
     del rc
+    grads(M)
+
+
+def grads(M) -> None:
+    """F15: one training step's gradients of reduced models under the reference Trainer's loss (trainer.py:97-109: train mode,
+    forward, L1 loss, backward; DropPath off so the vectors are deterministic).  Every parameter gradient is stored."""
+    import torch.nn.functional as F
+
+    cases = [
+        ("swinir", M.SwinIR, dict(scale=2, embed_dim=60, depths=[2, 2], num_heads=[6, 6], drop_path_rate=0.0), (2, 13, 17), 70),
+        ("swinir_direct", M.SwinIR, dict(scale=3, embed_dim=60, depths=[2], num_heads=[6], upsampler="pixelshuffledirect", drop_path_rate=0.0), (1, 16, 16), 71),
+        ("hat", M.HAT, dict(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=8, drop_path_rate=0.0), (2, 16, 24), 72),
+        ("edsr", M.EDSR, dict(scale=4, n_feats=32, n_resblocks=2), (2, 12, 10), 73),
+        ("rcan", M.RCAN, dict(scale=3, n_feats=32, n_resblocks=2, n_resgroups=2, reduction=8), (2, 9, 12), 74),
+    ]
+    for tag, ctor, cfg, (b, h, w), seed in cases:
+        model = ctor(**cfg)
+        randomize(model, seed)
+        model.train()
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(b, 3, h, w, generator=g)
+        sc = cfg["scale"]
+        tgt = torch.rand(b, 3, h * sc, w * sc, generator=g)
+        out = model(x)
+        loss = F.l1_loss(out, tgt)
+        loss.backward()
+        arrs = {"cfg": np.array(json.dumps(model.get_model_config())), "x": x.numpy(), "target": tgt.numpy(), "out": out.detach().numpy(), "loss": np.float64(loss.item())}
+        arrs.update(sd_arrays(model))
+        for n_, p_ in model.named_parameters():
+            if p_.grad is not None:
+                arrs["grad/" + n_] = p_.grad.numpy()
+        save(f"f15_grads_{tag}", **arrs)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--grads-only":
+        grads(import_reference()[0])
+    else:
+        main()

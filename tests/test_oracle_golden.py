@@ -171,3 +171,27 @@ def test_psnr_metric():
     assert OM.compute_psnr(z, o) == 0.0
     assert np.isinf(OM.compute_psnr(a, a.copy()))
     assert abs(OM.compute_psnr(a, b) - OM.compute_psnr(a / 255.0, b / 255.0)) < 1e-12
+
+
+@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN")])
+def test_oracle_autograd_matches_reference_gradients(tag, kind):
+    """f15: gradients of one L1 training step produced by the reference (generate.py grads()).  torch autograd through the oracle's
+    forward must reproduce them: this pins the oracle as a gradient reference for geometries without a fixture."""
+    import torch.nn.functional as F
+
+    from oracle import models as OM
+
+    g = load_golden(f"f15_grads_{tag}")
+    cfg, sd = golden_cfg(g), golden_sd(g)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "mean" not in k else v) for k, v in sd.items()}
+    out = OM.FORWARDS[kind](sdg, torch.from_numpy(g["x"]), cfg, training=True)
+    assert float((out.detach() - torch.from_numpy(g["out"])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["out"]).max()))
+    F.l1_loss(out, torch.from_numpy(g["target"])).backward()
+    n = 0
+    for k, v in g.items():
+        if k.startswith("grad/"):
+            got, ref = sdg[k[5:]].grad, torch.from_numpy(v)
+            assert got is not None, k
+            assert float((got - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-6), k
+            n += 1
+    assert n > 10

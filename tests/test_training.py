@@ -1,0 +1,212 @@
+"""GPU tests of the training path (BASELINE config 5): forward AND backward run on the HIP
+training engine through the C ABI (studiosr_amd/autograd.py -> sr_bgemm & co).
+
+Gradient parity: (1) against gradients produced by the REFERENCE itself (tests/golden/f15_grads_*.npz, written by
+tests/golden/generate.py: train mode, L1 loss, backward -- studiosr/engine/trainer.py:97-109), every parameter; (2) against torch
+autograd through the CPU oracle for geometries the fixtures do not hold (HAT window 16 / 576-key OCA).  Tolerance: fp32 with
+different summation order -> 3e-4 of the largest gradient entry of the tensor (weight gradients sum over up to 10^4 tokens)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden_cfg, golden_sd, load_golden
+
+pytestmark = pytest.mark.gpu
+
+import studiosr_amd as S  # noqa: E402
+from oracle import models as OM  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRAD_TOL = 3e-4
+
+
+def _grad_check(model, ref_grads, tol=GRAD_TOL):
+    n = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, name
+            continue
+        assert name in ref_grads, f"reference produced no gradient for {name}"
+        assert p.grad is not None, f"no gradient for {name}"
+        g, r = p.grad.detach().cpu(), ref_grads[name]
+        assert g.shape == r.shape, name
+        scale = float(r.abs().max())
+        err = float((g - r).abs().max())
+        assert err <= tol * max(scale, 1e-6), f"{name}: max|dg|={err:.3e} scale={scale:.3e}"
+        n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN")])
+def test_gradients_against_the_reference(tag, kind):
+    g = load_golden(f"f15_grads_{tag}")
+    cfg, sd = golden_cfg(g), golden_sd(g)
+    m = getattr(S, kind)(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    x, tgt = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    out = m(x)
+    assert out.requires_grad and out.dtype == torch.float32
+    ref_out = torch.from_numpy(g["out"])
+    assert float((out.detach().cpu() - ref_out).abs().max()) <= 2e-5 * max(1.0, float(ref_out.abs().max()))
+    loss = F.l1_loss(out, tgt)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * max(1.0, float(g["loss"]))
+    loss.backward()
+    _grad_check(m, {k[len("grad/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("grad/")})
+
+
+def _oracle_grads(fwd, sd, x, tgt, cfg, training):
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "mean" not in k else v) for k, v in sd.items()}
+    out = fwd(sdg, x, cfg, training=training)
+    F.l1_loss(out, tgt).backward()
+    return out.detach(), {k: v.grad for k, v in sdg.items() if v.is_floating_point() and v.grad is not None}
+
+
+def test_hat_window16_gradients_against_oracle_autograd():
+    """HAT with window 16 (256-token windows, 24x24 = 576-key overlapping cross attention with wrapped negative bias indices,
+    shift mask) on a 2 x 3 window image: torch autograd through the CPU oracle is the reference."""
+    torch.manual_seed(3)
+    m = S.HAT(scale=2, embed_dim=48, depths=[2], num_heads=[4], window_size=16, squeeze_factor=12, drop_path_rate=0.0)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+            elif n_.endswith("relative_position_bias_table"):
+                p_.copy_(torch.randn_like(p_) * 0.5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, tgt = torch.rand(1, 3, 30, 44), torch.rand(1, 3, 60, 88)  # reflect-padded to 32 x 48
+    ref_out, ref = _oracle_grads(OM.hat_forward, sd, x, tgt, m.get_model_config(), True)
+    m = m.to(DEV).train()
+    out = m(x.to(DEV))
+    assert float((out.detach().cpu() - ref_out).abs().max()) <= 2e-5 * max(1.0, float(ref_out.abs().max()))
+    F.l1_loss(out, tgt.to(DEV)).backward()
+    _grad_check(m, ref)
+
+
+def test_eval_mode_with_grad_enabled_is_differentiable_and_uses_eval_padding():
+    """in eval() with autograd recording the forward must not silently drop the graph.  SwinIR's eval padding (64 -> 72
+    style mirror pad, swinir.py:249-255) applies; values equal the inference path."""
+    g = load_golden("f11_swinir_x2")
+    m = S.SwinIR(**golden_cfg(g))
+    m.load_state_dict(golden_sd(g))
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(g["x_2_12_12"]).to(DEV)
+    y = m(x)
+    assert y.requires_grad
+    ref = torch.from_numpy(g["y_eval_2_12_12"])
+    assert float((y.detach().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    y.mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.requires_grad)
+    with pytest.raises(NotImplementedError):
+        m(x.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize("kind,kw", [("SwinIR", {}), ("HAT", dict(window_size=8)), ("EDSR", dict(n_feats=32, n_resblocks=2)), ("RCAN", dict(n_feats=32, n_resblocks=2, n_resgroups=2))])
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_reference_train_mode_shape_tests_pass(kind, kw, scale):
+    """The reference's own model tests (tests/models/test_{swinir,hat,edsr,rcan}.py): freshly constructed model, train mode, autograd
+    on, 8x8 and 12x12 inputs -> [B, 3, H*scale, W*scale]; here additionally backward must produce finite gradients everywhere."""
+    torch.manual_seed(0)
+    if kind in ("SwinIR", "HAT"):
+        kw = dict(kw, embed_dim=60, depths=[2, 2], num_heads=[6, 6])  # default drop_path_rate = 0.1: DropPath is live
+    m = getattr(S, kind)(scale=scale, **kw).to(DEV)
+    assert m.training
+    for size in (8, 12):
+        y = m(torch.rand(2, 3, size, size, device=DEV))
+        assert y.shape == (2, 3, size * scale, size * scale)
+    y.abs().mean().backward()
+    for n_, p_ in m.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n_
+
+
+def test_drop_path_semantics():
+    """timm DropPath (swinir.py:137,171-172): identity in eval; in train() a block whose rate is 1.0 contributes nothing (keep = 0:
+    all-zero mask, no rescale), so the output equals the same model with that block's branches zeroed; rate 0 < p < 1 is random."""
+    torch.manual_seed(1)
+    cfg = dict(scale=2, embed_dim=60, depths=[2], num_heads=[6])
+    m = S.SwinIR(drop_path_rate=1.0, **cfg).to(DEV).train()  # rates linspace(0, 1, 2) = [0, 1]
+    x = torch.rand(3, 3, 16, 16, device=DEV)
+    with torch.no_grad():
+        y = m(x)
+        assert torch.equal(m(x), y)  # keep probability 0 or 1 everywhere: deterministic
+        ref = S.SwinIR(drop_path_rate=0.0, **cfg).to(DEV).train()
+        ref.load_state_dict(m.state_dict())
+        blk = ref.layers[0].residual_group.blocks[1]
+        for lin in (blk.attn.proj, blk.mlp.fc2):
+            lin.weight.zero_()
+            lin.bias.zero_()
+        assert float((ref(x) - y).abs().max()) <= 1e-6
+        m2 = S.SwinIR(drop_path_rate=0.5, **cfg).to(DEV).train()
+        m2.load_state_dict(m.state_dict())
+        outs = torch.stack([m2(x) for _ in range(6)])
+        assert float((outs - outs[0]).abs().max()) > 0  # stochastic in train()
+        m2.eval()
+        assert torch.equal(m2(x), m2(x))  # identity (deterministic) in eval()
+
+
+def test_trainer_shaped_loop_on_default_hat():
+    """BASELINE configs[4] on one rank: the reference Trainer's step (trainer.py:97-109) -- train(), autocast(bf16) context, forward,
+    L1 loss, zero_grad, backward, Adam(2e-4, betas (0.9, 0.99)) step -- on the DEFAULT HAT x4 (embed 180, 6 x (6 HAB + OCAB), window 16,
+    DropPath 0.1), per-rank batch 4 of 64x64 LR patches.  The loss on a fixed batch must fall."""
+    torch.manual_seed(0)
+    m = S.HAT(scale=4).to(DEV).train()
+    cfg = m.get_training_config()
+    opt = torch.optim.Adam(m.parameters(), lr=cfg.get("learning_rate", 2e-4), betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.99)))
+    lr_img, hr_img = torch.rand(4, 3, 64, 64, device=DEV), torch.rand(4, 3, 256, 256, device=DEV)
+    losses = []
+    for _ in range(3):
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            out = m(lr_img)
+            loss = F.l1_loss(out, hr_img)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert out.shape == (4, 3, 256, 256) and all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
+
+
+def test_ddp_two_ranks_gloo_average_equals_single_process_mean(tmp_path):
+    """trainer.py:89-91: the model wrapped in DistributedDataParallel.  Two ranks (both on this GPU, gloo) see different halves of a
+    batch; DDP's averaged gradients must equal the mean of the two single-process gradients."""
+    script = tmp_path / "ddp.py"
+    script.write_text(f"""
+import os, sys, torch, torch.distributed as dist, torch.nn.functional as F
+sys.path.insert(0, {ROOT!r})
+import studiosr_amd as S
+from torch.nn.parallel import DistributedDataParallel as DDP
+rank = int(os.environ["RANK"]); dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+torch.manual_seed(0)
+m = S.SwinIR(scale=2, embed_dim=60, depths=[2], num_heads=[6], drop_path_rate=0.0).to(dev).train()
+g = torch.Generator().manual_seed(5)
+x, t = torch.rand(4, 3, 16, 16, generator=g).to(dev), torch.rand(4, 3, 32, 32, generator=g).to(dev)
+single = []
+for r in range(2):
+    m.zero_grad()
+    F.l1_loss(m(x[2 * r: 2 * r + 2]), t[2 * r: 2 * r + 2]).backward()
+    single.append([p.grad.clone() for p in m.parameters()])
+m.zero_grad()
+ddp = DDP(m, device_ids=[0])
+F.l1_loss(ddp(x[2 * rank: 2 * rank + 2]), t[2 * rank: 2 * rank + 2]).backward()
+worst = 0.0
+for p, a, b in zip(m.parameters(), *single):
+    ref = (a + b) / 2
+    worst = max(worst, float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-9))
+assert worst < 1e-5, worst
+dist.barrier(); dist.destroy_process_group(); print("DDP_OK", worst)
+""")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29623", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.count("DDP_OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]
