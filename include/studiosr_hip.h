@@ -298,6 +298,29 @@ int sr_pixel_shuffle_nhwc(const float* src, float* dst, int B, int H, int W, int
 int sr_bias_gather(const float* table, const long long* rpi, float* bias, float* dtable, int T, int heads, long long NN, int forward, void* stream);
 int sr_nhwc_out(const float* src, float* dst, const float* scale, const float* shift, int B, int Hs, int Ws, int C, int Ho, int Wo, int forward, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One-time weight layout transforms, device side, enqueue-only (what studiosr_amd/packing.py does on the host; bit-identical).
+ * A host in any language turns reference checkpoint tensors (fp32, state_dict layouts) into the packed operands above:
+ *   sr_pack_matrix          nn.Linear weight [n_rows, n_cols] (row stride ld) -> fragments of out_dtype.  Padded row n takes
+ *                           source row row_idx[n] (-1 = zero row; NULL = identity up to n_rows), padded column k takes col_idx[k].
+ *                           row_scale[N_p] (attention scale hd^-0.5 on the q rows, swinir.py:83) and col_scale[n_cols]
+ *                           (LayerNorm gamma when the affine is folded into the Linear) are optional single multiplies.
+ *                           The qkv row order is part*heads*hd_p + head*hd_p + d; proj / fc use identity maps with zero pads.
+ *   sr_pack_conv3x3         nn.Conv2d weight [Cout, Cin, 3, 3] -> fragments with k = (ky*3 + kx)*cin_p + c; row_idx as above
+ *                           (a conv feeding nn.PixelShuffle(r) uses packed row (i*r + j)*cps_p + c <- channel c*r*r + i*r + j,
+ *                           common.py:129,133,136).
+ *   sr_pack_vector          bias / LayerNorm vector -> zero-padded fp32 [n_p] through the same index map (+ optional scale).
+ *   sr_pack_bias_fragments  relative_position_bias_table [T, heads] gathered through rpi [Nq*Nk] (int64, negative indices wrap as
+ *                           the reference's python indexing does: hat.py:494-517) into accumulator-fragment order
+ *                           [heads][Nq/16][Nk/16][lane][4] for sr_swin_attn_fused / sr_window_attention / sr_oca_attention.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int sr_pack_matrix(const float* w, long long ld, const int* row_idx, const int* col_idx, const float* row_scale, const float* col_scale, void* out, int out_dtype,
+                   int N_p, int K_p, int n_rows, int n_cols, void* stream);
+int sr_pack_conv3x3(const float* w, const int* row_idx, void* out, int out_dtype, int N_p, int Cout, int Cin, int cin_p, void* stream);
+int sr_pack_vector(const float* b, const int* idx, const float* scale, float* out, int n_p, int n, void* stream);
+int sr_pack_bias_fragments(const float* table, const long long* rpi, float* out, int T, int heads, int Nq, int Nk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,11 @@ SYMBOLS = {
     "sr_pixel_shuffle_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sr_bias_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp]),
     "sr_nhwc_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    # device-side weight packing
+    "sr_pack_matrix": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sr_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sr_pack_vector": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sr_pack_bias_fragments": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -145,3 +145,42 @@ def nchw_to_u8(x: Tensor, mult: float) -> Tensor:
 
 def conv_pool_tiles(H: int, W: int, cout_p: int, compute_dtype: int) -> int:
     return L.lib().sr_conv3x3_pool_tiles(H, W, cout_p, compute_dtype)
+
+
+# --------------------------------------------------------------------------- device-side weight packing (sr_pack_*)
+def _ip(t: Optional[Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    return t.data_ptr()
+
+
+def pack_matrix(w: Tensor, n_p: int, k_p: int, dtype: torch.dtype, row_idx: Optional[Tensor] = None, col_idx: Optional[Tensor] = None,
+                row_scale: Optional[Tensor] = None, col_scale: Optional[Tensor] = None) -> Tensor:
+    """nn.Linear weight [rows, cols] fp32 -> MFMA fragments (the device twin of packing.pack_linear's matrix half)."""
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    out = torch.empty(n_p * k_p, dtype=dtype, device=w.device)
+    L.check(L.lib().sr_pack_matrix(_p(w) if w.is_contiguous() else w.data_ptr(), w.stride(0), _ip(row_idx), _ip(col_idx), _p(row_scale), _p(col_scale), out.data_ptr(), _dt(out),
+                                   n_p, k_p, w.shape[0], w.shape[1], _stream()), "sr_pack_matrix")
+    return out
+
+
+def pack_conv3x3(w: Tensor, cin_p: int, n_p: int, dtype: torch.dtype, row_idx: Optional[Tensor] = None) -> Tensor:
+    assert w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (3, 3) and w.is_contiguous()
+    out = torch.empty(n_p * 9 * cin_p, dtype=dtype, device=w.device)
+    L.check(L.lib().sr_pack_conv3x3(_p(w), _ip(row_idx), out.data_ptr(), _dt(out), n_p, w.shape[0], w.shape[1], cin_p, _stream()), "sr_pack_conv3x3")
+    return out
+
+
+def pack_vector(b: Optional[Tensor], n_p: int, idx: Optional[Tensor] = None, scale: Optional[Tensor] = None, device=None) -> Tensor:
+    out = torch.empty(n_p, dtype=torch.float32, device=b.device if b is not None else device)
+    L.check(L.lib().sr_pack_vector(_p(b), _ip(idx), _p(scale), out.data_ptr(), n_p, 0 if b is None else b.numel(), _stream()), "sr_pack_vector")
+    return out
+
+
+def pack_bias_fragments(table: Tensor, rpi: Tensor, n_q: int, n_k: int) -> Tensor:
+    assert table.dtype == torch.float32 and table.is_contiguous() and rpi.dtype == torch.int64 and rpi.is_contiguous() and rpi.numel() == n_q * n_k
+    heads = table.shape[1]
+    out = torch.empty(heads * n_q * n_k, dtype=torch.float32, device=table.device)
+    L.check(L.lib().sr_pack_bias_fragments(_p(table), rpi.data_ptr(), out.data_ptr(), table.shape[0], heads, n_q, n_k, _stream()), "sr_pack_bias_fragments")
+    return out

@@ -481,3 +481,51 @@ def test_errors_are_loud():
     hat = S.HAT(embed_dim=60, depths=[1], num_heads=[6], window_size=8).to(DEV).eval()
     with pytest.raises(RuntimeError):
         hat(torch.rand(1, 3, 3, 3, device=DEV))  # reflect pad larger than the image, as F.pad raises in the reference
+
+
+# ----------------------------------------------------------------------------- device-side weight packing (C ABI sr_pack_*)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_device_weight_packing_is_bit_identical_to_the_host_packing(dt):
+    """sr_pack_matrix / sr_pack_conv3x3 / sr_pack_vector / sr_pack_bias_fragments against studiosr_amd/packing.py: every element equal
+    (the host path writes its zero pads as value * 0, i.e. -0.0 under negative values; the kernels write +0.0 -- equal as numbers)."""
+    from studiosr_amd.models import hat as HATM
+
+    torch.manual_seed(0)
+    i32 = lambda t: t.to(torch.int32).to(DEV).contiguous()  # noqa: E731
+    C, Cp, heads, hd_p = 180, 192, 6, 32
+    hd = C // heads
+    # qkv Linear with the LayerNorm affine folded in, q rows scaled by hd^-0.5 (packing.pack_qkv + fold_layernorm)
+    w, b = (torch.randn(3 * C, C) * 0.1).to(DEV), torch.randn(3 * C).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(C)).to(DEV), (0.1 * torch.randn(C)).to(DEV)
+    fw, fb = packing.fold_layernorm(w, b, gamma, beta)
+    want_w, want_b = packing.pack_qkv(fw, fb, C, Cp, heads, hd_p, dt)
+    h_idx = packing.head_idx(heads, hd, hd_p)
+    rows = torch.cat([torch.where(h_idx >= 0, h_idx + p * C, h_idx) for p in range(3)])
+    scale = torch.ones(rows.numel())
+    scale[: heads * hd_p] = hd ** -0.5
+    got_w = ops.pack_matrix(w, rows.numel(), Cp, dt, row_idx=i32(rows), col_idx=i32(packing.identity_idx(C, Cp)), row_scale=scale.to(DEV), col_scale=gamma)
+    same = lambda a, b_: a.dtype == b_.dtype and a.shape == b_.shape and torch.equal(a.float(), b_.float())  # noqa: E731
+    assert same(got_w, want_w)
+    got_b = ops.pack_vector(fb, rows.numel(), idx=i32(rows), scale=scale.to(DEV))
+    assert torch.equal(got_b, want_b)
+    # proj: identity rows, head-padded columns; identity maps given as NULL
+    pw = (torch.randn(C, C) * 0.1).to(DEV)
+    want, _ = packing.pack_linear(pw, None, packing.identity_idx(C, Cp), packing.head_idx(heads, hd, hd_p), dt)
+    got = ops.pack_matrix(pw, Cp, heads * hd_p, dt, col_idx=i32(packing.head_idx(heads, hd, hd_p)))
+    assert same(got, want)
+    # 3x3 convs: identity rows and the PixelShuffle row permutation
+    cw, cb = (torch.randn(180, 60, 3, 3) * 0.1).to(DEV), torch.randn(180).to(DEV)
+    want, wb = packing.pack_conv3x3(cw, cb, 64, packing.identity_idx(180, 192), dt)
+    assert same(ops.pack_conv3x3(cw, 64, 192, dt), want)
+    assert torch.equal(ops.pack_vector(cb, 192), wb)
+    uw = (torch.randn(256, 64, 3, 3) * 0.1).to(DEV)
+    ps_rows = packing.pixel_shuffle_rows(64, 64, 2)
+    want, _ = packing.pack_conv3x3(uw, None, 64, ps_rows, dt)
+    assert same(ops.pack_conv3x3(uw, 64, ps_rows.numel(), dt, row_idx=i32(ps_rows)), want)
+    if dt == torch.float32:  # relative-position bias tables (fp32 only): SwinIR 64x64 and HAT's OCA 256x576 with wrapped negative indices
+        for ws, rpi in ((8, HATM.rpi_sa(8)), (16, HATM.rpi_oca(16, 0.5))):
+            nq, nk = rpi.shape
+            table = torch.randn(int(rpi.max() - min(int(rpi.min()), 0)) + 1 if rpi.min() >= 0 else (ws + ws + ws // 2 - 1) ** 2, heads).to(DEV)
+            want = packing.bias_fragments(packing.gather_bias(table, rpi.to(DEV), nq, nk))
+            got = ops.pack_bias_fragments(table, rpi.to(DEV).contiguous(), nq, nk)
+            assert torch.equal(got, want), ws
