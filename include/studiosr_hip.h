@@ -299,6 +299,13 @@ int sr_bias_gather(const float* table, const long long* rpi, float* bias, float*
 int sr_nhwc_out(const float* src, float* dst, const float* scale, const float* shift, int B, int Hs, int Ws, int C, int Ho, int Wo, int forward, void* stream);
 
 
+/* channel concat / split (swinfir.py:25,31,79; han.py:105,112): dst[r, off_d + c] (=|+=) src[r, off_s + c], c < n.
+ * nn.Conv3d(1, 1, 3, padding=1) over the (C, H, W) volume of an NHWC tensor (HAN's CSAM, han.py:37-53): w = 27 taps [dc][dy][dx];
+ * flip = 1 applies the adjoint (data gradient); sr_conv3d27_wgrad accumulates dw[27] and db[1]. */
+int sr_copy_cols(const float* src, float* dst, long long rows, int n, int ld_s, int off_s, int ld_d, int off_d, int accumulate, void* stream);
+int sr_conv3d27(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int flip, void* stream);
+int sr_conv3d27_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * One-time weight layout transforms, device side, enqueue-only (what studiosr_amd/packing.py does on the host; bit-identical).
  * A host in any language turns reference checkpoint tensors (fp32, state_dict layouts) into the packed operands above:

@@ -41,6 +41,24 @@ def swin_block(sd: SD, key: str, x: Tensor, ws: int, shift: int, heads: int) -> 
     return x + OF.mlp(sd, key + ".mlp", OF.layer_norm(sd, key + ".norm2", x))
 
 
+def sfb(sd: SD, key: str, x: Tensor) -> Tensor:
+    """SwinFIR's SFB on NCHW (studiosr/models/swinfir.py:9-81): S = conv-LeakyReLU(0.2)-conv + x; F = conv_after_fft(FourierUnit(y) + y)
+    with y = LeakyReLU(conv1x1(x)) and FourierUnit = irfftn(split(LeakyReLU(conv1x1(cat(rfftn(y).real, .imag))))), norm "ortho"."""
+    s = OF.conv(sd, key + ".S.body.2", F.leaky_relu(OF.conv(sd, key + ".S.body.0", x), 0.2)) + x
+    y = F.leaky_relu(OF.conv(sd, key + ".F.conv_before_fft.0", x), 0.2)
+    f = torch.fft.rfftn(y, dim=(-2, -1), norm="ortho")
+    z = F.leaky_relu(OF.conv(sd, key + ".F.fu.conv_layer", torch.cat((f.real, f.imag), dim=1)), 0.2)
+    re, im = z.split(y.shape[1], dim=1)
+    fu = torch.fft.irfftn(torch.complex(re, im), s=y.shape[-2:], dim=(-2, -1), norm="ortho")
+    f_out = OF.conv(sd, key + ".F.conv_after_fft", fu + y)
+    return OF.conv(sd, key + ".fusion", torch.cat([s, f_out], dim=1))
+
+
+def _resi(sd: SD, key: str, x: Tensor) -> Tensor:
+    """RSTB.conv / conv_after_body: nn.Conv2d for SwinIR, SFB for SwinFIR (swinir.py:241, swinfir.py:112-114)."""
+    return OF.conv(sd, key, x) if key + ".weight" in sd else sfb(sd, key, x)
+
+
 def swinir_forward(sd: SD, x: Tensor, cfg: Dict, training: bool = False) -> Tensor:
     """SwinIR.forward (studiosr/models/swinir.py:342-372)."""
     ws, scale, rng = cfg["window_size"], cfg["scale"], cfg["img_range"]
@@ -54,9 +72,9 @@ def swinir_forward(sd: SD, x: Tensor, cfg: Dict, training: bool = False) -> Tens
         for bi in range(depth):
             shift = 0 if bi % 2 == 0 else ws // 2  # :200
             t = swin_block(sd, f"layers.{li}.residual_group.blocks.{bi}", t, ws, shift, cfg["num_heads"][li])
-        t = OF.conv(sd, f"layers.{li}.conv", t.permute(0, 3, 1, 2)).permute(0, 2, 3, 1) + tin  # :245-246
+        t = _resi(sd, f"layers.{li}.conv", t.permute(0, 3, 1, 2)).permute(0, 2, 3, 1) + tin  # :245-246
     t = OF.layer_norm(sd, "norm", t).permute(0, 3, 1, 2)
-    x = OF.conv(sd, "conv_after_body", t) + first  # :362
+    x = _resi(sd, "conv_after_body", t) + first  # :362
     if cfg.get("upsampler", "pixelshuffle") == "pixelshuffle":
         x = F.leaky_relu(OF.conv(sd, "conv_before_upsample.0", x), 0.01)
         x = OF.conv(sd, "conv_last", OF.upsampler(sd, "upsample", x, scale))
@@ -186,7 +204,39 @@ def hat_forward(sd: SD, x: Tensor, cfg: Dict, training: bool = False) -> Tensor:
     return x[:, :, : h0 * scale, : w0 * scale]
 
 
+def han_forward(sd: SD, x: Tensor, cfg: Dict, training: bool = False) -> Tensor:
+    """HAN.forward (studiosr/models/han.py:92-115) with LAM (:19-33) and CSAM (:44-53)."""
+    ng, nb = cfg["n_resgroups"], cfg["n_resblocks"]
+    x = OF.conv(sd, "head.0", _mean_shift(x, cfg["img_range"], -1))
+    res, feats = x, []
+    for gi in range(ng):
+        r = res
+        for bi in range(nb):
+            k = f"body.{gi}.body.{bi}.body"
+            y = OF.conv(sd, k + ".2", F.relu(OF.conv(sd, k + ".0", r)))
+            r = OF.channel_attention(y, sd[k + ".3.conv_du.0.weight"], sd[k + ".3.conv_du.0.bias"], sd[k + ".3.conv_du.2.weight"], sd[k + ".3.conv_du.2.bias"]) + r
+        res = OF.conv(sd, f"body.{gi}.body.{nb}", r) + res
+        feats.insert(0, res)  # res1 = cat([res.unsqueeze(1), res1], 1): newest first (:98-101)
+    res = OF.conv(sd, f"body.{ng}", res)
+    feats.insert(0, res)
+    out1 = res
+    st = torch.stack(feats, 1)  # [B, N, C, H, W]
+    b, n, c, h, w = st.shape
+    q = st.reshape(b, n, -1)
+    energy = q @ q.transpose(1, 2)
+    att = torch.softmax(energy.max(-1, keepdim=True)[0] - energy, dim=-1)
+    la = (sd["la.gamma"] * (att @ q).reshape(b, n, c, h, w) + st).reshape(b, n * c, h, w)
+    out2 = OF.conv(sd, "last_conv", la)
+    a3 = torch.sigmoid(F.conv3d(out1.unsqueeze(1), sd["csa.conv.weight"], sd["csa.conv.bias"], padding=1))
+    out1 = out1 * (sd["csa.gamma"] * a3).reshape(b, c, h, w) + out1
+    res = OF.conv(sd, "last", torch.cat([out1, out2], 1)) + x
+    y = OF.conv(sd, "tail.1", OF.upsampler(sd, "tail.0", res, cfg["scale"]))
+    return _mean_shift(y, cfg["img_range"], +1)
+
+
 FORWARDS: Dict[str, Callable] = {
+    "SwinFIR": swinir_forward,
+    "HAN": han_forward,
     "SwinIR": swinir_forward,
     "EDSR": edsr_forward,
     "RCAN": rcan_forward,

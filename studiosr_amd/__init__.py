@@ -8,7 +8,7 @@ is no CPU fallback (use the reference for CPU runs).
 from . import _lib, autograd, models, ops, packing, parallel, runtime, strips  # noqa: F401
 from .evaluator import Evaluator  # noqa: F401
 from .metrics import compute_psnr, compute_ssim  # noqa: F401
-from .models import EDSR, HAT, RCAN, SwinIR  # noqa: F401
+from .models import EDSR, HAN, HAT, RCAN, SwinFIR, SwinIR  # noqa: F401
 from .trainer import Trainer  # noqa: F401
 
 __version__ = "0.1.0"

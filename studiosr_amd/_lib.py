@@ -154,6 +154,9 @@ SYMBOLS = {
     "sr_pixel_shuffle_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sr_bias_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp]),
     "sr_nhwc_out": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_copy_cols": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp]),
+    "sr_conv3d27": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sr_conv3d27_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     # device-side weight packing
     "sr_pack_matrix": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sr_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -532,3 +532,274 @@ def shift_mask(H: int, W: int, ws: int, shift: int, device) -> Tensor:
         m = torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff)).contiguous().to(device)
         _MASKS[key] = m
     return m
+
+
+# --------------------------------------------------------------------------- SwinFIR / HAN pieces
+def _copy_cols(src: Tensor, dst: Tensor, rows: int, n: int, ld_s: int, off_s: int, ld_d: int, off_d: int, *, s_base: int = 0, d_base: int = 0, accumulate: bool = False) -> None:
+    L.check(L.lib().sr_copy_cols(src.data_ptr() + 4 * s_base, dst.data_ptr() + 4 * d_base, rows, n, ld_s, off_s, ld_d, off_d, int(accumulate), _st()), "sr_copy_cols")
+
+
+class _Concat(Fn):
+    """torch.cat along the channel (last) axis of row-major tensors (swinfir.py:25,79; han.py:112)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_chk(x) for x in xs]
+        widths = [x.shape[-1] for x in xs]
+        rows = xs[0].numel() // widths[0]
+        out = torch.empty(*xs[0].shape[:-1], sum(widths), device=xs[0].device, dtype=torch.float32)
+        off = 0
+        for x, w_ in zip(xs, widths):
+            assert x.numel() // w_ == rows
+            _copy_cols(x, out, rows, w_, w_, 0, sum(widths), off)
+            off += w_
+        ctx.widths, ctx.shapes = widths, [tuple(x.shape) for x in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _chk(d)
+        tot = sum(ctx.widths)
+        rows = d.numel() // tot
+        outs, off = [], 0
+        for w_, shp in zip(ctx.widths, ctx.shapes):
+            g = torch.empty(shp, device=d.device, dtype=torch.float32)
+            _copy_cols(d, g, rows, w_, tot, off, w_, 0)
+            outs.append(g)
+            off += w_
+        return tuple(outs)
+
+
+def concat(*xs: Tensor) -> Tensor:
+    return _Concat.apply(*xs)
+
+
+class _Slice(Fn):
+    @staticmethod
+    def forward(ctx, x, off, n):
+        x = _chk(x)
+        ld = x.shape[-1]
+        rows = x.numel() // ld
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+        _copy_cols(x, out, rows, n, ld, off, n, 0)
+        ctx.meta = (off, n, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        off, n, shp = ctx.meta
+        d = _chk(d)
+        g = torch.zeros(shp, device=d.device, dtype=torch.float32)
+        _copy_cols(d, g, d.numel() // n, n, n, 0, shp[-1], off)
+        return g, None, None
+
+
+def slice_channels(x: Tensor, off: int, n: int) -> Tensor:
+    """x[..., off : off + n] as a contiguous tensor (torch.split, swinfir.py:30)."""
+    return _Slice.apply(x, off, n)
+
+
+class _ScaleParam(Fn):
+    """gamma * x with a learnable scalar gamma (HAN's LAM / CSAM, han.py:16,31,41,50)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        x, gamma = _chk(x), _chk(gamma)
+        ctx.save_for_backward(x, gamma)
+        return eltwise(L.EW_SCALE_SAMPLE, x, torch.empty_like(x), s=gamma, inner=x.numel())
+
+    @staticmethod
+    def backward(ctx, d):
+        x, gamma = ctx.saved_tensors
+        d = _chk(d)
+        dx = eltwise(L.EW_SCALE_SAMPLE, d, torch.empty_like(d), s=gamma, inner=d.numel())
+        prod = eltwise(L.EW_MUL, d, torch.empty_like(d), y=x)
+        dg = colsum(prod, torch.zeros(1, device=d.device), 1, prod.numel(), 1)
+        return dx, dg.reshape(gamma.shape)
+
+
+def scale_param(x: Tensor, gamma: Tensor) -> Tensor:
+    return _ScaleParam.apply(x, gamma)
+
+
+def mul(x: Tensor, y: Tensor) -> Tensor:
+    return _Mul.apply(x, y)
+
+
+class _Mul(Fn):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _chk(x), _chk(y)
+        ctx.save_for_backward(x, y)
+        return eltwise(L.EW_MUL, x, torch.empty_like(x), y=y)
+
+    @staticmethod
+    def backward(ctx, d):
+        x, y = ctx.saved_tensors
+        d = _chk(d)
+        return eltwise(L.EW_MUL, d, torch.empty_like(d), y=y), eltwise(L.EW_MUL, d, torch.empty_like(d), y=x)
+
+
+class _LayerAttention(Fn):
+    """HAN's LAM (han.py:19-33) on x [B, N, D]: softmax(max(E) - E) x with E = x x^T.  The row maximum is a constant shift of a softmax
+    argument, so this is softmax(-E) x: a plain self-attention with scale -1 whose contraction runs over D = C*H*W (split over workgroups)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, N, D = x.shape
+        E = torch.zeros(B, N, N, device=x.device, dtype=torch.float32)
+        bgemm(x, x, E, N, N, D, (D, 1), (1, D), (N, 1), alpha=-1.0, nb=(B, 1), sab=(N * D, 0), sbb=(N * D, 0), scb=(N * N, 0), ksplit=_ksplit(N, N, D))
+        L.check(L.lib().sr_softmax_fwd(E.data_ptr(), None, None, B * N, 1, N, N, 0, _st()), "sr_softmax_fwd")
+        out = torch.empty_like(x)
+        bgemm(E, x, out, N, D, N, (N, 1), (D, 1), (D, 1), nb=(B, 1), sab=(N * N, 0), sbb=(N * D, 0), scb=(N * D, 0))
+        ctx.save_for_backward(x, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        x, P = ctx.saved_tensors
+        dO = _chk(dO)
+        B, N, D = x.shape
+        nb, sx, sp = (B, 1), (N * D, 0), (N * N, 0)
+        dP = torch.zeros_like(P)
+        bgemm(dO, x, dP, N, N, D, (D, 1), (1, D), (N, 1), nb=nb, sab=sx, sbb=sx, scb=sp, ksplit=_ksplit(N, N, D))
+        dx = torch.empty_like(x)
+        bgemm(P, dO, dx, N, D, N, (1, N), (D, 1), (D, 1), nb=nb, sab=sp, sbb=sx, scb=sx)  # P^T dO
+        L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), B * N, N, _st()), "sr_softmax_bwd")
+        bgemm(dP, x, dx, N, D, N, (N, 1), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS x)
+        bgemm(dP, x, dx, N, D, N, (1, N), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS^T x)
+        return dx
+
+
+def layer_attention(x: Tensor) -> Tensor:
+    return _LayerAttention.apply(x)
+
+
+class _Conv3d27(Fn):
+    """nn.Conv3d(1, 1, 3, 1, 1) over the (C, H, W) volume of an NHWC tensor (han.py:40,46-47)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _chk(x), _chk(w), _chk(b)
+        B, H, W, Cn = x.shape
+        out = torch.empty_like(x)
+        L.check(L.lib().sr_conv3d27(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cn, 0, _st()), "sr_conv3d27")
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        x, w = ctx.saved_tensors
+        d = _chk(d)
+        B, H, W, Cn = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.lib().sr_conv3d27(d.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, H, W, Cn, 1, _st()), "sr_conv3d27")
+        dw, db = torch.zeros_like(w), torch.zeros(1, device=d.device)
+        L.check(L.lib().sr_conv3d27_wgrad(x.data_ptr(), d.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H, W, Cn, _st()), "sr_conv3d27_wgrad")
+        return dx, dw, db
+
+
+def conv3d_27(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """w: the nn.Conv3d weight [1,1,3,3,3] whose kernel axes are (channel-depth, H, W)."""
+    return _Conv3d27.apply(x, w.reshape(27), b)
+
+
+# ---- 2-D real FFT as matrix products on the fp32 matrix cores (SwinFIR's FourierUnit, swinfir.py:19-35: rfftn / irfftn, norm="ortho")
+_DFT = {}
+
+
+def _dft_mats(H: int, W: int, device):
+    key = (H, W, str(device))
+    m = _DFT.get(key)
+    if m is None:
+        f64 = torch.float64
+        Wf = W // 2 + 1
+        k, w_ = torch.arange(Wf, dtype=f64)[:, None], torch.arange(W, dtype=f64)[None, :]
+        ang = 2 * torch.pi * k * w_ / W
+        fw = torch.stack([torch.cos(ang), -torch.sin(ang)], 1).reshape(2 * Wf, W) / W ** 0.5           # rows (k, part) -> [2Wf, W]
+        wk = torch.full((Wf,), 2.0, dtype=f64)
+        wk[0] = 1.0
+        if W % 2 == 0:
+            wk[-1] = 1.0
+        finv = (torch.stack([torch.cos(ang) * wk[:, None], -torch.sin(ang) * wk[:, None]], 1).reshape(2 * Wf, W) / W ** 0.5).t().contiguous()  # [W, 2Wf]
+        hh = torch.arange(H, dtype=f64)
+        angh = 2 * torch.pi * hh[:, None] * hh[None, :] / H
+        gr, gi = torch.cos(angh) / H ** 0.5, -torch.sin(angh) / H ** 0.5
+        m = tuple(t.to(torch.float32).contiguous().to(device) for t in (fw, finv, gr, gi))
+        _DFT[key] = m
+    return m
+
+
+def _dft_h(Y: Tensor, Gr: Tensor, Gi: Tensor, sgn: float, B: int, H: int, Wf: int, Cn: int) -> Tensor:
+    """Z = (Gr + i sgn Gi) Y along H for Y [B, H, Wf, (re | im) x C]: four real GEMMs batched over (b, k)."""
+    Z = torch.empty_like(Y)
+    ld = Wf * 2 * Cn
+    kw = dict(nb=(B, Wf), sab=(0, 0), sbb=(H * ld, 2 * Cn), scb=(H * ld, 2 * Cn))
+    bgemm(Gr, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=0, c_off=0, **kw)                               # Zr  = Gr Yr
+    bgemm(Gi, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=Cn, c_off=0, alpha=-sgn, accumulate=True, **kw)  # Zr -= sgn Gi Yi
+    bgemm(Gi, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=0, c_off=Cn, alpha=sgn, **kw)                    # Zi  = sgn Gi Yr
+    bgemm(Gr, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=Cn, c_off=Cn, accumulate=True, **kw)             # Zi += Gr Yi
+    return Z
+
+
+class _Rfft2(Fn):
+    """x [B,H,W,C] -> rfftn over (H, W), norm 'ortho', as [B, H, W/2+1, 2C] with channels (real | imag) = torch.cat((f.real, f.imag), 1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x)
+        B, H, W, Cn = x.shape
+        Wf = W // 2 + 1
+        fw, finv, gr, gi = _dft_mats(H, W, x.device)
+        Y = torch.empty(B, H, Wf, 2 * Cn, device=x.device, dtype=torch.float32)
+        bgemm(fw, x, Y, 2 * Wf, Cn, W, (W, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0))
+        ctx.shape = (B, H, W, Cn)
+        return _dft_h(Y, gr, gi, 1.0, B, H, Wf, Cn)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        B, H, W, Cn = ctx.shape
+        Wf = W // 2 + 1
+        dZ = _chk(dZ)
+        fw, finv, gr, gi = _dft_mats(H, W, dZ.device)
+        dY = _dft_h(dZ, gr, gi, -1.0, B, H, Wf, Cn)  # the DFT matrix is symmetric: adjoint = conjugate
+        dx = torch.empty(B, H, W, Cn, device=dZ.device, dtype=torch.float32)
+        bgemm(fw, dY, dx, W, Cn, 2 * Wf, (1, W), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0))
+        return dx
+
+
+class _Irfft2(Fn):
+    """[B, H, W/2+1, (real | imag) x C] -> irfftn(s=(H, W), norm 'ortho') [B,H,W,C] (imaginary parts of the DC / Nyquist bins are ignored,
+    as torch's c2r transform does)."""
+
+    @staticmethod
+    def forward(ctx, Z, W):
+        Z = _chk(Z)
+        B, H, Wf, C2 = Z.shape
+        Cn = C2 // 2
+        assert Wf == W // 2 + 1
+        fw, finv, gr, gi = _dft_mats(H, W, Z.device)
+        Y = _dft_h(Z, gr, gi, -1.0, B, H, Wf, Cn)
+        x = torch.empty(B, H, W, Cn, device=Z.device, dtype=torch.float32)
+        bgemm(finv, Y, x, W, Cn, 2 * Wf, (2 * Wf, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0))
+        ctx.shape = (B, H, W, Cn)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, H, W, Cn = ctx.shape
+        Wf = W // 2 + 1
+        dx = _chk(dx)
+        fw, finv, gr, gi = _dft_mats(H, W, dx.device)
+        dY = torch.empty(B, H, Wf, 2 * Cn, device=dx.device, dtype=torch.float32)
+        bgemm(finv, dx, dY, 2 * Wf, Cn, W, (1, 2 * Wf), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0))
+        return _dft_h(dY, gr, gi, 1.0, B, H, Wf, Cn), None
+
+
+def rfft2(x: Tensor) -> Tensor:
+    return _Rfft2.apply(x)
+
+
+def irfft2(z: Tensor, W: int) -> Tensor:
+    return _Irfft2.apply(z, W)

@@ -14,6 +14,7 @@
 // is exceeded, not approximated.  Speed-of-light kernels for this path are later rounds' work; the bar here is gradient parity.
 #include "sr_common.cuh"
 #include "sr_host.h"
+#include <algorithm>
 
 namespace {
 
@@ -413,6 +414,70 @@ __global__ void sr_nhwc_out_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
+// dst[r, off_d + c] = src[r, off_s + c], c < n  (channel concat / split as strided column copies)
+__global__ void sr_copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int n, int ld_s, int off_s, int ld_d, int off_d, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const long long r = i / n;
+    const int c = (int)(i - r * n);
+    float* d = dst + r * ld_d + off_d + c;
+    const float v = src[r * ld_s + off_s + c];
+    *d = accumulate ? *d + v : v;
+}
+
+// nn.Conv3d(1, 1, 3, padding=1) over the (C, H, W) volume of an NHWC tensor (HAN's CSAM, han.py:37-53): 27 taps w[dc][dy][dx].
+// flip = 1 evaluates the adjoint (data gradient): taps mirrored.
+__global__ void sr_conv3d27_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int C, int flip) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long m = idx / C;
+    const int xx = (int)(m % W), yy = (int)((m / W) % H);
+    const long long b = m / ((long long)W * H);
+    float s = (bias && !flip) ? bias[0] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int dc = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+        const int c2 = c + dc, y2 = yy + dy, x2 = xx + dx;
+        if ((unsigned)c2 < (unsigned)C && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) s += w[flip ? 26 - t : t] * x[((b * H + y2) * W + x2) * C + c2];
+    }
+    out[idx] = s;
+}
+// dw[t] += sum x[shifted by tap t] * dy ; db += sum dy   (28 block-reduced atomics per workgroup)
+__global__ void sr_conv3d27_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C) {
+    __shared__ float red[4][28];
+    const long long total = (long long)B * H * W * C;
+    float acc[28];
+#pragma unroll
+    for (int t = 0; t < 28; ++t) acc[t] = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long long m = idx / C;
+        const int xx = (int)(m % W), yy = (int)((m / W) % H);
+        const long long b = m / ((long long)W * H);
+        const float d = dy[idx];
+        acc[27] += d;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int c2 = c + t / 9 - 1, y2 = yy + (t / 3) % 3 - 1, x2 = xx + t % 3 - 1;
+            if ((unsigned)c2 < (unsigned)C && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) acc[t] += d * x[((b * H + y2) * W + x2) * C + c2];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 28; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(threadIdx.x < 27 ? dw + threadIdx.x : db, v);
+    }
+}
+
 inline dim3 flat_grid(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -520,5 +585,26 @@ extern "C" int sr_nhwc_out(const float* src, float* dst, const float* scale, con
     const long long total = forward ? (long long)B * C * Ho * Wo : (long long)B * Hs * Ws * C;
     hipLaunchKernelGGL(sr_nhwc_out_kernel, flat_grid(total), dim3(256), 0, ST, src, dst, scale, shift, B, Hs, Ws, C, Ho, Wo, forward);
     SR_CHECK_LAUNCH("sr_nhwc_out");
+    return SR_OK;
+}
+
+extern "C" int sr_copy_cols(const float* src, float* dst, long long rows, int n, int ld_s, int off_s, int ld_d, int off_d, int accumulate, void* stream) {
+    SR_REQUIRE(src && dst && rows > 0 && n > 0 && off_s >= 0 && off_d >= 0 && off_s + n <= ld_s && off_d + n <= ld_d, "sr_copy_cols: bad arguments");
+    hipLaunchKernelGGL(sr_copy_cols_kernel, flat_grid(rows * n), dim3(256), 0, ST, src, dst, rows, n, ld_s, off_s, ld_d, off_d, accumulate);
+    SR_CHECK_LAUNCH("sr_copy_cols");
+    return SR_OK;
+}
+extern "C" int sr_conv3d27(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int flip, void* stream) {
+    SR_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0 && C > 0, "sr_conv3d27: bad arguments");
+    hipLaunchKernelGGL(sr_conv3d27_kernel, flat_grid((long long)B * H * W * C), dim3(256), 0, ST, x, w, bias, out, B, H, W, C, flip);
+    SR_CHECK_LAUNCH("sr_conv3d27");
+    return SR_OK;
+}
+extern "C" int sr_conv3d27_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int H, int W, int C, void* stream) {
+    SR_REQUIRE(x && dy && dw && db && B > 0 && H > 0 && W > 0 && C > 0, "sr_conv3d27_wgrad: bad arguments");
+    const long long total = (long long)B * H * W * C;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(sr_conv3d27_wgrad_kernel, dim3(blocks), dim3(256), 0, ST, x, dy, dw, db, B, H, W, C);
+    SR_CHECK_LAUNCH("sr_conv3d27_wgrad");
     return SR_OK;
 }

@@ -63,7 +63,26 @@ def _drop_rates(model) -> List[float]:
     return [float(v) for v in torch.linspace(0, model.drop_path_rate, n)] if n else []  # swinir.py:296, hat.py:440
 
 
-# --------------------------------------------------------------------------- SwinIR
+# --------------------------------------------------------------------------- SwinIR / SwinFIR
+def _conv1x1(x: Tensor, m: torch.nn.Conv2d) -> Tensor:
+    return A.linear(x, m.weight, m.bias)
+
+
+def _sfb(m, x: Tensor) -> Tensor:
+    """SwinFIR's SFB (swinfir.py:38-81): spatial branch conv-LeakyReLU(0.2)-conv + x; spectral branch 1x1 conv + LeakyReLU ->
+    FourierUnit (rfftn -> 1x1 conv on (real | imag) + LeakyReLU -> irfftn) -> 1x1 conv(fu + y); 1x1 fusion conv of the concatenation."""
+    s = A.add(_conv(A.leaky_relu(_conv(x, m.S.body[0]), 0.2), m.S.body[2]), x)
+    y = A.leaky_relu(_conv1x1(x, m.F.conv_before_fft[0]), 0.2)
+    z = A.leaky_relu(_conv1x1(A.rfft2(y), m.F.fu.conv_layer), 0.2)
+    f = _conv1x1(A.add(A.irfft2(z, y.shape[2]), y), m.F.conv_after_fft)
+    return _conv1x1(A.concat(s, f), m.fusion)
+
+
+def _resi(m, t: Tensor) -> Tensor:
+    """RSTB.conv / conv_after_body: a 3x3 conv (SwinIR) or an SFB (SwinFIR's resi_connection, swinir.py:241, swinfir.py:112-114)."""
+    return _conv(t, m) if isinstance(m, torch.nn.Conv2d) else _sfb(m, t)
+
+
 def _window_msa(attn, t: Tensor, ws: int, shift: int, heads: int, rpi: Tensor) -> Tensor:
     B, H, W, Cn = t.shape
     win = A.window_partition(t, ws, shift)
@@ -98,9 +117,9 @@ def swinir_forward(model, x: Tensor) -> Tensor:
             m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
             t = A.add(t, A.drop_path(m, dpr[k], model.training))
             k += 1
-        t = A.add(_conv(t, layer.conv), tin)  # swinir.py:245-246
+        t = A.add(_resi(layer.conv, t), tin)  # swinir.py:245-246
     t = A.layer_norm(t, model.norm.weight, model.norm.bias)
-    body = A.add(_conv(t, model.conv_after_body), first)
+    body = A.add(_resi(model.conv_after_body, t), first)
     if model.upsampler == "pixelshuffle":
         f = A.leaky_relu(_conv(body, model.conv_before_upsample[0]), 0.01)
         y = _conv(_upsampler(model.upsample, f), model.conv_last)
@@ -194,4 +213,38 @@ def rcan_forward(model, x: Tensor) -> Tensor:
     return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
 
 
-FORWARDS = {"SwinIR": swinir_forward, "HAT": hat_forward, "EDSR": edsr_forward, "RCAN": rcan_forward}
+def han_forward(model, x: Tensor) -> Tensor:
+    """HAN.forward (han.py:92-115)."""
+    B, _, H, W = x.shape
+    s, F = model.scale, model.n_feats
+    h = _conv(_ingest(x, H, W, L.PAD_NONE, *_mean_shift(model.sub_mean)), model.head[0], cin=model.n_colors)
+    feats = []
+    res = h
+    for gi in range(model.n_resgroups):
+        grp = model.body[gi]
+        r = res
+        for bi in range(model.n_resblocks):
+            b = grp.body[bi].body
+            du = b[3].conv_du
+            y = _conv(A.relu(_conv(r, b[0])), b[2])
+            r = A.add(A.channel_attention(y, du[0].weight, du[0].bias, du[2].weight, du[2].bias), r)
+        res = A.add(_conv(r, grp.body[model.n_resblocks]), res)
+        feats.append(res)
+    res = _conv(res, model.body[model.n_resgroups])
+    feats.append(res)
+    out1 = res
+    # LAM over the N = n_resgroups + 1 features, newest first (han.py:96-103): each feature is one vector of H*W*C values
+    N = len(feats)
+    stack = A.concat(*[f.reshape(B, H * W * F) for f in reversed(feats)]).reshape(B, N, H * W * F)
+    la = A.add(A.scale_param(A.layer_attention(stack), model.la.gamma), stack)                      # gamma * out + x  (han.py:31)
+    la = A.concat(*[A.slice_channels(la.reshape(B, N * H * W * F), n * H * W * F, H * W * F).reshape(B * H * W, F) for n in range(N)]).reshape(B, H, W, N * F)
+    out2 = _conv(la, model.last_conv)
+    # CSAM (han.py:44-53): x * (gamma * sigmoid(conv3d(x))) + x
+    att = A.scale_param(A.sigmoid(A.conv3d_27(out1, model.csa.conv.weight, model.csa.conv.bias)), model.csa.gamma)
+    out1 = A.add(A.mul(out1, att), out1)
+    res = A.add(_conv(A.concat(out1, out2), model.last), h)
+    y = _conv(_upsampler(model.tail[0], res), model.tail[1])
+    return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
+
+
+FORWARDS = {"SwinIR": swinir_forward, "SwinFIR": swinir_forward, "HAT": hat_forward, "EDSR": edsr_forward, "RCAN": rcan_forward, "HAN": han_forward}

@@ -274,14 +274,22 @@ def grads(M) -> None:
     forward, L1 loss, backward; DropPath off so the vectors are deterministic).  Every parameter gradient is stored."""
     import torch.nn.functional as F
 
+    torch.set_num_threads(1)  # index_put(accumulate) of the bias-table gradient sums in thread order: one thread makes the files bit-reproducible
+    from studiosr.models.han import HAN
+    from studiosr.models.swinfir import SwinFIR
+
     cases = [
         ("swinir", M.SwinIR, dict(scale=2, embed_dim=60, depths=[2, 2], num_heads=[6, 6], drop_path_rate=0.0), (2, 13, 17), 70),
         ("swinir_direct", M.SwinIR, dict(scale=3, embed_dim=60, depths=[2], num_heads=[6], upsampler="pixelshuffledirect", drop_path_rate=0.0), (1, 16, 16), 71),
         ("hat", M.HAT, dict(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=8, drop_path_rate=0.0), (2, 16, 24), 72),
         ("edsr", M.EDSR, dict(scale=4, n_feats=32, n_resblocks=2), (2, 12, 10), 73),
         ("rcan", M.RCAN, dict(scale=3, n_feats=32, n_resblocks=2, n_resgroups=2, reduction=8), (2, 9, 12), 74),
+        # row f-4 models: SwinFIR (SFB with the rFFT branch; odd and even widths) and HAN (LAM + CSAM; han.py:87 hard-codes 11 groups)
+        ("swinfir", SwinFIR, dict(scale=2, embed_dim=60, depths=[2], num_heads=[6], drop_path_rate=0.0), (2, 13, 18), 75),
+        ("han", HAN, dict(scale=2, n_feats=16, n_resblocks=1, n_resgroups=10, reduction=4), (2, 9, 10), 76),
     ]
     for tag, ctor, cfg, (b, h, w), seed in cases:
+        torch.manual_seed(seed)  # parameter init draws from the global generator: seed it per case so that every file is reproducible on its own
         model = ctor(**cfg)
         randomize(model, seed)
         model.train()
@@ -289,6 +297,14 @@ def grads(M) -> None:
         x = torch.rand(b, 3, h, w, generator=g)
         sc = cfg["scale"]
         tgt = torch.rand(b, 3, h * sc, w * sc, generator=g)
+        if tag in ("swinfir", "han"):  # also the eval-mode forward (SwinFIR: eval padding); HAN's zero-initialised gammas made non-trivial
+            with torch.no_grad():
+                for n_, p_ in model.named_parameters():
+                    if n_.endswith("gamma"):
+                        p_.fill_(0.3)
+                model.eval()
+                y_eval = model(x).numpy()
+                model.train()
         out = model(x)
         loss = F.l1_loss(out, tgt)
         loss.backward()
@@ -297,11 +313,13 @@ def grads(M) -> None:
         for n_, p_ in model.named_parameters():
             if p_.grad is not None:
                 arrs["grad/" + n_] = p_.grad.numpy()
+        if tag in ("swinfir", "han"):
+            arrs["y_eval"] = y_eval
         save(f"f15_grads_{tag}", **arrs)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--grads-only":
-        grads(import_reference()[0])
+        grads(import_reference()[0])  # (every case is independently seeded: regenerating leaves the other fixtures byte-identical)
     else:
         main()

@@ -173,7 +173,7 @@ def test_psnr_metric():
     assert abs(OM.compute_psnr(a, b) - OM.compute_psnr(a / 255.0, b / 255.0)) < 1e-12
 
 
-@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN")])
+@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN"), ("swinfir", "SwinFIR"), ("han", "HAN")])
 def test_oracle_autograd_matches_reference_gradients(tag, kind):
     """f15: gradients of one L1 training step produced by the reference (generate.py grads()).  torch autograd through the oracle's
     forward must reproduce them: this pins the oracle as a gradient reference for geometries without a fixture."""
@@ -186,6 +186,10 @@ def test_oracle_autograd_matches_reference_gradients(tag, kind):
     sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "mean" not in k else v) for k, v in sd.items()}
     out = OM.FORWARDS[kind](sdg, torch.from_numpy(g["x"]), cfg, training=True)
     assert float((out.detach() - torch.from_numpy(g["out"])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["out"]).max()))
+    if "y_eval" in g:  # SwinFIR / HAN: the eval-mode forward too (SwinFIR pads differently in eval)
+        with torch.no_grad():
+            ye = OM.FORWARDS[kind](sd, torch.from_numpy(g["x"]), cfg, training=False)
+        assert float((ye - torch.from_numpy(g["y_eval"])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["y_eval"]).max()))
     F.l1_loss(out, torch.from_numpy(g["target"])).backward()
     n = 0
     for k, v in g.items():

@@ -44,7 +44,7 @@ def _grad_check(model, ref_grads, tol=GRAD_TOL):
     assert n > 0
 
 
-@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN")])
+@pytest.mark.parametrize("tag,kind", [("swinir", "SwinIR"), ("swinir_direct", "SwinIR"), ("hat", "HAT"), ("edsr", "EDSR"), ("rcan", "RCAN"), ("swinfir", "SwinFIR"), ("han", "HAN")])
 def test_gradients_against_the_reference(tag, kind):
     g = load_golden(f"f15_grads_{tag}")
     cfg, sd = golden_cfg(g), golden_sd(g)
@@ -60,6 +60,14 @@ def test_gradients_against_the_reference(tag, kind):
     assert abs(loss.item() - float(g["loss"])) <= 1e-5 * max(1.0, float(g["loss"]))
     loss.backward()
     _grad_check(m, {k[len("grad/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("grad/")})
+    if "y_eval" in g:  # SwinFIR / HAN: eval-mode forward and the uint8 inference() entry point
+        m.eval()
+        with torch.no_grad():
+            ye = m(x).cpu()
+        ref_e = torch.from_numpy(g["y_eval"])
+        assert float((ye - ref_e).abs().max()) <= 2e-5 * max(1.0, float(ref_e.abs().max()))
+        img = (np.random.default_rng(0).integers(0, 256, size=(9, 11, 3))).astype(np.uint8)
+        assert m.inference(img).shape == (9 * cfg["scale"], 11 * cfg["scale"], 3)
 
 
 def _oracle_grads(fwd, sd, x, tgt, cfg, training):
