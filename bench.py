@@ -10,7 +10,7 @@ one rank per GPU) every rank processes its own batch of 8 tiles -- tiles are ind
 data-path collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
 
 The JSON line also carries
-  roofline      dominant kernel (the one-launch Swin block kernel `sr_swin_attn_kernel<MLP>`) vs the bf16 MFMA peak,
+  roofline      dominant kernel (the one-launch Swin block kernel `sr_swin_block_kernel<MLP>`) vs the bf16 MFMA peak,
                 timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this
                 host's cores on a bounded sample of the same workload.
@@ -51,7 +51,7 @@ def build_model(device):
 
 
 def time_dominant_kernel(model, x, iters: int = 50):
-    """Average duration of ONE launch of the dominant kernel, `sr_swin_attn_kernel<MLP=true>` -- one whole Swin block
+    """Average duration of ONE launch of the dominant kernel, `sr_swin_block_kernel<MLP=true>` -- one whole Swin block
     (LayerNorm1 + QKV + shifted-window attention + proj + residual, LayerNorm2 + fc1 + GELU + fc2 + residual) at the
     bench shape: 648 windows = 41,472 tokens, 36 launches per forward -- timed with HIP events on the launch stream
     (torch's current stream is the stream the C-ABI call enqueues on), and its ALGORITHMIC FLOPs per token:
@@ -99,7 +99,7 @@ def profiled_hbm_traffic():
     vals, key = {}, None
     for line in open(files[-1]):
         if line.startswith("("):
-            key = "swin_attn_kernel<true>" in line and ", 324)" in line
+            key = "swin_block_kernel<true>" in line and ", 648)" in line
         elif key:
             m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
             if m:
@@ -430,7 +430,8 @@ def main() -> None:
         # fp32 residual stream in + out (Cp = 192 channels) + the block's packed bf16 weights and biases, per launch
         algo_bytes = 2 * BATCH * PADDED * PADDED * 192 * 4 + 2 * (192 * 576 + 192 * 192 + 2 * 192 * 384) + 4 * 6 * 64 * 64
         roof = dict(
-            bound="mfma", kernel="sr_swin_attn_kernel<MLP> (one whole Swin block: LN1 + QKV + shifted-window attention + proj + residual + LN2 + MLP + residual; 648 windows x 64 tokens, 36 launches per forward)",
+            bound="mfma", kernel="sr_swin_block_kernel<MLP> (one whole Swin block per launch: LN1 + QKV + shifted-window attention + proj + residual + LN2 + MLP + residual; "
+                                 "one 64-token window per 4-wave workgroup, 648 workgroups, 36 launches per forward)",
             achieved=round(achieved, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
             traffic=(traffic or {}).get("bytes"), traffic_detail=traffic, algorithmic_hbm_bytes=algo_bytes, kernel_ms=round(k_ms, 5),
             forward=dict(achieved=round(fwd_tflops, 2), frac=round(fwd_tflops / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -261,9 +261,9 @@ typedef struct SrBgemm {
 } SrBgemm;
 int sr_bgemm(const SrBgemm* g, void* stream);
 
-/* col[m, c*9 + tap] = x[b, y + tap/3 - 1, x + tap%3 - 1, c] (zero outside), m = (b*H + y)*W + x: the column order is OIHW's,
- * so conv(x, w) = col @ w.view(Cout, Cin*9)^T (common.py:104-105).  x is addressed by element strides (NCHW or NHWC).
- * sr_col2im3x3 is the adjoint written as a gather: dx[m, c] = sum_tap dcol[m - tap offset, c*9 + tap]. */
+/* col[m, tap*C + c] = x[b, y + tap/3 - 1, x + tap%3 - 1, c] (zero outside), m = (b*H + y)*W + x, tap = ky*3 + kx: reads and writes
+ * are contiguous over c, so conv(x, w) = col @ w.permute(0, 2, 3, 1).view(Cout, 9*Cin)^T (common.py:104-105).  x is addressed by
+ * element strides (NCHW or NHWC).  sr_col2im3x3 is the adjoint written as a gather: dx[m, c] = sum_tap dcol[m - tap offset, tap*C + c]. */
 int sr_im2col3x3(const float* x, float* col, int B, int H, int W, int C, long long sb, long long sy, long long sx, long long sc, void* stream);
 int sr_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, void* stream);
 

@@ -120,40 +120,43 @@ def _im2col(x: Tensor, strides=None, Cn: Optional[int] = None) -> Tensor:
 
 
 class _Conv3x3(Fn):
-    """nn.Conv2d(Cin, Cout, 3, padding=1) on NHWC (common.py:104-105): y = im2col(x) @ w.view(Cout, Cin*9)^T + b.  The column buffer
-    is rebuilt in backward instead of being kept (a 256x256 conv_last buffer is 0.6 GB)."""
+    """nn.Conv2d(Cin, Cout, 3, padding=1) on NHWC (common.py:104-105): y = im2col(x) @ w2^T + b with the column order (tap, c) and
+    w2 = the weight permuted to [Cout, 3, 3, Cin] (a 1 MB layout copy; the gradient is permuted back).  The column buffer is rebuilt in
+    backward instead of being kept (a 256x256 conv_last buffer is 0.6 GB)."""
 
     @staticmethod
     def forward(ctx, x, w, b, cin):
-        x, w = _chk(x), _chk(w)
+        x, w = _chk(x), _chk(w)  # w: [Cout, Cin, 3, 3]
         B, H, W = x.shape[:3]
         ld = x.shape[3]  # cin < ld: the input is a channel-padded buffer (the ingest kernel's NHWC-32 image)
         Cout = w.shape[0]
+        w2 = w.permute(0, 2, 3, 1).contiguous()  # [Cout, (ky, kx), Cin]
         col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
         y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
-        bgemm(col, w, y, B * H * W, Cout, 9 * cin, (9 * cin, 1), (1, 9 * cin), (Cout, 1), bias=None if b is None else _chk(b))
-        ctx.save_for_backward(x, w)
+        bgemm(col, w2, y, B * H * W, Cout, 9 * cin, (9 * cin, 1), (1, 9 * cin), (Cout, 1), bias=None if b is None else _chk(b))
+        ctx.save_for_backward(x, w2)
         ctx.cin, ctx.has_bias = cin, b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w2 = ctx.saved_tensors
         dy = _chk(dy)
         B, H, W = x.shape[:3]
         ld, cin = x.shape[3], ctx.cin
-        Cout, M, K = w.shape[0], B * H * W, 9 * cin
+        Cout, M, K = w2.shape[0], B * H * W, 9 * cin
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             assert ld == cin, "no input gradient through a channel-padded input buffer"
             dcol = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            bgemm(dy, w, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
+            bgemm(dy, w2, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
             dx = torch.empty_like(x)
             L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
         if ctx.needs_input_grad[1]:
             col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-            dw = torch.zeros_like(w)
-            bgemm(dy, col, dw, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
+            dw2 = torch.zeros(Cout, K, device=dy.device, dtype=torch.float32)
+            bgemm(dy, col, dw2, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
+            dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, torch.zeros(Cout, device=dy.device), 1, M, Cout)
         return dx, dw, db, None
@@ -162,7 +165,7 @@ class _Conv3x3(Fn):
 def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], cin: Optional[int] = None) -> Tensor:
     """x [B,H,W,C] -> [B,H,W,Cout]; w is the nn.Conv2d weight [Cout, Cin, 3, 3]."""
     cin = w.shape[1] if cin is None else cin
-    return _Conv3x3.apply(x, w.reshape(w.shape[0], -1), b, cin)
+    return _Conv3x3.apply(x, w, b, cin)
 
 
 # --------------------------------------------------------------------------- LayerNorm

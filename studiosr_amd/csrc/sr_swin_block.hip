@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block_kernel(SwinBlockDev dv) 
                     for (int r = 0; r < 4; ++r) s[qt][kt][r] += fminf(rowneg, colneg[r]);
                 }
             }
+#ifndef SR_EXP_NOVALU
             f32x4 tm;  // per key tile maxima: independent chains
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) tm[kt] = fmaxf(fmaxf(s[qt][kt][0], s[qt][kt][1]), fmaxf(s[qt][kt][2], s[qt][kt][3]));
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block_kernel(SwinBlockDev dv) 
                     s[qt][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], 1.4426950408889634f, nmx));  // exp(s - max)
 #endif
                 }
+#endif
             const Frag<bf16> p0 = pack2(s[qt][0], s[qt][1]), p1 = pack2(s[qt][2], s[qt][3]);
             f32x4 o0 = (f32x4)(0.0f), o1 = (f32x4)(0.0f);
             mma(vf[0][0], p0, o0);
@@ -537,7 +539,9 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block_kernel(SwinBlockDev dv) 
                 for (int m = 0; m < 4; ++m) {
                     f32x4 g;
 #pragma unroll
-#ifdef SR_EXP_NOTRANS
+#if defined(SR_EXP_NOVALU)
+                    for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r];
+#elif defined(SR_EXP_NOTRANS)
                     for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r] * 0.5f;
 #else
                     for (int r = 0; r < 4; ++r) g[r] = gelu_bf16(acc[m][n][r]);

@@ -18,6 +18,8 @@
 
 namespace {
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte global access that only needs dword alignment
+
 // ----------------------------------------------------------------------------- strided batched GEMM (fp32 MFMA)
 __global__ __launch_bounds__(256) void sr_bgemm_kernel(SrBgemm g) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
@@ -93,24 +95,192 @@ __global__ __launch_bounds__(256) void sr_bgemm_kernel(SrBgemm g) {
         }
 }
 
-// ----------------------------------------------------------------------------- im2col / col2im (k order = (c, tap): OIHW flattening)
-__global__ void sr_im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C, long long sb, long long sy, long long sx, long long sc) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * H * W * C;
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const long long m = idx / C;
-    const int xx = (int)(m % W);
-    const int yy = (int)((m / W) % H);
-    const int b = (int)(m / ((long long)W * H));
-    float* dst = col + m * (9LL * C) + 9 * c;
+// ----------------------------------------------------------------------------- the same GEMM, LDS-tiled (large M, N)
+// 128 x 128 output tile per workgroup, 4 waves of 64 x 64 (16 accumulator tiles each); K in steps of 16.  Both operand tiles are
+// staged [row][16 k] (row stride 20 floats: the ds_read_b128 of 16 consecutive rows is bank-conflict free) through registers, the
+// global loads of step t+1 issued before the MFMAs of step t.  A lane's fragment of a 16-row tile is one ds_read_b128 = its four
+// k values 4 lg .. 4 lg + 3, consumed by MFMA steps j = 0..3 (same k permutation on both operands as in the direct kernel).
+// Staging vectorises along whichever axis is contiguous: float4 along k (stride_k == 1) or float4 along rows (stride_row == 1).
+constexpr int BT = 128, BK = 16, BLD = 20;
+
+template <int MODE>  // 0: k contiguous, 1: row contiguous, 2: generic
+SR_DEV void bg_load(const float* __restrict__ base, long long s_row, long long s_k, int row0, int nrows, int k0, int kend, float (&r)[8]) {
+    const int t = threadIdx.x;
+    const bool interior = row0 + BT <= nrows && k0 + BK <= kend;  // block-uniform: whole tile in range -> unguarded 16-byte loads
+    if (MODE == 0 && interior) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-        dst[t] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? x[b * sb + y2 * sy + x2 * sx + c * sc] : 0.0f;
+        for (int i = 0; i < 2; ++i) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)(row0 + (t >> 2) + 64 * i) * s_row + k0 + 4 * (t & 3));
+            r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+        }
+    } else if (MODE == 1 && interior) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)(k0 + (t >> 5) + 8 * i) * s_k + row0 + 4 * (t & 31));
+            r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+        }
+    } else if (MODE == 0) {  // thread -> (row = t / 4 + 64 i, k quad = t % 4)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + (t >> 2) + 64 * i, k = k0 + 4 * (t & 3);
+            const float* p = base + (long long)min(row, nrows - 1) * s_row + min(k, kend - 1);
+            const bool rok = row < nrows;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[4 * i + j] = (rok && k + j < kend) ? p[min(j, kend - 1 - min(k, kend - 1))] : 0.f;
+        }
+    } else if (MODE == 1) {  // thread -> (row quad = t % 32, k = t / 32 + 8 i)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + 4 * (t & 31), k = k0 + (t >> 5) + 8 * i;
+            const float* p = base + (long long)min(k, kend - 1) * s_k + min(row, nrows - 1);
+            const bool kok = k < kend;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[4 * i + j] = (kok && row + j < nrows) ? p[min(j, nrows - 1 - min(row, nrows - 1))] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // element e = t + 256 i -> (row = e / 16, k = e % 16)
+            const int e = t + 256 * i, row = row0 + (e >> 4), k = k0 + (e & 15);
+            const float v = base[(long long)min(row, nrows - 1) * s_row + (long long)min(k, kend - 1) * s_k];
+            r[i] = (row < nrows && k < kend) ? v : 0.f;
+        }
     }
 }
-// dx[b,y,x,c] = sum_tap dcol[(b, y - dy, x - dx), c*9 + tap]  (the adjoint of im2col written as a gather)
+template <int MODE>
+SR_DEV void bg_store(float* __restrict__ tile, const float (&r)[8]) {
+    const int t = threadIdx.x;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(tile + ((t >> 2) + 64 * i) * BLD + 4 * (t & 3)) = f32x4{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
+    } else if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[(4 * (t & 31) + j) * BLD + (t >> 5) + 8 * i] = r[4 * i + j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = t + 256 * i;
+            tile[(e >> 4) * BLD + (e & 15)] = r[i];
+        }
+    }
+}
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void sr_bgemm_tiled_kernel(SrBgemm g) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BT * BLD];  // [buffer][A | B][row][k]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    int z = blockIdx.z;
+    const int ks = z % g.ksplit;
+    z /= g.ksplit;
+    const int b2 = z % g.nb2, b1 = z / g.nb2;
+    const float* A = g.A + (long long)b1 * g.sa_b1 + (long long)b2 * g.sa_b2;
+    const float* B = g.B + (long long)b1 * g.sb_b1 + (long long)b2 * g.sb_b2;
+    float* C = g.C + (long long)b1 * g.sc_b1 + (long long)b2 * g.sc_b2;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int kchunk = (((g.K + g.ksplit - 1) / g.ksplit) + BK - 1) / BK * BK;
+    const int kbeg = ks * kchunk, kend = min(g.K, kbeg + kchunk);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.0f);
+    if (kbeg < kend) {
+        float ra[8], rb[8];
+        bg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, ra);
+        bg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, rb);
+        bg_store<MA>(lds[0][0], ra);
+        bg_store<MB>(lds[0][1], rb);
+        __syncthreads();
+        int cur = 0;
+        for (int k = kbeg; k < kend; k += BK) {
+            const bool more = k + BK < kend;
+            if (more) {
+                bg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, k + BK, kend, ra);
+                bg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, k + BK, kend, rb);
+            }
+            const float* ta = lds[cur][0] + (wm * 64 + li) * BLD + 4 * lg;
+            const float* tb = lds[cur][1] + (wn * 64 + li) * BLD + 4 * lg;
+            f32x4 av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                av[t] = *reinterpret_cast<const f32x4*>(ta + t * 16 * BLD);
+                bv[t] = *reinterpret_cast<const f32x4*>(tb + t * 16 * BLD);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+            if (more) {
+                bg_store<MA>(lds[cur ^ 1][0], ra);
+                bg_store<MB>(lds[cur ^ 1][1], rb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + 16 * nt + li;
+            if (n >= g.N) continue;
+            const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + 16 * mt + 4 * lg + r;
+                if (m >= g.M) continue;
+                float* c = C + (long long)m * g.sc_m + (long long)n * g.sc_n;
+                const float v = g.alpha * acc[mt][nt][r] + bias;
+                if (g.ksplit > 1)
+                    atomicAdd(c, v);
+                else if (g.accumulate)
+                    *c += v;
+                else
+                    *c = v;
+            }
+        }
+}
+
+template <int MA>
+int launch_tiled_b(const SrBgemm& g, int mb, dim3 grid, hipStream_t st) {
+    if (mb == 0)
+        hipLaunchKernelGGL((sr_bgemm_tiled_kernel<MA, 0>), grid, dim3(256), 0, st, g);
+    else if (mb == 1)
+        hipLaunchKernelGGL((sr_bgemm_tiled_kernel<MA, 1>), grid, dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((sr_bgemm_tiled_kernel<MA, 2>), grid, dim3(256), 0, st, g);
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- im2col / col2im, column order (tap, c)
+// col[m][tap*C + c] = x[b, y + tap/3 - 1, x + tap%3 - 1, c]: every read and write is contiguous over c (the caller permutes the small
+// OIHW weight to [O][tap][C] instead of making the big buffer follow OIHW's (c, tap) order)
+template <int V>  // V channels per thread (4: C % 4 == 0 and unit channel stride)
+__global__ void sr_im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C, long long sb, long long sy, long long sx, long long sc) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CV = C / V;
+    const long long total = (long long)B * H * W * 9 * CV;
+    if (idx >= total) return;
+    const int c = (int)(idx % CV) * V;
+    const int t = (int)((idx / CV) % 9);
+    const long long m = idx / (9LL * CV);
+    const int xx = (int)(m % W);
+    const int yy = (int)((m / W) % H);
+    const long long b = m / ((long long)W * H);
+    const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+    const bool in = (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W;
+    float* dst = col + m * (9LL * C) + t * C + c;
+    if (V == 4) {
+        *reinterpret_cast<f32x4u*>(dst) = in ? *reinterpret_cast<const f32x4u*>(x + b * sb + y2 * sy + x2 * sx + c) : (f32x4u)(0.0f);
+    } else {
+        dst[0] = in ? x[b * sb + y2 * sy + x2 * sx + c * sc] : 0.0f;
+    }
+}
+// dx[b,y,x,c] = sum_tap dcol[(b, y - dy, x - dx)][tap*C + c]  (the adjoint of im2col written as a gather)
 __global__ void sr_col2im3x3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W, int C) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)B * H * W * C;
@@ -124,7 +294,7 @@ __global__ void sr_col2im3x3_kernel(const float* __restrict__ dcol, float* __res
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int y2 = yy - (t / 3 - 1), x2 = xx - (t % 3 - 1);  // the pixel whose tap t looked at (yy, xx)
-        if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) s += dcol[((b * H + y2) * W + x2) * (9LL * C) + 9 * c + t];
+        if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) s += dcol[((b * H + y2) * W + x2) * (9LL * C) + t * C + c];
     }
     dx[idx] = s;
 }
@@ -254,16 +424,26 @@ __global__ void sr_ln_bwd_kernel(const float* __restrict__ x, const float* __res
 }
 
 // out[b][c] += alpha * sum_{p in chunk} x[b][p][c]   (bias gradients, pooling; rows p, columns c contiguous)
-constexpr int COLSUM_ROWS = 128;
-__global__ void sr_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long P, int C, float alpha) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+constexpr int COLSUM_ROWS = 512;
+__global__ __launch_bounds__(256) void sr_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long P, int C, float alpha) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
     const long long b = blockIdx.z;
     const long long p0 = (long long)blockIdx.x * COLSUM_ROWS, p1 = min(P, p0 + COLSUM_ROWS);
     const float* xb = x + b * P * C;
-    float s = 0.f;
-    for (long long p = p0; p < p1; ++p) s += xb[p * C + c];
-    atomicAdd(out + b * C + c, alpha * s);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        long long p = p0 + rg;
+        for (; p + 4 < p1; p += 8) {
+            s0 += xb[p * C + c];
+            s1 += xb[(p + 4) * C + c];
+        }
+        if (p < p1) s0 += xb[p * C + c];
+    }
+    red[rg][cl] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < C) atomicAdd(out + b * C + c, alpha * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]));
 }
 // out[i] = sum_b x[b][i]  (relative-position-bias gradient: sum of dS over windows; deterministic, no atomics)
 __global__ void sr_batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long nb, long long n, long long stride_b) {
@@ -490,14 +670,30 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     SR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nb1 > 0 && g.nb2 > 0 && g.ksplit > 0, "sr_bgemm: bad sizes M=%d N=%d K=%d nb=%dx%d ksplit=%d", g.M, g.N, g.K, g.nb1, g.nb2, g.ksplit);
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
     SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large (batches x ksplit = %lld)", nz);
-    hipLaunchKernelGGL(sr_bgemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, (unsigned)nz), dim3(256), 0, ST, g);
+    static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
+    if (g.M >= 96 && g.N >= 24 && g.K >= 16 && !no_tiled && (g.M + BT - 1) / BT <= 65535) {
+        // 128 x 128 LDS-tiled kernel; the staging mode of each operand follows which of its axes is contiguous
+        const int ma = g.sa_k == 1 ? 0 : (g.sa_m == 1 ? 1 : 2), mb = g.sb_k == 1 ? 0 : (g.sb_n == 1 ? 1 : 2);
+        const dim3 grid((g.N + BT - 1) / BT, (g.M + BT - 1) / BT, (unsigned)nz);
+        if (ma == 0)
+            launch_tiled_b<0>(g, mb, grid, ST);
+        else if (ma == 1)
+            launch_tiled_b<1>(g, mb, grid, ST);
+        else
+            launch_tiled_b<2>(g, mb, grid, ST);
+    } else {
+        hipLaunchKernelGGL(sr_bgemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, (unsigned)nz), dim3(256), 0, ST, g);
+    }
     SR_CHECK_LAUNCH("sr_bgemm");
     return SR_OK;
 }
 
 extern "C" int sr_im2col3x3(const float* x, float* col, int B, int H, int W, int C, long long sb, long long sy, long long sx, long long sc, void* stream) {
     SR_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0, "sr_im2col3x3: bad arguments");
-    hipLaunchKernelGGL(sr_im2col3x3_kernel, flat_grid((long long)B * H * W * C), dim3(256), 0, ST, x, col, B, H, W, C, sb, sy, sx, sc);
+    if (C % 4 == 0 && sc == 1)
+        hipLaunchKernelGGL(sr_im2col3x3_kernel<4>, flat_grid((long long)B * H * W * 9 * (C / 4)), dim3(256), 0, ST, x, col, B, H, W, C, sb, sy, sx, sc);
+    else
+        hipLaunchKernelGGL(sr_im2col3x3_kernel<1>, flat_grid((long long)B * H * W * 9 * C), dim3(256), 0, ST, x, col, B, H, W, C, sb, sy, sx, sc);
     SR_CHECK_LAUNCH("sr_im2col3x3");
     return SR_OK;
 }
@@ -534,7 +730,7 @@ extern "C" int sr_layernorm_bwd(const float* x, const float* stats, const float*
 }
 extern "C" int sr_colsum(const float* x, float* out, int nb, long long P, int C, float alpha, void* stream) {
     SR_REQUIRE(x && out && nb > 0 && nb <= 65535 && P > 0 && C > 0, "sr_colsum: bad arguments");
-    hipLaunchKernelGGL(sr_colsum_kernel, dim3((unsigned)((P + COLSUM_ROWS - 1) / COLSUM_ROWS), (C + 63) / 64, nb), dim3(64), 0, ST, x, out, P, C, alpha);
+    hipLaunchKernelGGL(sr_colsum_kernel, dim3((unsigned)((P + COLSUM_ROWS - 1) / COLSUM_ROWS), (C + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
     SR_CHECK_LAUNCH("sr_colsum");
     return SR_OK;
 }
