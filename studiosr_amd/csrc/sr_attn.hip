@@ -11,7 +11,7 @@
 //   the O^T accumulator gives every lane 4 consecutive features of one query -> 8/16-byte stores.
 // The -100 shift mask is recomputed from window coordinates (same labels as the reference's
 // calculate_mask) instead of being read from memory.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

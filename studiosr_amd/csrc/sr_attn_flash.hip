@@ -12,7 +12,7 @@
 //     (in place), so both land during the softmax; the only exposed global latency is the first block's;
 //   * `OcaKeys`: K gathered from the zero-bordered image, V^T from the zero-bordered planes (nn.Unfold is never materialised).
 // (Plain window attention keeps the register-only flash kernel of sr_attn.hip: with 256 keys it is as fast without LDS.)
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

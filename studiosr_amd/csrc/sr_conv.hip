@@ -2,7 +2,7 @@
 //
 // One workgroup (4 waves) produces a TH x 16 pixel tile of N_T = WN*NW*16 output channels:
 //   * the (TH+2) x 18 input halo tile, ALL input channels, is staged once into LDS in the
-//     K-group-major image of sr_common.cuh (zero padding at the image border is written here);
+//     K-group-major image of sr_common.h (zero padding at the image border is written here);
 //   * an MFMA row tile is 16 horizontally adjacent output pixels, so its operand for tap
 //     (ky, kx) is 16 CONSECUTIVE rows of that image starting at (y+ky)*18 + kx: the nine
 //     shifted views are read from the one tile, conflict-free, with no im2col buffer;
@@ -14,7 +14,7 @@
 //     lane's 4 consecutive accumulators are 4 consecutive channels of ONE shuffled pixel), or the
 //     final un-normalise + crop + NCHW fp32 image.  Optionally emits per-tile channel sums for
 //     channel attention (deterministic, no atomics).
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

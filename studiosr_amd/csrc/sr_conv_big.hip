@@ -11,7 +11,7 @@
 //     channels (192: one phase, 123 KiB; 256: two phases of 128 channels, 82 KiB); the accumulators live across phases;
 //   * activation fragments are double buffered by half chunks (8 row tiles), weights run through a register ring;
 //   * taps are a run-time loop (9 iterations), the chunks of a tap are unrolled: code stays a few KiB.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

@@ -1,7 +1,7 @@
 // Memory-bound helpers around the MFMA kernels: image ingest (pad + normalise + NCHW->NHWC),
 // LayerNorm, standalone PixelShuffle and the channel-attention gate.  All HBM-bound: one pass,
 // 16-byte accesses, no LDS except the tiny channel-attention MLP.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

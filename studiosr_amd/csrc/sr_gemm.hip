@@ -12,7 +12,7 @@
 //     each lane owns 4 consecutive output features of one row -> 8/16-byte stores.  The V third
 //     of a QKV projection is produced un-swapped instead and stored transposed ([d][token]) so
 //     that the attention kernel can use it as an MFMA operand without any transpose.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

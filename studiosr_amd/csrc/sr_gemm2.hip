@@ -13,10 +13,10 @@
 //       72+ MFMAs ahead of use);
 //   t3  stores only.
 // No integer division anywhere: window geometry uses shifts (ws, ntok, hd_p are powers of two)
-// and host-computed multiply-shift constants (sr_common.cuh FastDiv).
+// and host-computed multiply-shift constants (sr_common.h FastDiv).
 // Two workgroups fit per CU (<= 48 KiB LDS, <= 256 VGPRs), so one's MFMA phase hides the
 // other's load / LayerNorm / store phases.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

@@ -13,7 +13,7 @@
 //   t5  + bias, 16-byte fp32 stores
 // 72 KiB of LDS -> two workgroups per CU, so one workgroup's VALU phases (LN, GELU) run beside
 // the other's MFMA phases.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {
@@ -30,7 +30,7 @@ __device__ unsigned long long sr_dbg_mlp[16];
 //     both bias vectors) -- a load placed after a store or in an epilogue costs a full exposed L2 round trip;
 //   * fc1 runs as two N-halves of 3 n-tiles: 12 live accumulator tiles instead of 24;
 //   * one sched_barrier per K-chunk keeps hipcc from sinking the ring loads or hoisting 50 of them at once;
-//   * GELU is the sigmoid form (sr_common.cuh gelu_bf16): with the erf polynomial the VALU time of this kernel
+//   * GELU is the sigmoid form (sr_common.h gelu_bf16): with the erf polynomial the VALU time of this kernel
 //     exceeded its MFMA time.
 template <int KC1, int KC2>
 __global__ __launch_bounds__(256, 2) void sr_mlp_kernel(SrMlp a) {

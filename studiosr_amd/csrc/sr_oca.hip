@@ -8,7 +8,7 @@
 //   * V^T fragments are two 8-byte loads from the transposed zero-bordered planes (4 consecutive keys of one
 //     neighbourhood row are 4 consecutive pixels),
 //   * the key count (576 / 144) is padded to a multiple of 32 with masked logits.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

@@ -3,7 +3,7 @@
 // Pure index shuffling + one optional multiply per element (attention scale on the q rows, swinir.py:83; LayerNorm gamma on the
 // columns when the affine is folded into the following Linear) -- bit-identical to studiosr_amd/packing.py (GPU test).
 // Fragment order (include/studiosr_hip.h): Wp[n_tile][k_chunk][lane][8], element (n = 16 n_tile + (lane & 15), k = 32 k_chunk + 8 (lane >> 4) + j).
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

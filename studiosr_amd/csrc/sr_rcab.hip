@@ -11,7 +11,7 @@
 //     inner 14); waves split 2 x 2 over (rows, output channels); weights stream L2 -> registers through a 3-slot ring;
 //   * K is walked tap-major exactly like sr_conv3x3, so y has the same bits as the two-launch path.
 // 76 KiB LDS -> two workgroups per CU.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

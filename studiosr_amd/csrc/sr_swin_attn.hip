@@ -18,7 +18,7 @@
 //       proj for output columns [32h, 32h+32) on top of the residual registers, 16-byte stores
 //       scattered back through the window map.
 // 2 x 75 KiB LDS and <= 168 VGPRs -> one 12-wave workgroup = 3 waves on every SIMD of a CU.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

@@ -19,7 +19,7 @@
 //     hidden image (24 KiB) reuses the K / V / O region.
 //   * x is read twice (token-row layout for LayerNorm1: statistics stay inside one wave, no barrier; accumulator layout as
 //     the residual) -- the second read hits L1 / L2 -- and written once.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 
 namespace {

@@ -12,7 +12,7 @@
 //     roll, OCA unfold, PixelShuffle, im2col / col2im -- gathers in both directions, never scatter-atomics) and flat elementwise ops.
 // All tensors are fp32 and UNPADDED (C = 180 stays 180): the reference's bf16 autocast contract (fp32 master weights, fp32 grads)
 // is exceeded, not approximated.  Speed-of-light kernels for this path are later rounds' work; the bar here is gradient parity.
-#include "sr_common.cuh"
+#include "sr_common.h"
 #include "sr_host.h"
 #include <algorithm>
 

@@ -44,8 +44,12 @@ class TileParallel:
             mine = self.fn(tiles[lo:hi].contiguous())
         else:  # more ranks than tiles: run one tile to learn the output shape, contribute nothing
             mine = self.fn(tiles[:1].contiguous())[:0]
+        out_dev = mine.device
+        if mine.is_cuda and dist.get_backend(self.group) != "nccl":  # only RCCL is ordered on the device stream: stage through the host
+            torch.cuda.current_stream(out_dev).synchronize()
+            mine = mine.cpu()
         pad = torch.zeros((n_max,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
         pad[: hi - lo] = mine
         gathered = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(gathered, pad, group=self.group)
-        return torch.cat([g[: b - a] for g, (a, b) in zip(gathered, parts)], dim=0)
+        return torch.cat([g[: b - a] for g, (a, b) in zip(gathered, parts)], dim=0).to(out_dev)

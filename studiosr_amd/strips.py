@@ -106,6 +106,12 @@ class DistStripComm(StripComm):
     def _peer(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
+    def _host_staged(self, t: Tensor) -> bool:
+        """RCCL ("nccl") p2p is ordered on the device stream.  Any other backend (gloo: CPU tests, several processes on one GPU) moves
+        device tensors through the host without ordering against the compute stream, so the halo is staged explicitly: wait for
+        the producing kernels, send from / receive into host buffers, copy back on the compute stream."""
+        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+
     def _shift(self, send, recv, cyclic: bool, step: int) -> None:
         n, r = self.world, self.rank
         (s,), (d,) = send, recv
@@ -115,16 +121,24 @@ class DistStripComm(StripComm):
         dst, src = r + step, r - step
         if cyclic:
             dst, src = dst % n, src % n
+        staged = self._host_staged(s)
+        if staged:
+            torch.cuda.current_stream(s.device).synchronize()
+            s_buf, d_buf = s.detach().cpu(), torch.empty(d.shape, dtype=d.dtype)
+        else:
+            s_buf, d_buf = s, d
         p2p = []
         if 0 <= dst < n:
-            p2p.append(dist.P2POp(dist.isend, s, self._peer(dst), self.group))
+            p2p.append(dist.P2POp(dist.isend, s_buf, self._peer(dst), self.group))
         if 0 <= src < n:
-            p2p.append(dist.P2POp(dist.irecv, d, self._peer(src), self.group))
+            p2p.append(dist.P2POp(dist.irecv, d_buf, self._peer(src), self.group))
         else:
             d.zero_()
         if p2p:
             for req in dist.batch_isend_irecv(p2p):
                 req.wait()
+        if staged and 0 <= src < n:
+            d.copy_(d_buf)
 
     def shift_up(self, send, recv, cyclic):
         self._shift(send, recv, cyclic, -1)
@@ -134,6 +148,10 @@ class DistStripComm(StripComm):
 
     def gather_rows(self, parts, dim):
         (mine,) = parts
+        out_dev = mine.device
+        if self._host_staged(mine):
+            torch.cuda.current_stream(out_dev).synchronize()
+            mine = mine.cpu()
         mine = mine.movedim(dim, 0).contiguous()
         n_rows = torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device)
         counts = [torch.empty_like(n_rows) for _ in range(self.world)]
@@ -143,7 +161,7 @@ class DistStripComm(StripComm):
         pad[: mine.shape[0]] = mine
         gathered = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(gathered, pad, group=self.group)
-        return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0).movedim(0, dim)
+        return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0).movedim(0, dim).to(out_dev)
 
 
 # --------------------------------------------------------------------------- strip buffers
