@@ -102,40 +102,40 @@ __global__ __launch_bounds__(256) void sr_bgemm_kernel(SrBgemm g) {
 // k values 4 lg .. 4 lg + 3, consumed by MFMA steps j = 0..3 (same k permutation on both operands as in the direct kernel).
 // Staging vectorises along whichever axis is contiguous: float4 along k (stride_k == 1) or float4 along rows (stride_row == 1).
 constexpr int BT = 128, BK = 16, BLD = 20;
+static_assert(16 * (BT + 4) <= BT * BLD, "the [k][row] tile must fit the [row][k] tile");
+
+// LDS tile of one operand: k-contiguous and generic operands are staged [row][16 k] (row stride BLD, fragment = one ds_read_b128);
+// row-contiguous operands are staged [16 k][row] (row stride KLD: the 16-byte stores of 4 consecutive rows are conflict-free, the
+// fragment is four ds_read_b32 whose 16 lanes read 16 consecutive rows).
+constexpr int KLD = BT + 4;
+constexpr int TILE_FLOATS = BT * BLD;  // >= 16 * KLD
 
 template <int MODE>  // 0: k contiguous, 1: row contiguous, 2: generic
 SR_DEV void bg_load(const float* __restrict__ base, long long s_row, long long s_k, int row0, int nrows, int k0, int kend, float (&r)[8]) {
     const int t = threadIdx.x;
-    const bool interior = row0 + BT <= nrows && k0 + BK <= kend;  // block-uniform: whole tile in range -> unguarded 16-byte loads
-    if (MODE == 0 && interior) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)(row0 + (t >> 2) + 64 * i) * s_row + k0 + 4 * (t & 3));
-            r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
-        }
-    } else if (MODE == 1 && interior) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)(k0 + (t >> 5) + 8 * i) * s_k + row0 + 4 * (t & 31));
-            r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
-        }
-    } else if (MODE == 0) {  // thread -> (row = t / 4 + 64 i, k quad = t % 4)
+    if (MODE == 0) {  // thread -> (row = t / 4 + 64 i, k quad = t % 4)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = row0 + (t >> 2) + 64 * i, k = k0 + 4 * (t & 3);
-            const float* p = base + (long long)min(row, nrows - 1) * s_row + min(k, kend - 1);
-            const bool rok = row < nrows;
+            if (row < nrows && k + 4 <= kend) {  // whole quad in range: one 16-byte load
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)row * s_row + k);
+                r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[4 * i + j] = (rok && k + j < kend) ? p[min(j, kend - 1 - min(k, kend - 1))] : 0.f;
+                for (int j = 0; j < 4; ++j) r[4 * i + j] = (row < nrows && k + j < kend) ? base[(long long)row * s_row + k + j] : 0.f;
+            }
         }
     } else if (MODE == 1) {  // thread -> (row quad = t % 32, k = t / 32 + 8 i)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = row0 + 4 * (t & 31), k = k0 + (t >> 5) + 8 * i;
-            const float* p = base + (long long)min(k, kend - 1) * s_k + min(row, nrows - 1);
-            const bool kok = k < kend;
+            if (k < kend && row + 4 <= nrows) {
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(base + (long long)k * s_k + row);
+                r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[4 * i + j] = (kok && row + j < nrows) ? p[min(j, nrows - 1 - min(row, nrows - 1))] : 0.f;
+                for (int j = 0; j < 4; ++j) r[4 * i + j] = (k < kend && row + j < nrows) ? base[(long long)k * s_k + row + j] : 0.f;
+            }
         }
     } else {
 #pragma unroll
@@ -152,11 +152,9 @@ SR_DEV void bg_store(float* __restrict__ tile, const float (&r)[8]) {
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(tile + ((t >> 2) + 64 * i) * BLD + 4 * (t & 3)) = f32x4{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
-    } else if (MODE == 1) {
+    } else if (MODE == 1) {  // [k][row]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tile[(4 * (t & 31) + j) * BLD + (t >> 5) + 8 * i] = r[4 * i + j];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(tile + ((t >> 5) + 8 * i) * KLD + 4 * (t & 31)) = f32x4{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -165,10 +163,19 @@ SR_DEV void bg_store(float* __restrict__ tile, const float (&r)[8]) {
         }
     }
 }
+// the four k values 4 lg .. 4 lg + 3 of row `row` of a staged tile
+template <int MODE>
+SR_DEV f32x4 bg_frag(const float* __restrict__ tile, int row, int lg) {
+    if (MODE == 1) {
+        const float* p = tile + (4 * lg) * KLD + row;
+        return f32x4{p[0], p[KLD], p[2 * KLD], p[3 * KLD]};
+    }
+    return *reinterpret_cast<const f32x4*>(tile + row * BLD + 4 * lg);
+}
 
 template <int MA, int MB>
 __global__ __launch_bounds__(256) void sr_bgemm_tiled_kernel(SrBgemm g) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BT * BLD];  // [buffer][A | B][row][k]
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];  // [buffer][A | B][tile]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
     const int li = lane & 15, lg = lane >> 4;
     int z = blockIdx.z;
@@ -200,13 +207,11 @@ __global__ __launch_bounds__(256) void sr_bgemm_tiled_kernel(SrBgemm g) {
                 bg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, k + BK, kend, ra);
                 bg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, k + BK, kend, rb);
             }
-            const float* ta = lds[cur][0] + (wm * 64 + li) * BLD + 4 * lg;
-            const float* tb = lds[cur][1] + (wn * 64 + li) * BLD + 4 * lg;
             f32x4 av[4], bv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                av[t] = *reinterpret_cast<const f32x4*>(ta + t * 16 * BLD);
-                bv[t] = *reinterpret_cast<const f32x4*>(tb + t * 16 * BLD);
+                av[t] = bg_frag<MA>(lds[cur][0], wm * 64 + t * 16 + li, lg);
+                bv[t] = bg_frag<MB>(lds[cur][1], wn * 64 + t * 16 + li, lg);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
