@@ -23,6 +23,9 @@ extern "C" {
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
+/* compute_dtype only (sr_gemm, sr_conv3x3): fp32 tensors, every contraction as hi*hi + hi*lo + lo*hi on the bf16 matrix cores
+ * (split operands, fp32 accumulate): fp32-class accuracy at 3 bf16 MFMAs per K-chunk.  Packed weights: per lane 8 hi then 8 lo. */
+enum { SR_BF16X3 = 2 };
 enum { SR_ACT_NONE_ = 0, SR_ACT_RELU_ = 1, SR_ACT_LRELU_ = 2, SR_ACT_GELU_ = 3 };
 enum { SR_PAD_NONE = 0, SR_PAD_EVAL_MIRROR = 1, SR_PAD_REFLECT = 2 };
 enum { SR_MAP_IDENTITY = 0, SR_MAP_WINDOW = 1 };

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "lib", "libstudi
 CSRC = os.path.join(_HERE, "csrc")
 
 SR_F32, SR_BF16 = 0, 1
+SR_BF16X3 = 2  # compute_dtype of sr_gemm / sr_conv3x3 only: split-operand bf16 (hi + lo), fp32 tensors
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
 PAD_NONE, PAD_EVAL_MIRROR, PAD_REFLECT = 0, 1, 2
 MAP_IDENTITY, MAP_WINDOW = 0, 1

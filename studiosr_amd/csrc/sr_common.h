@@ -26,6 +26,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// "bf16x3": a value carried as two bf16 numbers hi + lo (lo = bf16(x - hi)): 16 mantissa bits.  A product of two such operands is
+// evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation (the lo*lo term is below 2^-16 relative):
+// fp32-class accuracy at 3 bf16 MFMAs per K-chunk instead of the 8 quarter... 1/16-rate fp32 MFMAs of the exact path.
+struct bf3 {
+    bf16 hi, lo;
+};
+
 #define SR_DEV __device__ __forceinline__
 
 // In-kernel cycle stamps (diagnostic builds only: `make STAMPS=1`; see tools/stamp_test*.py).  One lane of one
@@ -48,7 +55,22 @@ struct __attribute__((aligned(16))) Frag<float> {
     f32x4 lo, hi;
 };
 
+template <>
+struct __attribute__((aligned(16))) Frag<bf3> {
+    bf16x8 hi, lo;
+};
+
 SR_DEV void frag_zero(Frag<bf16>& f) { f.v = (bf16x8)(0.0f); }
+SR_DEV void frag_zero(Frag<bf3>& f) {
+    f.hi = (bf16x8)(0.0f);
+    f.lo = (bf16x8)(0.0f);
+}
+SR_DEV Frag<bf3> frag_keep_if(bool keep, const Frag<bf3>& f) {
+    Frag<bf3> r;
+    r.hi = keep ? f.hi : (bf16x8)(0.0f);
+    r.lo = keep ? f.lo : (bf16x8)(0.0f);
+    return r;
+}
 SR_DEV void frag_zero(Frag<float>& f) {
     f.lo = (f32x4)(0.0f);
     f.hi = (f32x4)(0.0f);
@@ -94,9 +116,26 @@ SR_DEV Frag<float> frag_make<float>(const float* x) {
     return f;
 }
 
+template <>
+SR_DEV Frag<bf3> frag_make<bf3>(const float* x) {
+    Frag<bf3> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bf16 h = (bf16)x[j];
+        f.hi[j] = h;
+        f.lo[j] = (bf16)(x[j] - (float)h);
+    }
+    return f;
+}
+
 // C[i][j] += sum_k X[i][k] Y[j][k]; lane holds C col j = l&15, rows i = 4*(l>>4)+r.
 SR_DEV void mma(const Frag<bf16>& x, const Frag<bf16>& y, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, c, 0, 0, 0);
+}
+SR_DEV void mma(const Frag<bf3>& x, const Frag<bf3>& y, f32x4& c) {  // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.lo, y.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, y.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, y.hi, c, 0, 0, 0);
 }
 SR_DEV void mma(const Frag<float>& x, const Frag<float>& y, f32x4& c) {
 #pragma unroll
@@ -131,6 +170,16 @@ SR_DEV Frag<bf16> load_group<bf16, float>(const float* p) {
     f.v[6] = (bf16)b[2];
     f.v[7] = (bf16)b[3];
     return f;
+}
+
+template <>
+SR_DEV Frag<bf3> load_group<bf3, float>(const float* p) {
+    float v[8];
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return frag_make<bf3>(v);
 }
 
 SR_DEV void load8f(const float* p, float* v) {

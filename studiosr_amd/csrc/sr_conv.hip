@@ -391,6 +391,7 @@ extern "C" int sr_conv3x3(const SrConv3x3* p, void* stream) {
         if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 8>(c, st);
         return dispatch_conv<bf16, bf16, 8>(c, st);
     }
-    SR_REQUIRE(c.x_dtype == SR_F32, "sr_conv3x3: fp32 compute needs fp32 input");
+    SR_REQUIRE(c.x_dtype == SR_F32, "sr_conv3x3: fp32 / bf16x3 compute needs fp32 input");
+    if (c.compute_dtype == SR_BF16X3) return dispatch_conv<bf3, float, 4>(c, st);
     return dispatch_conv<float, float, 4>(c, st);
 }

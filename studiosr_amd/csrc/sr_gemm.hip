@@ -299,6 +299,7 @@ extern "C" int sr_gemm(const SrGemm* a, void* stream) {
         if (g.a_dtype == SR_F32) return dispatch_nw<bf16, float>(g, st);
         return dispatch_nw<bf16, bf16>(g, st);
     }
-    SR_REQUIRE(g.a_dtype == SR_F32, "sr_gemm: fp32 compute needs fp32 A");
+    SR_REQUIRE(g.a_dtype == SR_F32, "sr_gemm: fp32 / bf16x3 compute needs fp32 A");
+    if (g.compute_dtype == SR_BF16X3) return dispatch_nw<bf3, float>(g, st);
     return dispatch_nw<float, float>(g, st);
 }

@@ -74,14 +74,21 @@ class Model(nn.Module):
     def __call__(self, *args, **kwargs):
         """Launches go to the CURRENT device's current stream: make the input's device current for the whole forward
         (model.to('cuda:1') with device 0 current is the standard multi-GPU idiom)."""
-        x = args[0] if args else None
-        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
-            with torch.cuda.device(x.device):
-                return super().__call__(*args, **kwargs)
-        return super().__call__(*args, **kwargs)
+        from ..runtime import x3_mode
 
-    def _get_packed(self, dt: torch.dtype) -> Dict:
+        x = args[0] if args else None
+        with x3_mode(self.precision == "fp32x3"):
+            if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+                with torch.cuda.device(x.device):
+                    return super().__call__(*args, **kwargs)
+            return super().__call__(*args, **kwargs)
+
+    def _get_packed(self, dt) -> Dict:
         """Fragment-ordered weights for compute dtype dt, rebuilt when a parameter changes."""
+        if self.precision == "fp32x3" and dt == torch.float32:
+            from ..runtime import X3_KEY
+
+            dt = X3_KEY  # split-operand packing (hi | lo); everything else of the fp32 path is unchanged
         ver = self._param_version()
         ent = self._packed.get(dt)
         if ent is None or ent["__version__"] != ver:

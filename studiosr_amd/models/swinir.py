@@ -391,9 +391,11 @@ class SwinIR(Model):
     def forward_strips(self, x: Tensor, comm) -> Tensor:
         """forward() of ONE image, row-strip sharded with per-layer halo exchange (studiosr_amd/strips.py; SURVEY.md
         section 8e, config 4).  `comm` is a strips.DistStripComm (one strip per process / GPU) or a strips.LocalStripComm."""
+        from ..runtime import x3_mode
         from ..strips import swinir_forward_strips
 
-        return swinir_forward_strips(self, x, comm)
+        with x3_mode(self.precision == "fp32x3"):
+            return swinir_forward_strips(self, x, comm)
 
     # ------------------------------------------------------------------ reference API
     def get_model_config(self) -> Dict:

@@ -47,7 +47,15 @@ def layernorm(x: Tensor, out: Tensor, gamma: Tensor, beta: Tensor, C_real: int, 
     return out
 
 
+def _x3(kw) -> None:
+    from .runtime import x3_active
+
+    if kw.get("compute_dtype", L.SR_F32) == L.SR_F32 and x3_active():
+        kw["compute_dtype"] = L.SR_BF16X3
+
+
 def gemm(**kw) -> None:
+    _x3(kw)
     g = L.SrGemm()
     for k, v in kw.items():
         setattr(g, k, v)
@@ -77,6 +85,7 @@ def mlp_fused(**kw) -> None:
 
 
 def conv3x3(**kw) -> None:
+    _x3(kw)
     c = L.SrConv3x3()
     for k, v in kw.items():
         setattr(c, k, v)

@@ -48,6 +48,12 @@ def to_fragments(wm: Tensor, dtype: torch.dtype) -> Tensor:
     n_p, k_p = wm.shape
     assert n_p % 16 == 0 and k_p % 32 == 0, (n_p, k_p)
     t = wm.reshape(n_p // 16, 16, k_p // 32, 4, 8).permute(0, 2, 3, 1, 4)  # [ntile, kchunk, g, n16, j]
+    if isinstance(dtype, str):  # "bf16x3" (SR_BF16X3): per lane 8 hi then 8 lo bf16, lo = bf16(w - hi)
+        assert dtype == "bf16x3", dtype
+        t = t.contiguous().to(torch.float32)
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+        return torch.cat([hi, lo], dim=-1).contiguous().reshape(-1)
     return t.contiguous().to(dtype).reshape(-1)
 
 

@@ -21,10 +21,36 @@ def require_device(x: Tensor) -> None:
     L.lib()  # raises if libstudiosr_hip.so is missing
 
 
+X3_KEY = "bf16x3"  # key of the split-operand weight packing
+_x3_depth = 0      # > 0 while a forward with precision "fp32x3" is enqueueing (one forward at a time per process: SURVEY 8b)
+
+
+class x3_mode:
+    """While active, ops.gemm / ops.conv3x3 turn an fp32 compute request into SR_BF16X3 (split-operand bf16 on fp32 tensors)."""
+
+    def __init__(self, on: bool) -> None:
+        self.on = on
+
+    def __enter__(self):
+        global _x3_depth
+        _x3_depth += int(self.on)
+
+    def __exit__(self, *exc):
+        global _x3_depth
+        _x3_depth -= int(self.on)
+
+
+def x3_active() -> bool:
+    return _x3_depth > 0
+
+
 def compute_dtype(precision: str) -> torch.dtype:
     """'fp32' (reference inference semantics, exact-fp32 MFMA), 'bf16' (bf16 operands, fp32 accumulate,
-    fp32 residual stream / LayerNorm / softmax), or 'auto' = bf16 under torch.autocast(bfloat16) as in the
-    reference Trainer (studiosr/engine/trainer.py:80,102), fp32 otherwise."""
+    fp32 residual stream / LayerNorm / softmax), 'fp32x3' (fp32 tensors and op order as 'fp32', but every Linear / conv
+    contraction runs as hi*hi + hi*lo + lo*hi on the bf16 matrix cores: fp32-class accuracy several times faster), or
+    'auto' = bf16 under torch.autocast(bfloat16) as in the reference Trainer (studiosr/engine/trainer.py:80,102), fp32 otherwise."""
+    if precision == "fp32x3":
+        return torch.float32
     if precision == "auto":
         if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             return torch.bfloat16
@@ -33,7 +59,7 @@ def compute_dtype(precision: str) -> torch.dtype:
         return torch.bfloat16
     if precision == "fp32":
         return torch.float32
-    raise ValueError(f"precision must be 'auto', 'fp32' or 'bf16', got {precision!r}")
+    raise ValueError(f"precision must be 'auto', 'fp32', 'fp32x3' or 'bf16', got {precision!r}")
 
 
 def sr_dtype(dt: torch.dtype) -> int:

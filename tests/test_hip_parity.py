@@ -213,11 +213,12 @@ def test_swinir_x4_full_size_one_tile_against_oracle(swinir_full):
     m = m.to(DEV)
     u8 = lambda t: (t[0].permute(1, 2, 0) * 255.0).round().clip(0, 255).to(torch.uint8).numpy()  # noqa: E731
     p_ref = OMT.compute_psnr(u8(ref), tgt, y_only=True, crop_border=4)
-    for prec, tol, dtol in (("fp32", 5e-5, 1e-3), ("bf16", 2e-2, 1e-2)):
+    # fp32x3: fp32 tensors / op order, contractions as split-operand bf16 (hi*hi + hi*lo + lo*hi): must meet the metric's fp32 bar
+    for prec, tol, dtol in (("fp32", 5e-5, 1e-3), ("fp32x3", 3e-4, 1e-3), ("bf16", 2e-2, 1e-2)):
         m.set_precision(prec)
         with torch.no_grad():
             y = m(x.to(DEV)).cpu()
-        assert float((y - ref).abs().max()) <= tol * float(ref.abs().max()), prec
+        assert float((y - ref).abs().max()) <= tol * float(ref.abs().max()), (prec, float((y - ref).abs().max()))
         assert abs(OMT.compute_psnr(u8(y), tgt, y_only=True, crop_border=4) - p_ref) <= dtol, prec
     m.cpu()
 
@@ -350,7 +351,7 @@ def test_full_depth_one_tile_against_oracle(kind, cfg, oracle_fwd, train):
     m = m.to(DEV)
     m.train(train)  # HAT: the training forward's geometry (reflect pad, no-op at 64 = 4 x 16) with DropPath off
     rngv = max(1.0, float(ref.abs().max()))
-    for prec, tol, dtol in (("fp32", 5e-5, 1e-3), ("bf16", 3e-2, 1e-2)):
+    for prec, tol, dtol in (("fp32", 5e-5, 1e-3), ("fp32x3", 3e-4, 1e-3), ("bf16", 3e-2, 1e-2)):
         m.set_precision(prec)
         with torch.no_grad():
             y = m(x.to(DEV)).cpu()
