@@ -261,6 +261,9 @@ typedef struct SrBgemm {
     float alpha;
     int accumulate;                   /* ksplit == 1: C += instead of C = */
     int ksplit;
+    int compute_dtype;                /* SR_F32: exact fp32 MFMA.  SR_BF16: operands rounded to bf16 while staged, bf16 MFMA, fp32 accumulate
+                                       * (what torch.autocast(bfloat16) does to the reference's matmuls, trainer.py:80,102); large shapes only,
+                                       * small ones stay on the fp32 kernel */
 } SrBgemm;
 int sr_bgemm(const SrBgemm* g, void* stream);
 

@@ -110,7 +110,7 @@ class SrBgemm(C.Structure):
         ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("M", _i), ("N", _i), ("K", _i),
         ("sa_m", _ll), ("sa_k", _ll), ("sb_k", _ll), ("sb_n", _ll), ("sc_m", _ll), ("sc_n", _ll),
         ("nb1", _i), ("nb2", _i), ("sa_b1", _ll), ("sa_b2", _ll), ("sb_b1", _ll), ("sb_b2", _ll), ("sc_b1", _ll), ("sc_b2", _ll),
-        ("alpha", _f), ("accumulate", _i), ("ksplit", _i),
+        ("alpha", _f), ("accumulate", _i), ("ksplit", _i), ("compute_dtype", _i),
     ]
 
 

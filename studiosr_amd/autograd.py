@@ -36,8 +36,11 @@ def _chk(t: Tensor) -> Tensor:
 # --------------------------------------------------------------------------- raw launches
 def bgemm(A: Tensor, B: Tensor, Cc: Tensor, M: int, N: int, K: int, sa: Tuple[int, int], sb: Tuple[int, int], sc: Tuple[int, int], *,
           a_off: int = 0, b_off: int = 0, c_off: int = 0, bias: Optional[Tensor] = None, alpha: float = 1.0, accumulate: bool = False, ksplit: int = 1,
-          nb: Tuple[int, int] = (1, 1), sab=(0, 0), sbb=(0, 0), scb=(0, 0)) -> None:
-    """C[b][m,n] (=|+=) alpha * sum_k A[b][m,k] B[b][k,n] + bias[n]; strides in elements, offsets in elements from data_ptr."""
+          nb: Tuple[int, int] = (1, 1), sab=(0, 0), sbb=(0, 0), scb=(0, 0), bf16_ok: bool = True) -> None:
+    """C[b][m,n] (=|+=) alpha * sum_k A[b][m,k] B[b][k,n] + bias[n]; strides in elements, offsets in elements from data_ptr.
+    Under torch.autocast(bfloat16) (the reference Trainer's context) large contractions round their operands to bf16 and run on the
+    bf16 matrix cores with fp32 accumulation, exactly the reference's autocast contract; `bf16_ok=False` pins a call to exact fp32
+    (the DFT matrices of SwinFIR: torch.fft is not autocast to bf16 either)."""
     g = L.SrBgemm()
     g.A, g.B, g.C = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cc.data_ptr() + 4 * c_off
     g.bias = None if bias is None else bias.data_ptr()
@@ -50,7 +53,35 @@ def bgemm(A: Tensor, B: Tensor, Cc: Tensor, M: int, N: int, K: int, sa: Tuple[in
     g.sb_b1, g.sb_b2 = sbb
     g.sc_b1, g.sc_b2 = scb
     g.alpha, g.accumulate, g.ksplit = float(alpha), int(accumulate), int(ksplit)
+    g.compute_dtype = L.SR_BF16 if (bf16_ok and _autocast_bf16()) else L.SR_F32
     L.check(L.lib().sr_bgemm(C.byref(g), _st()), "sr_bgemm")
+
+
+_AUTOCAST_STATE = {"fwd": False}
+
+
+def _autocast_bf16() -> bool:
+    """bf16 autocast active for THIS launch: read live in forward; backward runs outside the context manager, so every Function records
+    the state it was built under (torch does the same: autocast backward ops run in the dtype their forward ran in)."""
+    return _AUTOCAST_STATE["fwd"]
+
+
+class autocast_state:
+    """with autocast_state(flag): ... -- sets what bgemm() sees.  Functions wrap forward (flag = torch state) and backward (flag = saved)."""
+
+    def __init__(self, flag: bool) -> None:
+        self.flag = flag
+
+    def __enter__(self):
+        self.prev = _AUTOCAST_STATE["fwd"]
+        _AUTOCAST_STATE["fwd"] = self.flag
+
+    def __exit__(self, *exc):
+        _AUTOCAST_STATE["fwd"] = self.prev
+
+
+def torch_autocast_bf16() -> bool:
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
 def _ksplit(rows: int, cols: int, K: int) -> int:
@@ -77,33 +108,36 @@ class _Linear(Fn):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        x, w = _chk(x), _chk(w)
-        K = x.shape[-1]
-        M = x.numel() // K
-        N = w.shape[0]
-        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-        bgemm(x, w, y, M, N, K, (K, 1), (1, K), (N, 1), bias=None if b is None else _chk(b))
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return y
+        ctx.ac = torch_autocast_bf16()
+        with autocast_state(ctx.ac):
+            x, w = _chk(x), _chk(w)
+            K = x.shape[-1]
+            M = x.numel() // K
+            N = w.shape[0]
+            y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+            bgemm(x, w, y, M, N, K, (K, 1), (1, K), (N, 1), bias=None if b is None else _chk(b))
+            ctx.save_for_backward(x, w)
+            ctx.has_bias = b is not None
+            return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = _chk(dy)
-        K = x.shape[-1]
-        M = x.numel() // K
-        N = w.shape[0]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
-        if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            bgemm(dy, x, dw, N, K, M, (1, N), (K, 1), (K, 1), ksplit=_ksplit(N, K, M))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, torch.zeros(N, device=dy.device), 1, M, N)
-        return dx, dw, db
+        with autocast_state(ctx.ac):
+            x, w = ctx.saved_tensors
+            dy = _chk(dy)
+            K = x.shape[-1]
+            M = x.numel() // K
+            N = w.shape[0]
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
+            if ctx.needs_input_grad[1]:
+                dw = torch.zeros_like(w)
+                bgemm(dy, x, dw, N, K, M, (1, N), (K, 1), (K, 1), ksplit=_ksplit(N, K, M))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy, torch.zeros(N, device=dy.device), 1, M, N)
+            return dx, dw, db
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -126,40 +160,43 @@ class _Conv3x3(Fn):
 
     @staticmethod
     def forward(ctx, x, w, b, cin):
-        x, w = _chk(x), _chk(w)  # w: [Cout, Cin, 3, 3]
-        B, H, W = x.shape[:3]
-        ld = x.shape[3]  # cin < ld: the input is a channel-padded buffer (the ingest kernel's NHWC-32 image)
-        Cout = w.shape[0]
-        w2 = w.permute(0, 2, 3, 1).contiguous()  # [Cout, (ky, kx), Cin]
-        col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-        y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
-        bgemm(col, w2, y, B * H * W, Cout, 9 * cin, (9 * cin, 1), (1, 9 * cin), (Cout, 1), bias=None if b is None else _chk(b))
-        ctx.save_for_backward(x, w2)
-        ctx.cin, ctx.has_bias = cin, b is not None
-        return y
+        ctx.ac = torch_autocast_bf16()
+        with autocast_state(ctx.ac):
+            x, w = _chk(x), _chk(w)  # w: [Cout, Cin, 3, 3]
+            B, H, W = x.shape[:3]
+            ld = x.shape[3]  # cin < ld: the input is a channel-padded buffer (the ingest kernel's NHWC-32 image)
+            Cout = w.shape[0]
+            w2 = w.permute(0, 2, 3, 1).contiguous()  # [Cout, (ky, kx), Cin]
+            col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
+            y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float32)
+            bgemm(col, w2, y, B * H * W, Cout, 9 * cin, (9 * cin, 1), (1, 9 * cin), (Cout, 1), bias=None if b is None else _chk(b))
+            ctx.save_for_backward(x, w2)
+            ctx.cin, ctx.has_bias = cin, b is not None
+            return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w2 = ctx.saved_tensors
-        dy = _chk(dy)
-        B, H, W = x.shape[:3]
-        ld, cin = x.shape[3], ctx.cin
-        Cout, M, K = w2.shape[0], B * H * W, 9 * cin
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            assert ld == cin, "no input gradient through a channel-padded input buffer"
-            dcol = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            bgemm(dy, w2, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
-            dx = torch.empty_like(x)
-            L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
-        if ctx.needs_input_grad[1]:
-            col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-            dw2 = torch.zeros(Cout, K, device=dy.device, dtype=torch.float32)
-            bgemm(dy, col, dw2, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
-            dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, torch.zeros(Cout, device=dy.device), 1, M, Cout)
-        return dx, dw, db, None
+        with autocast_state(ctx.ac):
+            x, w2 = ctx.saved_tensors
+            dy = _chk(dy)
+            B, H, W = x.shape[:3]
+            ld, cin = x.shape[3], ctx.cin
+            Cout, M, K = w2.shape[0], B * H * W, 9 * cin
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                assert ld == cin, "no input gradient through a channel-padded input buffer"
+                dcol = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+                bgemm(dy, w2, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
+                dx = torch.empty_like(x)
+                L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
+            if ctx.needs_input_grad[1]:
+                col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
+                dw2 = torch.zeros(Cout, K, device=dy.device, dtype=torch.float32)
+                bgemm(dy, col, dw2, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
+                dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy, torch.zeros(Cout, device=dy.device), 1, M, Cout)
+            return dx, dw, db, None
 
 
 def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], cin: Optional[int] = None) -> Tensor:
@@ -370,58 +407,61 @@ class _Attention(Fn):
 
     @staticmethod
     def forward(ctx, qs, kvs, table, rpi, mask, meta):
-        heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = meta
-        qs = _chk(qs)
-        kvs = qs if same else _chk(kvs)
-        table = _chk(table)
-        hd = Cn // heads
-        ldq, ldk = qs.shape[-1], kvs.shape[-1]
-        nbw = qs.numel() // ldq // Nq
-        dev = qs.device
-        P = torch.empty(nbw, heads, Nq, Nk, device=dev, dtype=torch.float32)
-        nbh = (nbw, heads)
-        bgemm(qs, kvs, P, Nq, Nk, hd, (ldq, 1), (1, ldk), (Nk, 1), a_off=q_off, b_off=k_off, alpha=scale, nb=nbh,
-              sab=(Nq * ldq, hd), sbb=(Nk * ldk, hd), scb=(heads * Nq * Nk, Nq * Nk))
-        bias = _gather_bias(table, rpi, heads)
-        nW = mask.shape[0] if mask is not None else 0
-        L.check(L.lib().sr_softmax_fwd(P.data_ptr(), bias.data_ptr(), None if mask is None else mask.data_ptr(), nbw * heads * Nq, heads, Nq, Nk, nW, _st()), "sr_softmax_fwd")
-        O = torch.empty(nbw * Nq, Cn, device=dev, dtype=torch.float32)
-        bgemm(P, kvs, O, Nq, hd, Nk, (Nk, 1), (ldk, 1), (Cn, 1), b_off=v_off, nb=nbh, sab=(heads * Nq * Nk, Nq * Nk), sbb=(Nk * ldk, hd), scb=(Nq * Cn, hd))
-        ctx.save_for_backward(qs, kvs, P, rpi, table)
-        ctx.meta = meta
-        return O
+        ctx.ac = torch_autocast_bf16()
+        with autocast_state(ctx.ac):
+            heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = meta
+            qs = _chk(qs)
+            kvs = qs if same else _chk(kvs)
+            table = _chk(table)
+            hd = Cn // heads
+            ldq, ldk = qs.shape[-1], kvs.shape[-1]
+            nbw = qs.numel() // ldq // Nq
+            dev = qs.device
+            P = torch.empty(nbw, heads, Nq, Nk, device=dev, dtype=torch.float32)
+            nbh = (nbw, heads)
+            bgemm(qs, kvs, P, Nq, Nk, hd, (ldq, 1), (1, ldk), (Nk, 1), a_off=q_off, b_off=k_off, alpha=scale, nb=nbh,
+                  sab=(Nq * ldq, hd), sbb=(Nk * ldk, hd), scb=(heads * Nq * Nk, Nq * Nk))
+            bias = _gather_bias(table, rpi, heads)
+            nW = mask.shape[0] if mask is not None else 0
+            L.check(L.lib().sr_softmax_fwd(P.data_ptr(), bias.data_ptr(), None if mask is None else mask.data_ptr(), nbw * heads * Nq, heads, Nq, Nk, nW, _st()), "sr_softmax_fwd")
+            O = torch.empty(nbw * Nq, Cn, device=dev, dtype=torch.float32)
+            bgemm(P, kvs, O, Nq, hd, Nk, (Nk, 1), (ldk, 1), (Cn, 1), b_off=v_off, nb=nbh, sab=(heads * Nq * Nk, Nq * Nk), sbb=(Nk * ldk, hd), scb=(Nq * Cn, hd))
+            ctx.save_for_backward(qs, kvs, P, rpi, table)
+            ctx.meta = meta
+            return O
 
     @staticmethod
     def backward(ctx, dO):
-        qs, kvs, P, rpi, table = ctx.saved_tensors
-        heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = ctx.meta
-        dO = _chk(dO)
-        hd = Cn // heads
-        ldq, ldk = qs.shape[-1], kvs.shape[-1]
-        nbw = qs.numel() // ldq // Nq
-        nbh = (nbw, heads)
-        sP = (heads * Nq * Nk, Nq * Nk)
-        dev = dO.device
-        # columns outside the q / k / v slices receive no gradient: zero-filled unless the three slices tile the packed tensor
-        dq = torch.empty_like(qs) if (same and ldq == 3 * Cn) else torch.zeros_like(qs)
-        dkv = dq if same else torch.zeros_like(kvs)
-        # dP = dO v^T
-        dP = torch.empty_like(P)
-        bgemm(dO, kvs, dP, Nq, Nk, hd, (Cn, 1), (1, ldk), (Nk, 1), b_off=v_off, nb=nbh, sab=(Nq * Cn, hd), sbb=(Nk * ldk, hd), scb=sP)
-        # dv = P^T dO
-        bgemm(P, dO, dkv, Nk, hd, Nq, (1, Nk), (Cn, 1), (ldk, 1), c_off=v_off, nb=nbh, sab=sP, sbb=(Nq * Cn, hd), scb=(Nk * ldk, hd))
-        # dS = P * (dP - rowsum(dP * P))
-        L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), nbw * heads * Nq, Nk, _st()), "sr_softmax_bwd")
-        dtable = None
-        if ctx.needs_input_grad[2]:
-            dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
-            L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
-            dtable = torch.zeros_like(table)
-            L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
-        # dq = scale * dS k ; dk = scale * dS^T q
-        bgemm(dP, kvs, dq, Nq, hd, Nk, (Nk, 1), (ldk, 1), (ldq, 1), b_off=k_off, c_off=q_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nk * ldk, hd), scb=(Nq * ldq, hd))
-        bgemm(dP, qs, dkv, Nk, hd, Nq, (1, Nk), (ldq, 1), (ldk, 1), b_off=q_off, c_off=k_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nq * ldq, hd), scb=(Nk * ldk, hd))
-        return dq, (None if same else dkv), dtable, None, None, None
+        with autocast_state(ctx.ac):
+            qs, kvs, P, rpi, table = ctx.saved_tensors
+            heads, Nq, Nk, Cn, scale, q_off, k_off, v_off, same = ctx.meta
+            dO = _chk(dO)
+            hd = Cn // heads
+            ldq, ldk = qs.shape[-1], kvs.shape[-1]
+            nbw = qs.numel() // ldq // Nq
+            nbh = (nbw, heads)
+            sP = (heads * Nq * Nk, Nq * Nk)
+            dev = dO.device
+            # columns outside the q / k / v slices receive no gradient: zero-filled unless the three slices tile the packed tensor
+            dq = torch.empty_like(qs) if (same and ldq == 3 * Cn) else torch.zeros_like(qs)
+            dkv = dq if same else torch.zeros_like(kvs)
+            # dP = dO v^T
+            dP = torch.empty_like(P)
+            bgemm(dO, kvs, dP, Nq, Nk, hd, (Cn, 1), (1, ldk), (Nk, 1), b_off=v_off, nb=nbh, sab=(Nq * Cn, hd), sbb=(Nk * ldk, hd), scb=sP)
+            # dv = P^T dO
+            bgemm(P, dO, dkv, Nk, hd, Nq, (1, Nk), (Cn, 1), (ldk, 1), c_off=v_off, nb=nbh, sab=sP, sbb=(Nq * Cn, hd), scb=(Nk * ldk, hd))
+            # dS = P * (dP - rowsum(dP * P))
+            L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), nbw * heads * Nq, Nk, _st()), "sr_softmax_bwd")
+            dtable = None
+            if ctx.needs_input_grad[2]:
+                dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
+                L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
+                dtable = torch.zeros_like(table)
+                L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
+            # dq = scale * dS k ; dk = scale * dS^T q
+            bgemm(dP, kvs, dq, Nq, hd, Nk, (Nk, 1), (ldk, 1), (ldq, 1), b_off=k_off, c_off=q_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nk * ldk, hd), scb=(Nq * ldq, hd))
+            bgemm(dP, qs, dkv, Nk, hd, Nq, (1, Nk), (ldq, 1), (ldk, 1), b_off=q_off, c_off=k_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nq * ldq, hd), scb=(Nk * ldk, hd))
+            return dq, (None if same else dkv), dtable, None, None, None
 
 
 def window_attention_packed(qkv: Tensor, table: Tensor, rpi: Tensor, mask: Optional[Tensor], heads: int, N: int, Cn: int) -> Tensor:
@@ -649,30 +689,33 @@ class _LayerAttention(Fn):
 
     @staticmethod
     def forward(ctx, x):
-        x = _chk(x)
-        B, N, D = x.shape
-        E = torch.zeros(B, N, N, device=x.device, dtype=torch.float32)
-        bgemm(x, x, E, N, N, D, (D, 1), (1, D), (N, 1), alpha=-1.0, nb=(B, 1), sab=(N * D, 0), sbb=(N * D, 0), scb=(N * N, 0), ksplit=_ksplit(N, N, D))
-        L.check(L.lib().sr_softmax_fwd(E.data_ptr(), None, None, B * N, 1, N, N, 0, _st()), "sr_softmax_fwd")
-        out = torch.empty_like(x)
-        bgemm(E, x, out, N, D, N, (N, 1), (D, 1), (D, 1), nb=(B, 1), sab=(N * N, 0), sbb=(N * D, 0), scb=(N * D, 0))
-        ctx.save_for_backward(x, E)
-        return out
+        ctx.ac = torch_autocast_bf16()
+        with autocast_state(ctx.ac):
+            x = _chk(x)
+            B, N, D = x.shape
+            E = torch.zeros(B, N, N, device=x.device, dtype=torch.float32)
+            bgemm(x, x, E, N, N, D, (D, 1), (1, D), (N, 1), alpha=-1.0, nb=(B, 1), sab=(N * D, 0), sbb=(N * D, 0), scb=(N * N, 0), ksplit=_ksplit(N, N, D))
+            L.check(L.lib().sr_softmax_fwd(E.data_ptr(), None, None, B * N, 1, N, N, 0, _st()), "sr_softmax_fwd")
+            out = torch.empty_like(x)
+            bgemm(E, x, out, N, D, N, (N, 1), (D, 1), (D, 1), nb=(B, 1), sab=(N * N, 0), sbb=(N * D, 0), scb=(N * D, 0))
+            ctx.save_for_backward(x, E)
+            return out
 
     @staticmethod
     def backward(ctx, dO):
-        x, P = ctx.saved_tensors
-        dO = _chk(dO)
-        B, N, D = x.shape
-        nb, sx, sp = (B, 1), (N * D, 0), (N * N, 0)
-        dP = torch.zeros_like(P)
-        bgemm(dO, x, dP, N, N, D, (D, 1), (1, D), (N, 1), nb=nb, sab=sx, sbb=sx, scb=sp, ksplit=_ksplit(N, N, D))
-        dx = torch.empty_like(x)
-        bgemm(P, dO, dx, N, D, N, (1, N), (D, 1), (D, 1), nb=nb, sab=sp, sbb=sx, scb=sx)  # P^T dO
-        L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), B * N, N, _st()), "sr_softmax_bwd")
-        bgemm(dP, x, dx, N, D, N, (N, 1), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS x)
-        bgemm(dP, x, dx, N, D, N, (1, N), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS^T x)
-        return dx
+        with autocast_state(ctx.ac):
+            x, P = ctx.saved_tensors
+            dO = _chk(dO)
+            B, N, D = x.shape
+            nb, sx, sp = (B, 1), (N * D, 0), (N * N, 0)
+            dP = torch.zeros_like(P)
+            bgemm(dO, x, dP, N, N, D, (D, 1), (1, D), (N, 1), nb=nb, sab=sx, sbb=sx, scb=sp, ksplit=_ksplit(N, N, D))
+            dx = torch.empty_like(x)
+            bgemm(P, dO, dx, N, D, N, (1, N), (D, 1), (D, 1), nb=nb, sab=sp, sbb=sx, scb=sx)  # P^T dO
+            L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), B * N, N, _st()), "sr_softmax_bwd")
+            bgemm(dP, x, dx, N, D, N, (N, 1), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS x)
+            bgemm(dP, x, dx, N, D, N, (1, N), (D, 1), (D, 1), alpha=-1.0, accumulate=True, nb=nb, sab=sp, sbb=sx, scb=sx)   # -(dS^T x)
+            return dx
 
 
 def layer_attention(x: Tensor) -> Tensor:

@@ -261,6 +261,133 @@ int launch_tiled_b(const SrBgemm& g, int mb, dim3 grid, hipStream_t st) {
     return 0;
 }
 
+// ----------------------------------------------------------------------------- the tiled GEMM with bf16 operands (autocast contract)
+// Same 128 x 128 tile / 4 waves of 64 x 64, but the fp32 operands are rounded to bf16 while they are staged (what torch.autocast does to
+// the reference's matmuls, studiosr/engine/trainer.py:80,102), K advances 32 per step and the MFMA is v_mfma_f32_16x16x32_bf16 (16x the
+// fp32 matrix rate), fp32 accumulate.  LDS tile [row][32 k] bf16 with an 80-byte row stride: the fragment (8 consecutive k of one row)
+// is one conflict-free ds_read_b128.  Staging: a k-contiguous operand gives each thread 8 consecutive k of one row (two 16-byte
+// loads); a row-contiguous operand gives each thread 16 k of ONE row (16 loads, each a coalesced 256 B per wave) so that the LDS
+// writes are 16-byte rows again instead of transposed 2-byte scatters.
+constexpr int HK = 32, HLD = 40;  // bf16 elements per row incl. pad
+
+template <int MODE>
+SR_DEV void hg_load(const float* __restrict__ base, long long s_row, long long s_k, int row0, int nrows, int k0, int kend, float (&v)[16]) {
+    const int t = threadIdx.x;
+    if (MODE == 0) {  // thread -> (row = t / 4 + 64 i, k octet = t % 4): v[8 i .. 8 i + 7]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + (t >> 2) + 64 * i, k = k0 + 8 * (t & 3);
+            if (row < nrows && k + 8 <= kend) {
+                const f32x4u a = *reinterpret_cast<const f32x4u*>(base + (long long)row * s_row + k), b = *reinterpret_cast<const f32x4u*>(base + (long long)row * s_row + k + 4);
+                v[8 * i] = a[0]; v[8 * i + 1] = a[1]; v[8 * i + 2] = a[2]; v[8 * i + 3] = a[3];
+                v[8 * i + 4] = b[0]; v[8 * i + 5] = b[1]; v[8 * i + 6] = b[2]; v[8 * i + 7] = b[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[8 * i + j] = (row < nrows && k + j < kend) ? base[(long long)row * s_row + k + j] : 0.f;
+            }
+        }
+    } else {  // row-contiguous or generic: thread -> (row = t % 128, 16 k = 16 (t / 128) ..)
+        const int row = row0 + (t & 127), kb = k0 + 16 * (t >> 7);
+        if (row < nrows && kb + 16 <= kend) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = base[(long long)row * s_row + (long long)(kb + j) * s_k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float x = base[(long long)min(row, nrows - 1) * s_row + (long long)min(kb + j, kend - 1) * s_k];
+                v[j] = (row < nrows && kb + j < kend) ? x : 0.f;
+            }
+        }
+    }
+}
+template <int MODE>
+SR_DEV void hg_store(bf16* __restrict__ tile, const float (&v)[16]) {
+    const int t = threadIdx.x;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<Frag<bf16>*>(tile + ((t >> 2) + 64 * i) * HLD + 8 * (t & 3)) = frag_from8(v + 8 * i);
+    } else {
+        bf16* p = tile + (t & 127) * HLD + 16 * (t >> 7);
+        *reinterpret_cast<Frag<bf16>*>(p) = frag_from8(v);
+        *reinterpret_cast<Frag<bf16>*>(p + 8) = frag_from8(v + 8);
+    }
+}
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[2][2][BT * HLD];  // [buffer][A | B][row][k]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    int z = blockIdx.z;
+    const int ks = z % g.ksplit;
+    z /= g.ksplit;
+    const int b2 = z % g.nb2, b1 = z / g.nb2;
+    const float* A = g.A + (long long)b1 * g.sa_b1 + (long long)b2 * g.sa_b2;
+    const float* B = g.B + (long long)b1 * g.sb_b1 + (long long)b2 * g.sb_b2;
+    float* C = g.C + (long long)b1 * g.sc_b1 + (long long)b2 * g.sc_b2;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int kchunk = (((g.K + g.ksplit - 1) / g.ksplit) + HK - 1) / HK * HK;
+    const int kbeg = ks * kchunk, kend = min(g.K, kbeg + kchunk);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.0f);
+    if (kbeg < kend) {
+        float ra[16], rb[16];
+        hg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, ra);
+        hg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, rb);
+        hg_store<MA>(lds[0][0], ra);
+        hg_store<MB>(lds[0][1], rb);
+        __syncthreads();
+        int cur = 0;
+        for (int k = kbeg; k < kend; k += HK) {
+            const bool more = k + HK < kend;
+            if (more) {  // the global loads of step t+1 travel under the MFMAs of step t
+                hg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, k + HK, kend, ra);
+                hg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, k + HK, kend, rb);
+            }
+            Frag<bf16> av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                av[t] = *reinterpret_cast<const Frag<bf16>*>(lds[cur][0] + (wm * 64 + t * 16 + li) * HLD + 8 * lg);
+                bv[t] = *reinterpret_cast<const Frag<bf16>*>(lds[cur][1] + (wn * 64 + t * 16 + li) * HLD + 8 * lg);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt].v, bv[nt].v, acc[mt][nt], 0, 0, 0);
+            if (more) {
+                hg_store<MA>(lds[cur ^ 1][0], ra);
+                hg_store<MB>(lds[cur ^ 1][1], rb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + 16 * nt + li;
+            if (n >= g.N) continue;
+            const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + 16 * mt + 4 * lg + r;
+                if (m >= g.M) continue;
+                float* c = C + (long long)m * g.sc_m + (long long)n * g.sc_n;
+                const float v = g.alpha * acc[mt][nt][r] + bias;
+                if (g.ksplit > 1)
+                    atomicAdd(c, v);
+                else if (g.accumulate)
+                    *c += v;
+                else
+                    *c = v;
+            }
+        }
+}
+
 // ----------------------------------------------------------------------------- im2col / col2im, column order (tap, c)
 // col[m][tap*C + c] = x[b, y + tap/3 - 1, x + tap%3 - 1, c]: every read and write is contiguous over c (the caller permutes the small
 // OIHW weight to [O][tap][C] instead of making the big buffer follow OIHW's (c, tap) order)
@@ -676,6 +803,20 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
     SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large (batches x ksplit = %lld)", nz);
     static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
+    if (g.compute_dtype == SR_BF16 && g.M >= 96 && g.N >= 24 && g.K >= 32 && (g.M + BT - 1) / BT <= 65535) {
+        const dim3 grid((g.N + BT - 1) / BT, (g.M + BT - 1) / BT, (unsigned)nz);
+        const bool a0 = g.sa_k == 1, b0 = g.sb_k == 1;
+        if (a0 && b0)
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 0>), grid, dim3(256), 0, ST, g);
+        else if (a0)
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 1>), grid, dim3(256), 0, ST, g);
+        else if (b0)
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<1, 0>), grid, dim3(256), 0, ST, g);
+        else
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<1, 1>), grid, dim3(256), 0, ST, g);
+        SR_CHECK_LAUNCH("sr_bgemm");
+        return SR_OK;
+    }
     if (g.M >= 96 && g.N >= 24 && g.K >= 16 && !no_tiled && (g.M + BT - 1) / BT <= 65535) {
         // 128 x 128 LDS-tiled kernel; the staging mode of each operand follows which of its axes is contiguous
         const int ma = g.sa_k == 1 ? 0 : (g.sa_m == 1 ? 1 : 2), mb = g.sb_k == 1 ? 0 : (g.sb_n == 1 ? 1 : 2);

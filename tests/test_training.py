@@ -70,6 +70,42 @@ def test_gradients_against_the_reference(tag, kind):
         assert m.inference(img).shape == (9 * cfg["scale"], 11 * cfg["scale"], 3)
 
 
+@pytest.mark.parametrize("tag,kind", [("hat", "HAT"), ("edsr", "EDSR"), ("swinir", "SwinIR"), ("rcan", "RCAN")])
+def test_gradients_under_bf16_autocast(tag, kind):
+    """The reference Trainer's context (trainer.py:80,102): under torch.autocast(bfloat16) the large contractions of forward AND backward
+    round their operands to bf16 (bf16 MFMA, fp32 accumulate) exactly as autocast does to the reference's matmuls; parameters, gradients
+    and everything else stay fp32.  Against the reference's fp32 gradients this is bf16-operand noise (2^-9 per operand, carried
+    through the whole backward chain).  Measured on these fixtures (tools/ac_stats.py): all gradients together 1.0-2.5e-2 relative
+    L2, the worst single tensor (a relative_position_bias_table / a bias, i.e. small sums of small terms) 6-8e-2.  Bounds: 4e-2 for
+    the whole gradient, 1.5e-1 per tensor, 2e-3 for the loss."""
+    g = load_golden(f"f15_grads_{tag}")
+    m = getattr(S, kind)(**golden_cfg(g))
+    m.load_state_dict(golden_sd(g))
+    m = m.to(DEV).train()
+    x, tgt = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["target"]).to(DEV)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        out = m(x)
+        loss = F.l1_loss(out, tgt)
+    assert out.dtype == torch.float32
+    assert abs(loss.item() - float(g["loss"])) <= 2e-3 * max(1.0, float(g["loss"]))
+    loss.backward()
+    ref = {k[len("grad/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("grad/")}
+    num = den = 0.0
+    for name, p in m.named_parameters():
+        if name not in ref:
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.float32, name
+        d, r = (p.grad.cpu() - ref[name]).double(), ref[name].double()
+        num, den = num + float((d * d).sum()), den + float((r * r).sum())
+        assert float(d.norm()) <= 0.15 * max(float(r.norm()), 1e-12), f"{name}: relative L2 {float(d.norm()) / max(float(r.norm()), 1e-12):.3e}"
+    assert (num / den) ** 0.5 <= 4e-2, f"whole gradient: relative L2 {(num / den) ** 0.5:.3e}"
+    # and it is a different computation from the fp32 path (the bf16 kernel really ran)
+    m.zero_grad()
+    F.l1_loss(m(x), tgt).backward()
+    p0 = next(p for n_, p in m.named_parameters() if n_.endswith("conv_first.weight") or n_.endswith("head.0.weight"))
+    assert float((p0.grad.cpu() - ref[[n_ for n_, p in m.named_parameters() if p is p0][0]]).abs().max()) <= GRAD_TOL * float(ref[[n_ for n_, p in m.named_parameters() if p is p0][0]].abs().max())
+
+
 def _oracle_grads(fwd, sd, x, tgt, cfg, training):
     sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "mean" not in k else v) for k, v in sd.items()}
     out = fwd(sdg, x, cfg, training=training)

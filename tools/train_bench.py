@@ -22,10 +22,12 @@ def main():
         opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.99))
         x, y = torch.rand(b, 3, 64, 64, device=dev), torch.rand(b, 3, 256, 256, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ac = os.environ.get("AUTOCAST", "1") != "0"  # the reference Trainer's bf16 autocast context (AUTOCAST=0: exact fp32 everywhere)
         for it in range(4):
             ev[0].record()
-            out = m(x)
-            loss = F.l1_loss(out, y)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=ac):
+                out = m(x)
+                loss = F.l1_loss(out, y)
             ev[1].record()
             loss.backward()
             ev[2].record()
@@ -34,7 +36,7 @@ def main():
             ev[3].record()
             torch.cuda.synchronize()
         t = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
-        print(f"{kind} x4 b{b}: forward {t[0]:.1f} ms  backward {t[1]:.1f} ms  adam {t[2]:.1f} ms  total {sum(t):.1f} ms  "
+        print(f"{kind} x4 b{b} {'autocast-bf16' if ac else 'fp32'}: forward {t[0]:.1f} ms  backward {t[1]:.1f} ms  adam {t[2]:.1f} ms  total {sum(t):.1f} ms  "
               f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB  loss {loss.item():.4f}", flush=True)
         del m, opt
         torch.cuda.empty_cache()
