@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 3
+#define SR_ABI_VERSION 4
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -170,6 +170,19 @@ typedef struct SrRcab {
     float* pool_partial;  /* optional [B, sr_rcab_pool_tiles(H, W), 64] */
     int B, H, W, C_p;     /* C_p must be 64 */
     int x_dtype, y_dtype;
+    /* Optional gated input (ABI v4): the channel-attention tail of the PREVIOUS RCAB (rcan.py:21-24: res = CA(body(x)); res += x) is
+     * folded into this launch's halo staging, so an RCAB is ONE launch instead of conv pair + sr_channel_attention:
+     *   x_eff = x + gate * gate_y,  gate = sigmoid(W2 relu(W1 mean(gate_y) + b1) + b2)  (mean from gate_pool, as sr_channel_attention)
+     * x_eff feeds conv1 and its tile interior is written to x_out (fp32 NHWC) -- the skip tensor of this RCAB.  x must be fp32,
+     * gate_y has y_dtype; neither may alias y / x_out / pool_partial.  gate_y == NULL: plain conv pair.  gate_Cr <= 8. */
+    const void* gate_y;        /* NHWC [B,H,W,64] y_dtype: conv-pair output of the previous RCAB */
+    const float* gate_pool;    /* its pool partials [B, sr_rcab_pool_tiles(H, W), 64] */
+    const float* gate_w1;      /* [Cr, C] */
+    const float* gate_b1;      /* [Cr] */
+    const float* gate_w2;      /* [C, Cr] */
+    const float* gate_b2;      /* [C] */
+    float* x_out;              /* NHWC [B,H,W,64] fp32 */
+    int gate_C, gate_Cr;
 } SrRcab;
 int sr_rcab_conv_pair(const SrRcab* a, void* stream);
 int sr_rcab_pool_tiles(int H, int W); /* n_tiles of pool_partial */

@@ -234,8 +234,13 @@ __global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
         const size_t off = (size_t)b * per_img * 4 + (size_t)i * 4;
         f32x4 v = ld4<float>(a.y, off, a.y_dtype);
         const f32x4 s = *reinterpret_cast<const f32x4*>(gate + g * 4);
-        v *= s;
-        if (a.skip) v += ld4<float>(a.skip, off, a.skip_dtype);
+        if (a.skip) {  // one fma per element (sr_rcab_conv_pair's gated input repeats exactly this)
+            const f32x4 k = ld4<float>(a.skip, off, a.skip_dtype);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], s[r], k[r]);
+        } else {
+            v *= s;
+        }
         if (a.skip2) v += ld4<float>(a.skip2, off, a.skip2_dtype);
         if (a.out_dtype == SR_BF16)
             store4(reinterpret_cast<bf16*>(a.out) + off, v);

@@ -11,6 +11,8 @@
 //     inner 14); waves split 2 x 2 over (rows, output channels); weights stream L2 -> registers through a 3-slot ring;
 //   * K is walked tap-major exactly like sr_conv3x3, so y has the same bits as the two-launch path.
 // 76 KiB LDS -> two workgroups per CU.
+// Gated form: the previous block's channel-attention tail (gate * y + skip) is applied while staging the halo, so a chain of RCABs is
+// one launch per block; only the last block of a residual group still needs the standalone sr_channel_attention.
 #include "sr_common.h"
 #include "sr_host.h"
 
@@ -27,7 +29,9 @@ constexpr int IN_ROWS = 328;       // 18 * 18 = 324 halo pixels, padded to a mul
 constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 1 margin cell, padded to a multiple of 8
 constexpr int RRING = 3;
 
-template <typename TIn, typename TOut>
+constexpr int GATE_SCRATCH = (8 * RC + RC + 8 + RC) * (int)sizeof(float);  // slice sums | mean | hidden | gate
+
+template <typename TIn, typename TOut, bool GATED>
 __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [RKG][IN_ROWS]
@@ -53,27 +57,139 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) br[s][n] = W1[((size_t)n * RKCT + s) * 64];
 
+    float gk[8];  // gated input: this lane's 8 channel gates
     // ---- stage the input halo (8 pixels x 8 K-groups per wave instruction: full 256-byte pixel rows), all loads of 3 passes in flight
     {
         const int r8 = lane & 7, kq = lane >> 3;
-        const TIn* xin = reinterpret_cast<const TIn*>(c.x);
         constexpr int NPASS = 3;
-        for (int pb = wave * 8; pb < IN_ROWS; pb += 32 * NPASS) {
-            Frag<bf16> f[NPASS];
-            bool valid[NPASS];
+        if constexpr (GATED) {
+            // x_eff = x + gate * gate_y (fp32, one fma per element as in sr_channel_attention); the tile interior goes back to HBM as this
+            // RCAB's skip.  Two rounds of 6 row passes; the loads of round 0 are in flight while the gate is computed.
+            constexpr int GP = 6;
+            const float* xin = reinterpret_cast<const float*>(c.x);
+            const TOut* yin = reinterpret_cast<const TOut*>(c.gate_y);  // the previous block's y: same dtype as this block's
+            float xv[GP][8], yv[GP][8];
+            bool valid[GP], interior[GP];
+            size_t off[GP];
+            auto issue = [&](int pb) {
 #pragma unroll
-            for (int u = 0; u < NPASS; ++u) {
-                const int p = pb + u * 32 + r8;
-                const int py = p / TIN, px = p - py * TIN;
-                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-                valid[u] = p < TIN * TIN && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
-                const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * RC + kq * 8;
-                f[u] = load_group<bf16, TIn>(src);
+                for (int u = 0; u < GP; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    const int py = p / TIN, px = p - py * TIN;
+                    const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                    valid[u] = p < TIN * TIN && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                    interior[u] = valid[u] && py >= 2 && py < 2 + TO && px >= 2 && px < 2 + TO;
+                    off[u] = ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * RC + kq * 8;
+                    load8f(xin + off[u], xv[u]);
+                    if constexpr (sizeof(TOut) == 4) {
+                        load8f(reinterpret_cast<const float*>(yin) + off[u], yv[u]);
+                    } else {
+                        const Frag<bf16> fy = *reinterpret_cast<const Frag<bf16>*>(yin + off[u]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) yv[u][i] = (float)fy.v[i];
+                    }
+                }
+            };
+            auto commit = [&](int pb) {
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    float e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e[i] = __builtin_fmaf(yv[u][i], gk[i], xv[u][i]);
+                    if (interior[u]) {
+                        store4(c.x_out + off[u], f32x4{e[0], e[1], e[2], e[3]});
+                        store4(c.x_out + off[u] + 4, f32x4{e[4], e[5], e[6], e[7]});
+                    }
+                    if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], frag_from8(e));
+                }
+            };
+            issue(wave * 8);
+            {
+                float* part = reinterpret_cast<float*>(Amid + RKG * MID_ROWS);  // [8][RC]
+                float* mean = part + 8 * RC;
+                float* hid = mean + RC;
+                float* gate = hid + 8;
+                const int tid = threadIdx.x, ch = tid & 63, sl = tid >> 6;
+                const int nt = tiles_x * tiles_y * 2, C = c.gate_C, Cr = c.gate_Cr;
+                float w1v[2], b1v[2], w2v[8], b2v = 0.f;
+        #pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = wave + 4 * u;
+                    w1v[u] = (j < Cr && lane < C) ? c.gate_w1[j * C + lane] : 0.f;
+                    b1v[u] = j < Cr ? c.gate_b1[j] : 0.f;
+                }
+        #pragma unroll
+                for (int j = 0; j < 8; ++j) w2v[j] = (tid < C && j < Cr) ? c.gate_w2[tid * Cr + j] : 0.f;
+                if (tid < C) b2v = c.gate_b2[tid];
+                float s0 = 0.f, s1 = 0.f;
+                if (ch < C) {
+                    const float* pp = c.gate_pool + (size_t)b * nt * RC + ch;
+                    for (int tt = sl; tt < nt; tt += 8) s0 += pp[(size_t)tt * RC];
+                    for (int tt = sl + 4; tt < nt; tt += 8) s1 += pp[(size_t)tt * RC];
+                }
+                part[sl * RC + ch] = s0;
+                part[(sl + 4) * RC + ch] = s1;
+                __syncthreads();
+                if (tid < RC) {
+                    float sum = 0.f;
+        #pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += part[q * RC + tid];
+                    mean[tid] = sum * (1.0f / (float)(c.H * c.W));
+                }
+                __syncthreads();
+        #pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = wave + 4 * u;
+                    if (j < Cr) {
+                        float sum = lane < C ? w1v[u] * mean[lane] : 0.f;
+        #pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                        if (lane == 0) {
+                            sum += b1v[u];
+                            hid[j] = sum > 0.f ? sum : 0.f;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid < RC) {
+                    float sum = 0.f;
+                    if (tid < C) {
+                        sum = b2v;
+        #pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j < Cr) sum += w2v[j] * hid[j];
+                        sum = 1.0f / (1.0f + __expf(-sum));
+                    }
+                    gate[tid] = sum;
+                }
+                __syncthreads();
+        #pragma unroll
+                for (int i = 0; i < 8; ++i) gk[i] = gate[(lane >> 3) * 8 + i];
             }
+            commit(wave * 8);
+            issue(wave * 8 + 32 * GP);
+            commit(wave * 8 + 32 * GP);
+            static_assert(2 * 32 * GP >= IN_ROWS, "two rounds cover the halo");
+        } else {
+            const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+            for (int pb = wave * 8; pb < IN_ROWS; pb += 32 * NPASS) {
+                Frag<bf16> f[NPASS];
+                bool valid[NPASS];
 #pragma unroll
-            for (int u = 0; u < NPASS; ++u) {
-                const int p = pb + u * 32 + r8;
-                if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], f[u]);
+                for (int u = 0; u < NPASS; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    const int py = p / TIN, px = p - py * TIN;
+                    const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                    valid[u] = p < TIN * TIN && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+                    const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * RC + kq * 8;
+                    f[u] = load_group<bf16, TIn>(src);
+                }
+#pragma unroll
+                for (int u = 0; u < NPASS; ++u) {
+                    const int p = pb + u * 32 + r8;
+                    if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], f[u]);
+                }
             }
         }
         if (threadIdx.x < 2 * RKG) {  // margin cells of the intermediate image (read by discarded edge columns only; keep them finite)
@@ -197,16 +313,16 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
     }
 }
 
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, bool GATED>
 int launch_rcab(const SrRcab& c, hipStream_t st) {
-    constexpr int lds = (RKG * IN_ROWS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>);
+    constexpr int lds = (RKG * IN_ROWS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>) + (GATED ? GATE_SCRATCH : 0);
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TIn, TOut>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TIn, TOut, GATED>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_rcab_conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int tiles = ((c.W + TO - 1) / TO) * ((c.H + TO - 1) / TO) * c.B;
-    hipLaunchKernelGGL((sr_rcab_kernel<TIn, TOut>), dim3(tiles), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_rcab_kernel<TIn, TOut, GATED>), dim3(tiles), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_rcab_conv_pair");
     return SR_OK;
 }
@@ -220,6 +336,13 @@ extern "C" int sr_rcab_conv_pair(const SrRcab* p, void* stream) {
     const SrRcab& c = *p;
     SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.C_p == RC, "sr_rcab_conv_pair: bad geometry (64 padded channels only)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (c.x_dtype == SR_F32) return c.y_dtype == SR_F32 ? launch_rcab<float, float>(c, st) : launch_rcab<float, bf16>(c, st);
-    return c.y_dtype == SR_F32 ? launch_rcab<bf16, float>(c, st) : launch_rcab<bf16, bf16>(c, st);
+    if (c.gate_y) {
+        SR_REQUIRE(c.x_dtype == SR_F32, "sr_rcab_conv_pair: the gated input needs fp32 x / gate_y");
+        SR_REQUIRE(c.gate_pool && c.gate_w1 && c.gate_b1 && c.gate_w2 && c.gate_b2 && c.x_out, "sr_rcab_conv_pair: gated input: null pointer");
+        SR_REQUIRE(c.gate_C > 0 && c.gate_C <= RC && c.gate_Cr > 0 && c.gate_Cr <= 8, "sr_rcab_conv_pair: gated input: C <= 64 and Cr <= 8");
+        SR_REQUIRE(c.x_out != c.x && c.x_out != c.y && c.gate_y != c.y && c.gate_pool != c.pool_partial, "sr_rcab_conv_pair: gated input: buffers alias");
+        return c.y_dtype == SR_F32 ? launch_rcab<float, float, true>(c, st) : launch_rcab<float, bf16, true>(c, st);
+    }
+    if (c.x_dtype == SR_F32) return c.y_dtype == SR_F32 ? launch_rcab<float, float, false>(c, st) : launch_rcab<float, bf16, false>(c, st);
+    return c.y_dtype == SR_F32 ? launch_rcab<bf16, float, false>(c, st) : launch_rcab<bf16, bf16, false>(c, st);
 }

@@ -113,20 +113,48 @@ class RCAN(Model):
         y = ws_.get("y", (B, H, W, Fp), f32)
         ga, gb = ws_.get("ga", (B, H, W, Fp), f32), ws_.get("gb", (B, H, W, Fp), f32)
         ra, rb = ws_.get("ra", (B, H, W, Fp), f32), ws_.get("rb", (B, H, W, Fp), f32)
+        # one launch per RCAB: block n+1 applies block n's channel-attention tail (gate * y + skip) while it stages its halo
+        # (sr_rcab_conv_pair's gated input); y / pool alternate because block n+1 reads block n's while writing its own
+        chained = fused_pair and self.n_feats // self.reduction <= 8
+        if chained:
+            # the branch output y is stored in the compute dtype (bf16; its pool sums are taken from the fp32 accumulators first): it is
+            # read once, multiplied by the gate and added to the fp32 skip stream -- 25 % less HBM traffic per block, >= 50 dB kept
+            y, y2, pool2 = ws_.get("yc", (B, H, W, Fp), cdt), ws_.get("y2", (B, H, W, Fp), cdt), ws_.get("pool2", (B, n_tiles, Fp), f32)
         g = h
         for blocks, gconv in P["groups"]:
             r = g
-            for (c1, c2, ca) in blocks:  # RCAB: r = CA(conv2(relu(conv1(r)))) + r
-                if fused_pair:
-                    ops.rcab_conv_pair(x=r.data_ptr(), w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(),
-                                       y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, C_p=Fp, x_dtype=sr_dtype(r.dtype),
-                                       y_dtype=sr_dtype(y.dtype))
-                else:
-                    conv_call(r, *c1, mid, cdt, act=L.ACT_RELU)
-                    conv_call(mid, *c2, y, cdt, pool=pool)
-                nxt = ra if (r is not ra) else rb
-                run_channel_attention(ca, y, pool, n_tiles, self.n_feats, nxt, skip=r)
-                r = nxt
+            if chained:
+                ys, pools, prev = (y, y2), (pool, pool2), None  # prev = (skip, y, pool, ca) of the block whose tail is still pending
+                for i, (c1, c2, ca) in enumerate(blocks):
+                    yc, pc = ys[i & 1], pools[i & 1]
+                    kw = dict(w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(), y=yc.data_ptr(),
+                              pool_partial=pc.data_ptr(), B=B, H=H, W=W, C_p=Fp, x_dtype=L.SR_F32, y_dtype=sr_dtype(yc.dtype))
+                    if prev is None:
+                        ops.rcab_conv_pair(x=r.data_ptr(), **kw)
+                    else:
+                        pr, py, pp, (w1, b1, w2, b2) = prev
+                        nxt = ra if (pr is not ra) else rb
+                        ops.rcab_conv_pair(x=pr.data_ptr(), gate_y=py.data_ptr(), gate_pool=pp.data_ptr(), gate_w1=w1.data_ptr(), gate_b1=b1.data_ptr(),
+                                           gate_w2=w2.data_ptr(), gate_b2=b2.data_ptr(), x_out=nxt.data_ptr(), gate_C=self.n_feats, gate_Cr=w1.shape[0], **kw)
+                        r = nxt
+                    prev = (r, yc, pc, ca)
+                if prev is not None:  # the last block's tail: standalone channel attention
+                    pr, py, pp, ca = prev
+                    nxt = ra if (pr is not ra) else rb
+                    run_channel_attention(ca, py, pp, n_tiles, self.n_feats, nxt, skip=pr)
+                    r = nxt
+            else:
+                for (c1, c2, ca) in blocks:  # RCAB: r = CA(conv2(relu(conv1(r)))) + r
+                    if fused_pair:
+                        ops.rcab_conv_pair(x=r.data_ptr(), w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(),
+                                           y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, C_p=Fp, x_dtype=sr_dtype(r.dtype),
+                                           y_dtype=sr_dtype(y.dtype))
+                    else:
+                        conv_call(r, *c1, mid, cdt, act=L.ACT_RELU)
+                        conv_call(mid, *c2, y, cdt, pool=pool)
+                    nxt = ra if (r is not ra) else rb
+                    run_channel_attention(ca, y, pool, n_tiles, self.n_feats, nxt, skip=r)
+                    r = nxt
             gn = ga if (g is not ga) else gb
             conv_call(r, *gconv, gn, cdt, skip=g)  # group conv + skip (rcan.py:33-36)
             g = gn

@@ -470,6 +470,45 @@ def test_rcab_pair_equals_two_conv_launches_bit_for_bit():
     torch.testing.assert_close(pool.sum(dim=1), want.sum(dim=(1, 2)), rtol=1e-4, atol=1e-2)
 
 
+def test_gated_rcab_equals_channel_attention_then_conv_pair():
+    """ABI v4 gated input of sr_rcab_conv_pair: x_eff = x + gate * y_prev folded into the halo staging must give the bits of the
+    two-launch sequence (sr_channel_attention -> plain sr_rcab_conv_pair): same skip tensor (x_out), same y, same pool partials."""
+    from studiosr_amd.models.rcan import pack_ca, run_channel_attention
+
+    torch.manual_seed(12)
+    B, H, W, Cc, Cr = 2, 30, 41, 64, 4
+    w1, w2 = torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05, torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(Cc, device=DEV) * 0.1, torch.randn(Cc, device=DEV) * 0.1
+    ident = packing.identity_idx(Cc, Cc)
+    c1, c2 = packing.pack_conv3x3(w1, b1, Cc, ident, torch.bfloat16), packing.pack_conv3x3(w2, b2, Cc, ident, torch.bfloat16)
+    ca = pack_ca(torch.randn(Cr, Cc, 1, 1, device=DEV) * 0.3, torch.randn(Cr, device=DEV) * 0.1, torch.randn(Cc, Cr, 1, 1, device=DEV) * 0.3,
+                 torch.randn(Cc, device=DEV) * 0.1)
+    n_tiles = ops.rcab_pool_tiles(H, W)
+    x_prev = torch.randn(B, H, W, Cc, device=DEV)
+    y_prev = torch.empty(B, H, W, Cc, device=DEV)
+    pool_prev = torch.zeros(B, n_tiles, Cc, device=DEV)
+    kw = dict(w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(), B=B, H=H, W=W, C_p=Cc, x_dtype=L.SR_F32, y_dtype=L.SR_F32)
+    ops.rcab_conv_pair(x=x_prev.data_ptr(), y=y_prev.data_ptr(), pool_partial=pool_prev.data_ptr(), **kw)  # a realistic (y, pool) pair
+    # two launches
+    x_want = torch.empty_like(x_prev)
+    run_channel_attention(ca, y_prev, pool_prev, n_tiles, Cc, x_want, skip=x_prev)
+    y_want, pool_want = torch.empty_like(x_prev), torch.zeros_like(pool_prev)
+    ops.rcab_conv_pair(x=x_want.data_ptr(), y=y_want.data_ptr(), pool_partial=pool_want.data_ptr(), **kw)
+    # one launch
+    x_got, y_got, pool_got = torch.full_like(x_prev, float("nan")), torch.full_like(x_prev, float("nan")), torch.zeros_like(pool_prev)
+    w1c, b1c, w2c, b2c = ca
+    ops.rcab_conv_pair(x=x_prev.data_ptr(), gate_y=y_prev.data_ptr(), gate_pool=pool_prev.data_ptr(), gate_w1=w1c.data_ptr(), gate_b1=b1c.data_ptr(),
+                       gate_w2=w2c.data_ptr(), gate_b2=b2c.data_ptr(), x_out=x_got.data_ptr(), gate_C=Cc, gate_Cr=Cr, y=y_got.data_ptr(),
+                       pool_partial=pool_got.data_ptr(), **kw)
+    assert torch.equal(x_got, x_want), f"x_out: max diff {float((x_got - x_want).abs().max()):.3e}, nan {int(torch.isnan(x_got).sum())}"
+    assert torch.equal(y_got, y_want), f"y: max diff {float((y_got - y_want).abs().max()):.3e}"
+    assert torch.equal(pool_got, pool_want)
+    with pytest.raises(L.HipLibraryError):  # aliasing the skip output with the input is refused
+        ops.rcab_conv_pair(x=x_prev.data_ptr(), gate_y=y_prev.data_ptr(), gate_pool=pool_prev.data_ptr(), gate_w1=w1c.data_ptr(), gate_b1=b1c.data_ptr(),
+                           gate_w2=w2c.data_ptr(), gate_b2=b2c.data_ptr(), x_out=x_prev.data_ptr(), gate_C=Cc, gate_Cr=Cr, y=y_got.data_ptr(),
+                           pool_partial=pool_got.data_ptr(), **kw)
+
+
 def test_errors_are_loud():
     m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).to(DEV).eval()
     with pytest.raises(RuntimeError):
