@@ -386,6 +386,7 @@ extern "C" int sr_conv3x3(const SrConv3x3* p, void* stream) {
                        c.fin_w <= c.W * (c.ps_r > 1 ? c.ps_r : 1) && !c.skip,
                    "sr_conv3x3: bad FINAL_NCHW arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sr_conv3x3_narrow_supported(c)) return sr_conv3x3_narrow(c, st);
     if (sr_conv3x3_big_supported(c)) return sr_conv3x3_big(c, st);
     if (c.compute_dtype == SR_BF16) {
         if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 8>(c, st);

@@ -54,6 +54,8 @@ static inline hipError_t sr_once_per_device(SrDeviceOnce& o, F&& f) {
 struct SrConv3x3;
 bool sr_conv3x3_big_supported(const SrConv3x3& c);
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st);
+bool sr_conv3x3_narrow_supported(const SrConv3x3& c);  // sr_conv_narrow.hip: RGB tail convs (persistent, register-resident weights)
+int sr_conv3x3_narrow(const SrConv3x3& c, hipStream_t st);
 
 // flash-form attention with the bias streamed through LDS (sr_attn_flash.hip)
 struct SrOcaAttn;

@@ -69,6 +69,7 @@ class Model(nn.Module):
     def __getstate__(self):  # deepcopy / pickle: derived device state (workspace, packed weights) is rebuilt on demand
         state = dict(self.__dict__)
         state["_packed"], state["_ws"] = {}, None
+        state.pop("_side", None)  # HIP stream of the two-branch blocks: per process, re-created on demand
         return state
 
     def __call__(self, *args, **kwargs):

@@ -253,6 +253,15 @@ class HAT(Model):
         return P
 
     # ------------------------------------------------------------------ blocks
+    dual_stream = True  # HAB: conv branch beside the attention branch on a second HIP stream
+
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        st = getattr(self, "_side", None)
+        if st is None or st.device != torch.device(device):
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
+
     def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt) -> None:
         """t = HAB(t_in); t_in may be t (in place)."""
         B, H, W, Cp = t_in.shape
@@ -261,13 +270,23 @@ class HAT(Model):
         n1 = ws_.get("hab.n1", (B, H, W, Cp), cdt)  # consumed only by the conv, which rounds to the compute dtype anyway
         ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
-        conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
         n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt))
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
-        conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
+        # The conv branch (2 launches) and the attention branch (3 launches) only share their input, and at the tile sizes of this model
+        # every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention branch (fork after
+        # LayerNorm1 -- the in-place projection must not overtake it -- join before the combine).  Also valid under HIP-graph capture.
+        main = torch.cuda.current_stream(t_in.device)
+        side = self._side_stream(t_in.device) if self.dual_stream else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
+            conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
         # attention branch + shortcut -> t   (hat.py:172-188)
         run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab")
+        if side is not main:
+            main.wait_stream(side)
         # x = shortcut + attn + conv_scale * CA(cab)   (hat.py:192)
         run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
         run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")

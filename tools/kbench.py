@@ -59,10 +59,11 @@ def conv_bench():
     from studiosr_amd import packing
     dev = torch.device("cuda")
     cdt = torch.bfloat16
-    only = os.environ.get("KB_CONV")  # e.g. KB_CONV=16,64,64,256,256 runs that case alone
-    for (B, H, W, cin, cout, mode) in [(1, 144, 144, 64, 256, "nhwc"), (2, 144, 144, 64, 256, "nhwc"), (4, 144, 144, 64, 256, "nhwc"), (1, 72, 72, 192, 192, "nhwc"), (8, 144, 144, 64, 256, "ps"), (8, 144, 144, 64, 256, "nhwc"), (8, 72, 72, 64, 256, "ps"), (8, 72, 72, 192, 192, "nhwc"),
+    only = os.environ.get("KB_CONV")  # e.g. KB_CONV=16,64,64,256,256 runs that case alone (any shape; KB_POOL=1 adds the pool-partial output)
+    extra = [tuple(int(v) for v in only.split(",")) + ("nhwc",)] if only else []
+    for (B, H, W, cin, cout, mode) in extra + [(1, 144, 144, 64, 256, "nhwc"), (2, 144, 144, 64, 256, "nhwc"), (4, 144, 144, 64, 256, "nhwc"), (1, 72, 72, 192, 192, "nhwc"), (8, 144, 144, 64, 256, "ps"), (8, 144, 144, 64, 256, "nhwc"), (8, 72, 72, 64, 256, "ps"), (8, 72, 72, 192, 192, "nhwc"),
                                        (8, 72, 72, 192, 192, "nhwc_f32"), (8, 288, 288, 64, 16, "nhwc"),
-                                       (16, 64, 64, 256, 256, "nhwc"), (16, 64, 64, 256, 1024, "ps"), (16, 128, 128, 256, 1024, "ps"), (16, 64, 64, 64, 64, "nhwc")]:
+                                       (8, 288, 288, 64, 16, "final"), (16, 256, 256, 256, 16, "final"), (16, 64, 64, 256, 256, "nhwc"), (16, 64, 64, 256, 1024, "ps"), (16, 128, 128, 256, 1024, "ps"), (16, 64, 64, 64, 64, "nhwc")]:
         if only and only != f"{B},{H},{W},{cin},{cout}":
             continue
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
@@ -74,15 +75,24 @@ def conv_bench():
         wp, bp = packing.pack_conv3x3(w, b, cin, rows, cdt)
         xdt = torch.float32 if mode == "nhwc_f32" else cdt
         x = torch.randn(B, H, W, cin, device=dev).to(xdt)
-        if mode == "ps":
+        if mode == "final":
+            out = torch.empty(B, 3, H, W, device=dev)
+            fs, fb = torch.ones(3, device=dev), torch.zeros(3, device=dev)
+            fn = lambda: conv_call(x, wp, bp, out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(fs, fb, 3, H, W), cout_p=16)
+        elif mode == "ps":
             out = torch.empty(B, 2 * H, 2 * W, cout // 4, device=dev, dtype=cdt)
             fn = lambda: conv_call(x, wp, bp, out, cdt, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=2, cps_p=cout // 4)
         else:
             out = torch.empty(B, H, W, cout, device=dev, dtype=torch.float32 if mode == "nhwc_f32" else cdt)
-            fn = lambda: conv_call(x, wp, bp, out, cdt)
+            pool = None
+            if os.environ.get("KB_POOL"):
+                pool = torch.zeros(B, ops.conv_pool_tiles(H, W, out.shape[-1], L.SR_BF16), out.shape[-1], device=dev)
+            fn = lambda: conv_call(x, wp, bp, out, cdt, pool=pool)
         us = timeit(fn)
         gf = 2.0 * B * H * W * 9 * cin * cout / 1e9
-        print(f"conv B={B} {H}x{W} {cin}->{cout} {mode:9s}: {us:8.1f} us  {gf / us * 1e3:8.1f} TF/s", flush=True)
+        print(f"conv B={B} {H}x{W} {cin}->{cout} {mode:9s}: {us:8.1f} us  {gf / us * 1e3:8.1f} TF/s  input {x.numel() * x.element_size() / us / 1e6:6.2f} TB/s", flush=True)
+        if extra:
+            break
         if os.environ.get("KB_STAMPS"):  # needs a `make STAMPS=1` build: s_memtime stamps of workgroup 7, wave 0 (sr_conv.hip only)
             import ctypes
             buf = (ctypes.c_ulonglong * 16)()
