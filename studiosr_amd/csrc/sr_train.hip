@@ -14,6 +14,8 @@
 // is exceeded, not approximated.  Speed-of-light kernels for this path are later rounds' work; the bar here is gradient parity.
 #include "sr_common.h"
 #include "sr_host.h"
+
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -270,12 +272,13 @@ int launch_tiled_b(const SrBgemm& g, int mb, dim3 grid, hipStream_t st) {
 // writes are 16-byte rows again instead of transposed 2-byte scatters.
 constexpr int HK = 32, HLD = 40;  // bf16 elements per row incl. pad
 
-template <int MODE>
-SR_DEV void hg_load(const float* __restrict__ base, long long s_row, long long s_k, int row0, int nrows, int k0, int kend, float (&v)[16]) {
+// ROWS x 32 fp32 operand slab -> registers: NV = ROWS / 8 floats per thread
+template <int MODE, int ROWS>
+SR_DEV void hg_load(const float* __restrict__ base, long long s_row, long long s_k, int row0, int nrows, int k0, int kend, float (&v)[ROWS / 8]) {
     const int t = threadIdx.x;
     if (MODE == 0) {  // thread -> (row = t / 4 + 64 i, k octet = t % 4): v[8 i .. 8 i + 7]
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ROWS / 64; ++i) {
             const int row = row0 + (t >> 2) + 64 * i, k = k0 + 8 * (t & 3);
             if (row < nrows && k + 8 <= kend) {
                 const f32x4u a = *reinterpret_cast<const f32x4u*>(base + (long long)row * s_row + k), b = *reinterpret_cast<const f32x4u*>(base + (long long)row * s_row + k + 4);
@@ -286,36 +289,82 @@ SR_DEV void hg_load(const float* __restrict__ base, long long s_row, long long s
                 for (int j = 0; j < 8; ++j) v[8 * i + j] = (row < nrows && k + j < kend) ? base[(long long)row * s_row + k + j] : 0.f;
             }
         }
-    } else {  // row-contiguous or generic: thread -> (row = t % 128, 16 k = 16 (t / 128) ..)
-        const int row = row0 + (t & 127), kb = k0 + 16 * (t >> 7);
-        if (row < nrows && kb + 16 <= kend) {
+    } else if (MODE == 1) {
+        // row-contiguous (unit row stride, 16-byte aligned k-rows): thread -> 4 consecutive rows x KP consecutive k, one 16-byte load per k;
+        // v[4 p + j] = (row 4 rg + j, k = KP kq + p)
+        constexpr int RG = ROWS / 4, KP = 32 / (256 / RG);
+        const int rg = t % RG, kq = t / RG;
+        const int row = row0 + 4 * rg;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = base[(long long)row * s_row + (long long)(kb + j) * s_k];
+        for (int p = 0; p < KP; ++p) {
+            const int k = k0 + KP * kq + p;
+            const float* src = base + row + (long long)k * s_k;
+            if (row + 4 <= nrows && k < kend) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                v[4 * p] = a[0]; v[4 * p + 1] = a[1]; v[4 * p + 2] = a[2]; v[4 * p + 3] = a[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * p + j] = (row + j < nrows && k < kend) ? src[j] : 0.f;
+            }
+        }
+    } else {  // generic strides: thread -> (row = t % ROWS, NV consecutive k from NV * (t / ROWS))
+        constexpr int NV = ROWS / 8;
+        const int row = row0 + (t & (ROWS - 1)), kb = k0 + NV * (t / ROWS);
+        if (row < nrows && kb + NV <= kend) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = base[(long long)row * s_row + (long long)(kb + j) * s_k];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const float x = base[(long long)min(row, nrows - 1) * s_row + (long long)min(kb + j, kend - 1) * s_k];
                 v[j] = (row < nrows && kb + j < kend) ? x : 0.f;
             }
         }
     }
 }
-template <int MODE>
-SR_DEV void hg_store(bf16* __restrict__ tile, const float (&v)[16]) {
+template <int MODE, int ROWS>
+SR_DEV void hg_store(bf16* __restrict__ tile, const float (&v)[ROWS / 8]) {
     const int t = threadIdx.x;
     if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<Frag<bf16>*>(tile + ((t >> 2) + 64 * i) * HLD + 8 * (t & 3)) = frag_from8(v + 8 * i);
+        for (int i = 0; i < ROWS / 64; ++i) *reinterpret_cast<Frag<bf16>*>(tile + ((t >> 2) + 64 * i) * HLD + 8 * (t & 3)) = frag_from8(v + 8 * i);
+    } else if (MODE == 1) {
+        constexpr int RG = ROWS / 4, KP = 32 / (256 / RG);
+        const int rg = t % RG, kq = t / RG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16* p = tile + (4 * rg + j) * HLD + KP * kq;
+            if constexpr (KP == 4) {
+                bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (bf16)v[4 * q + j];
+                *reinterpret_cast<bf16x4*>(p) = o;
+            } else {
+                typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                bf16x2_t o;
+                o[0] = (bf16)v[j];
+                o[1] = (bf16)v[4 + j];
+                *reinterpret_cast<bf16x2_t*>(p) = o;
+            }
+        }
     } else {
-        bf16* p = tile + (t & 127) * HLD + 16 * (t >> 7);
-        *reinterpret_cast<Frag<bf16>*>(p) = frag_from8(v);
-        *reinterpret_cast<Frag<bf16>*>(p + 8) = frag_from8(v + 8);
+        constexpr int NV = ROWS / 8;
+        bf16* p = tile + (t & (ROWS - 1)) * HLD + NV * (t / ROWS);
+#pragma unroll
+        for (int i = 0; i < NV / 8; ++i) *reinterpret_cast<Frag<bf16>*>(p + 8 * i) = frag_from8(v + 8 * i);
     }
 }
 
-template <int MA, int MB>
+// bf16-operand GEMM tile 128 x BN (BN = 128 or 64), K steps of 32.  What the first version (one K step of prefetch, 128 x 128 only,
+// element-wise stores) showed at the Linear shapes of a training step (tools/bgemm_bench.py: 50-140 TF/s, 1-2 TB/s): the launch is a
+// few hundred workgroups that all sit in the same latency chain -- global load -> convert -> LDS -> 16 MFMAs -- once per K step.  So:
+//   * TWO K steps of operands in flight in registers (the loads of step t + 2 are issued before the MFMAs of step t);
+//   * BN = 64 where that gives more / fuller workgroups (N = 180, 360, 540: 6 % padding instead of 18-42 %);
+//   * result tiles computed transposed (MFMA operands swapped) when C is row-major, so a lane owns 4 consecutive n: 16-byte stores.
+template <int MA, int MB, int BN>
 __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
-    __shared__ __attribute__((aligned(16))) bf16 lds[2][2][BT * HLD];  // [buffer][A | B][row][k]
+    constexpr int NTW = BN / 32;  // n tiles per wave (waves 2 x 2: 64 rows x BN / 2 columns each)
+    __shared__ __attribute__((aligned(16))) bf16 lds[2][(BT + BN) * HLD];  // [buffer][A rows | B rows][k]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
     const int li = lane & 15, lg = lane >> 4;
     int z = blockIdx.z;
@@ -325,51 +374,103 @@ __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
     const float* A = g.A + (long long)b1 * g.sa_b1 + (long long)b2 * g.sa_b2;
     const float* B = g.B + (long long)b1 * g.sb_b1 + (long long)b2 * g.sb_b2;
     float* C = g.C + (long long)b1 * g.sc_b1 + (long long)b2 * g.sc_b2;
-    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BN;
     const int kchunk = (((g.K + g.ksplit - 1) / g.ksplit) + HK - 1) / HK * HK;
     const int kbeg = ks * kchunk, kend = min(g.K, kbeg + kchunk);
-    f32x4 acc[4][4];
+    const int nsteps = kbeg < kend ? (kend - kbeg + HK - 1) / HK : 0;
+    // row-major C (unit column stride, 16-byte aligned rows), no split-K atomics: lane = row m, registers = 4 consecutive columns
+    const bool tr = g.ksplit == 1 && g.sc_n == 1 && (g.sc_m & 3) == 0 && ((g.sc_b1 | g.sc_b2) & 3) == 0 && (reinterpret_cast<size_t>(g.C) & 15) == 0;
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.0f);
-    if (kbeg < kend) {
-        float ra[16], rb[16];
-        hg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, ra);
-        hg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, rb);
-        hg_store<MA>(lds[0][0], ra);
-        hg_store<MB>(lds[0][1], rb);
-        __syncthreads();
-        int cur = 0;
-        for (int k = kbeg; k < kend; k += HK) {
-            const bool more = k + HK < kend;
-            if (more) {  // the global loads of step t+1 travel under the MFMAs of step t
-                hg_load<MA>(A, g.sa_m, g.sa_k, m0, g.M, k + HK, kend, ra);
-                hg_load<MB>(B, g.sb_n, g.sb_k, n0, g.N, k + HK, kend, rb);
-            }
-            Frag<bf16> av[4], bv[4];
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4)(0.0f);
+    float ra[2][BT / 8], rb[2][BN / 8];
+    auto load = [&](auto q, int t) {
+        constexpr int Q = decltype(q)::value;
+        hg_load<MA, BT>(A, g.sa_m, g.sa_k, m0, g.M, kbeg + t * HK, kend, ra[Q]);
+        hg_load<MB, BN>(B, g.sb_n, g.sb_k, n0, g.N, kbeg + t * HK, kend, rb[Q]);
+    };
+    auto store = [&](auto q, int buf) {
+        constexpr int Q = decltype(q)::value;
+        hg_store<MA, BT>(lds[buf], ra[Q]);
+        hg_store<MB, BN>(lds[buf] + BT * HLD, rb[Q]);
+    };
+    auto step = [&](auto q, int t) {  // registers Q hold step t + 1 after this (loaded two steps ago), and are refilled with t + 2 ... see below
+        constexpr int Q = decltype(q)::value;
+        using QN = std::integral_constant<int, 1 - Q>;
+        // registers Q held step t (already in LDS): refill them with step t + 2; registers 1 - Q hold step t + 1
+        if (t + 2 < nsteps) load(q, t + 2);
+        const bf16* At = lds[t & 1];
+        const bf16* Bt = At + BT * HLD;
+        Frag<bf16> av[4], bv[NTW];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                av[t] = *reinterpret_cast<const Frag<bf16>*>(lds[cur][0] + (wm * 64 + t * 16 + li) * HLD + 8 * lg);
-                bv[t] = *reinterpret_cast<const Frag<bf16>*>(lds[cur][1] + (wn * 64 + t * 16 + li) * HLD + 8 * lg);
-            }
+        for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const Frag<bf16>*>(At + (wm * 64 + i * 16 + li) * HLD + 8 * lg);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bv[j] = *reinterpret_cast<const Frag<bf16>*>(Bt + (wn * (BN / 2) + j * 16 + li) * HLD + 8 * lg);
+        if (tr) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt].v, bv[nt].v, acc[mt][nt], 0, 0, 0);
-            if (more) {
-                hg_store<MA>(lds[cur ^ 1][0], ra);
-                hg_store<MB>(lds[cur ^ 1][1], rb);
-            }
-            __syncthreads();
-            cur ^= 1;
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt].v, av[mt].v, acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt].v, bv[nt].v, acc[mt][nt], 0, 0, 0);
         }
+        if (t + 1 < nsteps) store(QN{}, (t + 1) & 1);
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (nsteps > 0) {
+        load(I0{}, 0);
+        if (nsteps > 1) load(I1{}, 1);
+        store(I0{}, 0);
+        __syncthreads();
+        for (int t = 0; t < nsteps; t += 2) {
+            step(I0{}, t);
+            if (t + 1 < nsteps) step(I1{}, t + 1);
+        }
+    }
+    if (tr) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + 16 * mt + li;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = n0 + wn * (BN / 2) + 16 * nt + 4 * lg;
+                if (n >= g.N) continue;
+                float* c = C + (long long)m * g.sc_m + n;
+                f32x4 v = g.alpha * acc[mt][nt];
+                if (g.bias && ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) v[r] += g.bias[n + r];
+                }
+                if (g.ksplit > 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) atomicAdd(c + r, v[r]);
+                } else if (n + 4 <= g.N) {
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+                    *reinterpret_cast<f32x4*>(c) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) c[r] = g.accumulate ? c[r] + v[r] : v[r];
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + 16 * nt + li;
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = n0 + wn * (BN / 2) + 16 * nt + li;
             if (n >= g.N) continue;
             const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
@@ -386,6 +487,19 @@ __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
                     *c = v;
             }
         }
+}
+
+template <int MA, int MB>
+void launch_bf16(const SrBgemm& g, long long nz, hipStream_t st) {
+    // BN = 64 where it pads N less or where 128-wide tiles leave the chip under-filled
+    static const int force = getenv("SR_BGEMM_BN") ? atoi(getenv("SR_BGEMM_BN")) : 0;
+    const long long t128 = (long long)((g.N + 127) / 128) * ((g.M + BT - 1) / BT) * nz;
+    const bool pad64 = ((g.N + 63) / 64) * 64 < ((g.N + 127) / 128) * 128;
+    const bool bn64 = force ? force == 64 : (pad64 || t128 < 1024);
+    if (bn64)
+        hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 64>), dim3((g.N + 63) / 64, (g.M + BT - 1) / BT, (unsigned)nz), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 128>), dim3((g.N + 127) / 128, (g.M + BT - 1) / BT, (unsigned)nz), dim3(256), 0, st, g);
 }
 
 // ----------------------------------------------------------------------------- im2col / col2im, column order (tap, c)
@@ -803,17 +917,29 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
     SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large (batches x ksplit = %lld)", nz);
     static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
-    if (g.compute_dtype == SR_BF16 && g.M >= 96 && g.N >= 24 && g.K >= 32 && (g.M + BT - 1) / BT <= 65535) {
-        const dim3 grid((g.N + BT - 1) / BT, (g.M + BT - 1) / BT, (unsigned)nz);
-        const bool a0 = g.sa_k == 1, b0 = g.sb_k == 1;
-        if (a0 && b0)
-            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 0>), grid, dim3(256), 0, ST, g);
-        else if (a0)
-            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 1>), grid, dim3(256), 0, ST, g);
-        else if (b0)
-            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<1, 0>), grid, dim3(256), 0, ST, g);
+    if (g.compute_dtype == SR_BF16 && g.M >= 96 && g.N >= 24 && g.K >= 16 && (g.M + BT - 1) / BT <= 65535) {
+        // staging mode per operand: 0 = contraction axis contiguous, 1 = row axis contiguous with 16-byte aligned k-rows, 2 = anything else
+        auto vec_rows = [](const float* p, long long s_row, long long s_k, long long sb1, long long sb2) {
+            return s_row == 1 && (s_k & 3) == 0 && (sb1 & 3) == 0 && (sb2 & 3) == 0 && (reinterpret_cast<size_t>(p) & 15) == 0;
+        };
+        const int ma = g.sa_k == 1 ? 0 : (vec_rows(g.A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2) ? 1 : 2);
+        const int mb = g.sb_k == 1 ? 0 : (vec_rows(g.B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2) ? 1 : 2);
+        if (ma == 2 || mb == 2) {  // rare: generic strides on either side -> both operands through the scalar staging, 128 x 128 tiles
+            const dim3 grid((g.N + 127) / 128, (g.M + BT - 1) / BT, (unsigned)nz);
+            if (ma == 0)
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 2, 128>), grid, dim3(256), 0, ST, g);
+            else if (mb == 0)
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 0, 128>), grid, dim3(256), 0, ST, g);
+            else
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 2, 128>), grid, dim3(256), 0, ST, g);
+        } else if (ma == 0 && mb == 0)
+            launch_bf16<0, 0>(g, nz, ST);
+        else if (ma == 0)
+            launch_bf16<0, 1>(g, nz, ST);
+        else if (mb == 0)
+            launch_bf16<1, 0>(g, nz, ST);
         else
-            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<1, 1>), grid, dim3(256), 0, ST, g);
+            launch_bf16<1, 1>(g, nz, ST);
         SR_CHECK_LAUNCH("sr_bgemm");
         return SR_OK;
     }
