@@ -102,6 +102,42 @@ def colsum(x: Tensor, out: Tensor, nb: int, P: int, Cn: int, alpha: float = 1.0)
     return out
 
 
+class _ZeroArena:
+    """Zero-initialised fp32 scratch for the accumulators of a backward pass (split-K weight gradients, bias / LayerNorm / bias-table
+    gradients that kernels add into): one fill per 32 MiB chunk instead of one `torch.zeros` launch per accumulator (a HAT step made
+    ~1,400 of them, 5.6 ms of 4-us fills).  Slices are views of the chunk; a chunk lives as long as any of its views (e.g. a
+    parameter's .grad until zero_grad) and is never handed out twice."""
+
+    CHUNK = 8 << 20  # floats
+
+    def __init__(self) -> None:
+        self.buf: Optional[Tensor] = None
+        self.off = 0
+
+    def take(self, shape, device) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n == 0 or n > self.CHUNK // 8:
+            return torch.zeros(tuple(shape), device=device, dtype=torch.float32)
+        if self.buf is None or self.buf.device != torch.device(device) or self.off + n > self.CHUNK:
+            self.buf, self.off = torch.zeros(self.CHUNK, device=device, dtype=torch.float32), 0
+        v = self.buf[self.off:self.off + n].view(tuple(shape))
+        self.off += (n + 63) // 64 * 64  # 256-byte granules
+        return v
+
+
+_ARENA = _ZeroArena()
+
+
+def _zeros(shape, device) -> Tensor:
+    return _ARENA.take(shape, device)
+
+
+def _zeros_like(t: Tensor) -> Tensor:
+    return _ARENA.take(t.shape, t.device)
+
+
 # --------------------------------------------------------------------------- nn.Linear / conv
 class _Linear(Fn):
     """y[M,N] = x[M,K] @ w[N,K]^T + b (swinir.py:69-71, common.py:184-195; 1x1 convs of the channel attention, common.py:161-167)."""
@@ -133,10 +169,10 @@ class _Linear(Fn):
                 dx = torch.empty_like(x)
                 bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
             if ctx.needs_input_grad[1]:
-                dw = torch.zeros_like(w)
+                dw = _zeros_like(w)
                 bgemm(dy, x, dw, N, K, M, (1, N), (K, 1), (K, 1), ksplit=_ksplit(N, K, M))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = colsum(dy, torch.zeros(N, device=dy.device), 1, M, N)
+                db = colsum(dy, _zeros((N,), dy.device), 1, M, N)
             return dx, dw, db
 
 
@@ -191,11 +227,11 @@ class _Conv3x3(Fn):
                 L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
             if ctx.needs_input_grad[1]:
                 col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-                dw2 = torch.zeros(Cout, K, device=dy.device, dtype=torch.float32)
+                dw2 = _zeros((Cout, K), dy.device)
                 bgemm(dy, col, dw2, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
                 dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = colsum(dy, torch.zeros(Cout, device=dy.device), 1, M, Cout)
+                db = colsum(dy, _zeros((Cout,), dy.device), 1, M, Cout)
             return dx, dw, db, None
 
 
@@ -225,7 +261,7 @@ class _LayerNorm(Fn):
         Cn = x.shape[-1]
         M = x.numel() // Cn
         dx = torch.empty_like(x)
-        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dg, db = _zeros_like(g), _zeros_like(g)
         L.check(L.lib().sr_layernorm_bwd(x.data_ptr(), stats.data_ptr(), g.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, Cn, _st()), "sr_layernorm_bwd")
         return dx, dg, db, None
 
@@ -456,7 +492,7 @@ class _Attention(Fn):
             if ctx.needs_input_grad[2]:
                 dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
                 L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
-                dtable = torch.zeros_like(table)
+                dtable = _zeros_like(table)
                 L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
             # dq = scale * dS k ; dk = scale * dS^T q
             bgemm(dP, kvs, dq, Nq, hd, Nk, (Nk, 1), (ldk, 1), (ldq, 1), b_off=k_off, c_off=q_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nk * ldk, hd), scb=(Nq * ldq, hd))
@@ -484,7 +520,7 @@ class _AvgPool(Fn):
         x = _chk(x)
         B, H, W, Cn = x.shape
         ctx.shape = tuple(x.shape)
-        return colsum(x, torch.zeros(B, Cn, device=x.device), B, H * W, Cn, 1.0 / (H * W))
+        return colsum(x, _zeros((B, Cn), x.device), B, H * W, Cn, 1.0 / (H * W))
 
     @staticmethod
     def backward(ctx, d):
@@ -513,7 +549,7 @@ class _MulBC(Fn):
         B, H, W, Cn = x.shape
         dx = eltwise(L.EW_MUL_BC, d, torch.empty_like(d), s=s, inner=H * W * Cn, Cn=Cn)
         prod = eltwise(L.EW_MUL, d, torch.empty_like(d), y=x)
-        ds = colsum(prod, torch.zeros(B, Cn, device=d.device), B, H * W, Cn)
+        ds = colsum(prod, _zeros((B, Cn), d.device), B, H * W, Cn)
         return dx, ds
 
 
@@ -657,7 +693,7 @@ class _ScaleParam(Fn):
         d = _chk(d)
         dx = eltwise(L.EW_SCALE_SAMPLE, d, torch.empty_like(d), s=gamma, inner=d.numel())
         prod = eltwise(L.EW_MUL, d, torch.empty_like(d), y=x)
-        dg = colsum(prod, torch.zeros(1, device=d.device), 1, prod.numel(), 1)
+        dg = colsum(prod, _zeros((1,), d.device), 1, prod.numel(), 1)
         return dx, dg.reshape(gamma.shape)
 
 
@@ -741,7 +777,7 @@ class _Conv3d27(Fn):
         B, H, W, Cn = x.shape
         dx = torch.empty_like(x)
         L.check(L.lib().sr_conv3d27(d.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, H, W, Cn, 1, _st()), "sr_conv3d27")
-        dw, db = torch.zeros_like(w), torch.zeros(1, device=d.device)
+        dw, db = _zeros_like(w), _zeros((1,), d.device)
         L.check(L.lib().sr_conv3d27_wgrad(x.data_ptr(), d.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H, W, Cn, _st()), "sr_conv3d27_wgrad")
         return dx, dw, db
 

@@ -592,6 +592,74 @@ __global__ void sr_softmax_bwd_kernel(const float* __restrict__ P, float* __rest
     for (int j = lane; j < Nk; j += 64) d[j] = p[j] * (d[j] - dot);
 }
 
+// Register-resident forms (Nk <= 64 NV): one read and one write of the row instead of three each; same arithmetic, same summation order.
+template <int NV>
+__global__ void sr_softmax_fwd_reg_kernel(float* __restrict__ S, const float* __restrict__ bias, const float* __restrict__ mask, long long rows, int heads, int Nq, int Nk, int nW) {
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(r % Nq);
+    const int h = (int)((r / Nq) % heads);
+    const long long bw = r / ((long long)Nq * heads);
+    float* s = S + r * Nk;
+    const float* bp = bias ? bias + ((long long)h * Nq + i) * Nk : nullptr;
+    const float* mp = mask ? mask + ((bw % nW) * Nq + i) * Nk : nullptr;
+    float v[NV];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int j = lane + 64 * q;
+        v[q] = -3.0e38f;
+        if (j < Nk) {
+            float t = s[j];
+            if (bp) t += bp[j];
+            if (mp) t += mp[j];
+            v[q] = t;
+            mx = fmaxf(mx, t);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (lane + 64 * q < Nk) {
+            v[q] = expf(v[q] - mx);
+            sum += v[q];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (lane + 64 * q < Nk) s[lane + 64 * q] = v[q] * inv;
+}
+template <int NV>
+__global__ void sr_softmax_bwd_reg_kernel(const float* __restrict__ P, float* __restrict__ dP, long long rows, int Nk) {
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = P + r * Nk;
+    float* d = dP + r * Nk;
+    float pv[NV], dv[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int j = lane + 64 * q;
+        pv[q] = dv[q] = 0.f;
+        if (j < Nk) {
+            pv[q] = p[j];
+            dv[q] = d[j];
+            dot += pv[q] * dv[q];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (lane + 64 * q < Nk) d[lane + 64 * q] = pv[q] * (dv[q] - dot);
+}
+
 // ----------------------------------------------------------------------------- LayerNorm forward (saving mean / rstd) and backward
 __global__ void sr_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
                                  long long M, int C, float eps) {
@@ -619,28 +687,50 @@ __global__ void sr_ln_fwd_kernel(const float* __restrict__ x, const float* __res
     for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
 }
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum_rows dy * xhat; dbeta += sum_rows dy
-constexpr int LN_ROWS_PER_WAVE = 16, LN_MAX_COLS_PER_LANE = 8;  // C <= 512
-__global__ void sr_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ dy, float* __restrict__ dx,
-                                 float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C) {
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+// One workgroup = 16 rows, 4 per wave, all of a wave's rows in flight at once (the first version walked 16 rows per wave one after the
+// other: 1,024 waves of serial load -> shuffle -> reload chains, 67 us for 35 MB); the workgroup's partial dgamma / dbeta are summed
+// through LDS, so the atomic count stays one per column per 16 rows.
+constexpr int LN_ROWS_PER_WAVE = 4, LN_ROWS_PER_WG = 16, LN_MAX_COLS_PER_LANE = 8;  // C <= 512
+__global__ __launch_bounds__(256) void sr_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C) {
+    __shared__ float red[2][4][64 * LN_MAX_COLS_PER_LANE];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long r0 = (long long)blockIdx.x * LN_ROWS_PER_WG + w * LN_ROWS_PER_WAVE;
+    float xh[LN_ROWS_PER_WAVE][LN_MAX_COLS_PER_LANE], dv[LN_ROWS_PER_WAVE][LN_MAX_COLS_PER_LANE], gm[LN_MAX_COLS_PER_LANE];
+    float mean[LN_ROWS_PER_WAVE], rstd[LN_ROWS_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) gm[q] = (lane + 64 * q < C) ? gamma[lane + 64 * q] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const long long r = r0 + rr;
+        const bool ok = r < M;
+        mean[rr] = ok ? stats[2 * r] : 0.f;
+        rstd[rr] = ok ? stats[2 * r + 1] : 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) {
+            const int c = lane + 64 * q;
+            const bool in = ok && c < C;
+            xh[rr][q] = in ? x[r * C + c] : 0.f;
+            dv[rr][q] = in ? dy[r * C + c] : 0.f;
+        }
+    }
     float pg[LN_MAX_COLS_PER_LANE], pb[LN_MAX_COLS_PER_LANE];
 #pragma unroll
     for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) pg[q] = pb[q] = 0.f;
+#pragma unroll
     for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
-        const long long r = wave * LN_ROWS_PER_WAVE + rr;
-        if (r >= M) break;
-        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+        const long long r = r0 + rr;
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) {
             const int c = lane + 64 * q;
             if (c < C) {
-                const float xh = (x[r * C + c] - mean) * rstd, d = dy[r * C + c], g = d * gamma[c];
+                xh[rr][q] = (xh[rr][q] - mean[rr]) * rstd[rr];
+                const float g = dv[rr][q] * gm[q];
                 m1 += g;
-                m2 += g * xh;
-                pg[q] += d * xh;
-                pb[q] += d;
+                m2 += g * xh[rr][q];
+                pg[q] += dv[rr][q] * xh[rr][q];
+                pb[q] += dv[rr][q];
             }
         }
 #pragma unroll
@@ -650,22 +740,23 @@ __global__ void sr_ln_bwd_kernel(const float* __restrict__ x, const float* __res
         }
         m1 /= C;
         m2 /= C;
+        if (r < M) {
 #pragma unroll
-        for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) {
-            const int c = lane + 64 * q;
-            if (c < C) {
-                const float xh = (x[r * C + c] - mean) * rstd, g = dy[r * C + c] * gamma[c];
-                dx[r * C + c] = rstd * (g - m1 - xh * m2);
+            for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) {
+                const int c = lane + 64 * q;
+                if (c < C) dx[r * C + c] = rstd[rr] * (dv[rr][q] * gm[q] - m1 - xh[rr][q] * m2);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < LN_MAX_COLS_PER_LANE; ++q) {
-        const int c = lane + 64 * q;
-        if (c < C) {
-            atomicAdd(dgamma + c, pg[q]);
-            atomicAdd(dbeta + c, pb[q]);
-        }
+        red[0][w][lane + 64 * q] = pg[q];
+        red[1][w][lane + 64 * q] = pb[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dgamma + c, ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c]);
+        atomicAdd(dbeta + c, ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c]);
     }
 }
 
@@ -690,6 +781,32 @@ __global__ __launch_bounds__(256) void sr_colsum_kernel(const float* __restrict_
     red[rg][cl] = s0 + s1;
     __syncthreads();
     if (rg == 0 && c < C) atomicAdd(out + b * C + c, alpha * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]));
+}
+// C % 4 == 0, 16-byte aligned rows: a lane owns 4 consecutive columns (one 16-byte load per row), 4 row groups x 2 rows in flight,
+// 128 rows per workgroup -- 3-4x the workgroups and a quarter of the load instructions of the scalar kernel above
+constexpr int COLSUM4_ROWS = 64;
+__global__ __launch_bounds__(256) void sr_colsum4_kernel(const float* __restrict__ x, float* __restrict__ out, long long P, int C, float alpha) {
+    __shared__ f32x4 red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = (blockIdx.y * 64 + cl) * 4;
+    const long long b = blockIdx.z;
+    const long long p0 = (long long)blockIdx.x * COLSUM4_ROWS, p1 = min(P, p0 + COLSUM4_ROWS);
+    const float* xb = x + b * P * C;
+    f32x4 acc[4] = {(f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f)};
+    if (c < C) {  // this thread's 16 rows: every load is independent, all of them can be in flight together
+#pragma unroll
+        for (int k = 0; k < COLSUM4_ROWS / 4; ++k) {
+            const long long p = p0 + rg + 4 * k;
+            if (p < p1) acc[k & 3] += *reinterpret_cast<const f32x4*>(xb + p * C + c);
+        }
+    }
+    red[rg][cl] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const f32x4 t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(out + b * C + c + r, alpha * t[r]);
+    }
 }
 // out[i] = sum_b x[b][i]  (relative-position-bias gradient: sum of dS over windows; deterministic, no atomics)
 __global__ void sr_batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long nb, long long n, long long stride_b) {
@@ -917,7 +1034,20 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
     SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large (batches x ksplit = %lld)", nz);
     static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
-    if (g.compute_dtype == SR_BF16 && g.M >= 96 && g.N >= 24 && g.K >= 16 && (g.M + BT - 1) / BT <= 65535) {
+    if (g.M < 96 && g.N >= 96 && !g.bias) {
+        // short-and-wide (weight gradients of convs with few output channels: M = 3 or 60, N = 9 Cin): run the transposed problem
+        // C^T = B^T A^T so that the long axis is the 128-row tile axis -- same products, same k order
+        std::swap(g.A, g.B);
+        std::swap(g.M, g.N);
+        const long long am = g.sa_m, ak = g.sa_k;
+        g.sa_m = g.sb_n, g.sa_k = g.sb_k, g.sb_n = am, g.sb_k = ak;
+        std::swap(g.sa_b1, g.sb_b1);
+        std::swap(g.sa_b2, g.sb_b2);
+        std::swap(g.sc_m, g.sc_n);
+    }
+    // bf16 operands: any N and K once M fills a 128-row tile (N = 3: the RGB tail conv over im2col -- memory-bound, the tile's idle
+    // columns cost nothing; K = 3: its data gradient)
+    if (g.compute_dtype == SR_BF16 && g.M >= 96 && (g.M + BT - 1) / BT <= 65535) {
         // staging mode per operand: 0 = contraction axis contiguous, 1 = row axis contiguous with 16-byte aligned k-rows, 2 = anything else
         auto vec_rows = [](const float* p, long long s_row, long long s_k, long long sb1, long long sb2) {
             return s_row == 1 && (s_k & 3) == 0 && (sb1 & 3) == 0 && (sb2 & 3) == 0 && (reinterpret_cast<size_t>(p) & 15) == 0;
@@ -977,13 +1107,26 @@ extern "C" int sr_col2im3x3(const float* dcol, float* dx, int B, int H, int W, i
 }
 extern "C" int sr_softmax_fwd(float* S, const float* bias, const float* mask, long long rows, int heads, int Nq, int Nk, int nW, void* stream) {
     SR_REQUIRE(S && rows > 0 && heads > 0 && Nq > 0 && Nk > 0 && (!mask || nW > 0), "sr_softmax_fwd: bad arguments");
-    hipLaunchKernelGGL(sr_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, S, bias, mask, rows, heads, Nq, Nk, nW > 0 ? nW : 1);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const int nw = nW > 0 ? nW : 1;
+    if (Nk <= 256)
+        hipLaunchKernelGGL(sr_softmax_fwd_reg_kernel<4>, grid, dim3(256), 0, ST, S, bias, mask, rows, heads, Nq, Nk, nw);
+    else if (Nk <= 640)
+        hipLaunchKernelGGL(sr_softmax_fwd_reg_kernel<10>, grid, dim3(256), 0, ST, S, bias, mask, rows, heads, Nq, Nk, nw);
+    else
+        hipLaunchKernelGGL(sr_softmax_fwd_kernel, grid, dim3(256), 0, ST, S, bias, mask, rows, heads, Nq, Nk, nw);
     SR_CHECK_LAUNCH("sr_softmax_fwd");
     return SR_OK;
 }
 extern "C" int sr_softmax_bwd(const float* P, float* dP, long long rows, int Nk, void* stream) {
     SR_REQUIRE(P && dP && rows > 0 && Nk > 0, "sr_softmax_bwd: bad arguments");
-    hipLaunchKernelGGL(sr_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, P, dP, rows, Nk);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (Nk <= 256)
+        hipLaunchKernelGGL(sr_softmax_bwd_reg_kernel<4>, grid, dim3(256), 0, ST, P, dP, rows, Nk);
+    else if (Nk <= 640)
+        hipLaunchKernelGGL(sr_softmax_bwd_reg_kernel<10>, grid, dim3(256), 0, ST, P, dP, rows, Nk);
+    else
+        hipLaunchKernelGGL(sr_softmax_bwd_kernel, grid, dim3(256), 0, ST, P, dP, rows, Nk);
     SR_CHECK_LAUNCH("sr_softmax_bwd");
     return SR_OK;
 }
@@ -995,14 +1138,16 @@ extern "C" int sr_layernorm_fwd_train(const float* x, const float* gamma, const 
 }
 extern "C" int sr_layernorm_bwd(const float* x, const float* stats, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, long long M, int C, void* stream) {
     SR_REQUIRE(x && stats && gamma && dy && dx && dgamma && dbeta && M > 0 && C > 0 && C <= 64 * LN_MAX_COLS_PER_LANE, "sr_layernorm_bwd: bad arguments (C <= 512)");
-    const long long waves = (M + LN_ROWS_PER_WAVE - 1) / LN_ROWS_PER_WAVE;
-    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST, x, stats, gamma, dy, dx, dgamma, dbeta, M, C);
+    hipLaunchKernelGGL(sr_ln_bwd_kernel, dim3((unsigned)((M + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG)), dim3(256), 0, ST, x, stats, gamma, dy, dx, dgamma, dbeta, M, C);
     SR_CHECK_LAUNCH("sr_layernorm_bwd");
     return SR_OK;
 }
 extern "C" int sr_colsum(const float* x, float* out, int nb, long long P, int C, float alpha, void* stream) {
     SR_REQUIRE(x && out && nb > 0 && nb <= 65535 && P > 0 && C > 0, "sr_colsum: bad arguments");
-    hipLaunchKernelGGL(sr_colsum_kernel, dim3((unsigned)((P + COLSUM_ROWS - 1) / COLSUM_ROWS), (C + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
+    if ((C & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && P >= 64)
+        hipLaunchKernelGGL(sr_colsum4_kernel, dim3((unsigned)((P + COLSUM4_ROWS - 1) / COLSUM4_ROWS), (C / 4 + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
+    else
+        hipLaunchKernelGGL(sr_colsum_kernel, dim3((unsigned)((P + COLSUM_ROWS - 1) / COLSUM_ROWS), (C + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
     SR_CHECK_LAUNCH("sr_colsum");
     return SR_OK;
 }

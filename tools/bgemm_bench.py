@@ -34,12 +34,14 @@ def main():
         for name, M, N, K in cases:
             X, W, Y = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.randn(M, N, device=dev)
             dX, dW = torch.empty_like(X), torch.zeros_like(W)
-            ks = AG._ksplit(N, K, M)
+            ks = int(os.environ["KS"]) if os.environ.get("KS") else AG._ksplit(N, K, M)
             with AG.autocast_state(bf):
                 f = {"fwd": lambda: AG.bgemm(X, W, Y, M, N, K, (K, 1), (1, K), (N, 1)),
                      "dgrad": lambda: AG.bgemm(Y, W, dX, M, K, N, (N, 1), (K, 1), (K, 1)),
                      "wgrad": lambda: (dW.zero_() if ks > 1 else None, AG.bgemm(Y, X, dW, N, K, M, (1, N), (K, 1), (K, 1), ksplit=ks))}
                 for kind, fn in f.items():
+                    if os.environ.get("KS") and kind != "wgrad":
+                        continue
                     us = timeit(fn)
                     nbytes = 4 * (M * K + N * K + M * N)
                     print(f"  {name:18s} {kind:5s} M={M} N={N} K={K}: {us:7.1f} us  {2 * M * N * K / us / 1e6:7.1f} TF/s  {nbytes / us / 1e3:7.0f} GB/s", flush=True)
