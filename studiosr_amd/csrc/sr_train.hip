@@ -361,25 +361,51 @@ SR_DEV void hg_store(bf16* __restrict__ tile, const float (&v)[ROWS / 8]) {
 //   * TWO K steps of operands in flight in registers (the loads of step t + 2 are issued before the MFMAs of step t);
 //   * BN = 64 where that gives more / fuller workgroups (N = 180, 360, 540: 6 % padding instead of 18-42 %);
 //   * result tiles computed transposed (MFMA operands swapped) when C is row-major, so a lane owns 4 consecutive n: 16-byte stores.
-template <int MA, int MB, int BN>
-__global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
+// XCD-aware workgroup order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): in the natural (x fastest) order
+// the n-tiles that re-read one A panel -- or the 15 tiles that share one split-K token slab -- land on 8 different XCDs and every panel
+// crosses the fabric up to 8 times (all Linear / conv GEMMs of a training step sat at ~5 TB/s of such traffic whatever their shape).
+// Here the workgroups of one XCD (linear id = xcd mod 8) own whole sharing groups: all n-tiles of an m-tile, or all tiles of a (batch, K slice).
+struct BgemmGrid {
+    int gx, gy, nz, natural;
+    SR_DEV bool decode(int& bx, int& by, int& bz) const {
+        if (natural) {
+            int t = blockIdx.x;
+            bx = t % gx, t /= gx;
+            by = t % gy, bz = t / gy;
+            return bz < nz;
+        }
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if (nz > 1) {
+            const int inner = gx * gy, outer = (j / inner) * 8 + xcd, t = j % inner;
+            bx = t % gx, by = t / gx, bz = outer;
+            return outer < nz;
+        }
+        bx = j % gx, by = (j / gx) * 8 + xcd, bz = 0;
+        return by < gy;
+    }
+    unsigned blocks() const { return natural ? (unsigned)gx * gy * nz : nz > 1 ? (unsigned)((nz + 7) / 8 * 8) * gx * gy : (unsigned)((gy + 7) / 8 * 8) * gx; }
+};
+
+template <int MA, int MB, int BN, bool TR>
+__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void sr_bgemm_bf16_kernel(SrBgemm g, BgemmGrid grid) {
     constexpr int NTW = BN / 32;  // n tiles per wave (waves 2 x 2: 64 rows x BN / 2 columns each)
     __shared__ __attribute__((aligned(16))) bf16 lds[2][(BT + BN) * HLD];  // [buffer][A rows | B rows][k]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
     const int li = lane & 15, lg = lane >> 4;
-    int z = blockIdx.z;
+    int bx, by, z;
+    if (!grid.decode(bx, by, z)) return;
     const int ks = z % g.ksplit;
     z /= g.ksplit;
     const int b2 = z % g.nb2, b1 = z / g.nb2;
     const float* A = g.A + (long long)b1 * g.sa_b1 + (long long)b2 * g.sa_b2;
     const float* B = g.B + (long long)b1 * g.sb_b1 + (long long)b2 * g.sb_b2;
     float* C = g.C + (long long)b1 * g.sc_b1 + (long long)b2 * g.sc_b2;
-    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BN;
+    const int m0 = by * BT, n0 = bx * BN;
     const int kchunk = (((g.K + g.ksplit - 1) / g.ksplit) + HK - 1) / HK * HK;
     const int kbeg = ks * kchunk, kend = min(g.K, kbeg + kchunk);
     const int nsteps = kbeg < kend ? (kend - kbeg + HK - 1) / HK : 0;
     // row-major C (unit column stride, 16-byte aligned rows), no split-K atomics: lane = row m, registers = 4 consecutive columns
-    const bool tr = g.ksplit == 1 && g.sc_n == 1 && (g.sc_m & 3) == 0 && ((g.sc_b1 | g.sc_b2) & 3) == 0 && (reinterpret_cast<size_t>(g.C) & 15) == 0;
+    constexpr bool tr = TR;
     f32x4 acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -408,7 +434,7 @@ __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
         for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const Frag<bf16>*>(At + (wm * 64 + i * 16 + li) * HLD + 8 * lg);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bv[j] = *reinterpret_cast<const Frag<bf16>*>(Bt + (wn * (BN / 2) + j * 16 + li) * HLD + 8 * lg);
-        if (tr) {
+        if constexpr (tr) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
             if (t + 1 < nsteps) step(I1{}, t + 1);
         }
     }
-    if (tr) {
+    if constexpr (tr) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int m = m0 + wm * 64 + 16 * mt + li;
@@ -489,6 +515,11 @@ __global__ __launch_bounds__(256) void sr_bgemm_bf16_kernel(SrBgemm g) {
         }
 }
 
+// row-major C (unit column stride, 16-byte aligned rows) and no split-K atomics: result tiles are computed transposed, 16-byte stores
+bool bgemm_row_major_out(const SrBgemm& g) {
+    return g.ksplit == 1 && g.sc_n == 1 && (g.sc_m & 3) == 0 && ((g.sc_b1 | g.sc_b2) & 3) == 0 && (reinterpret_cast<size_t>(g.C) & 15) == 0;
+}
+
 template <int MA, int MB>
 void launch_bf16(const SrBgemm& g, long long nz, hipStream_t st) {
     // BN = 64 where it pads N less or where 128-wide tiles leave the chip under-filled
@@ -496,10 +527,22 @@ void launch_bf16(const SrBgemm& g, long long nz, hipStream_t st) {
     const long long t128 = (long long)((g.N + 127) / 128) * ((g.M + BT - 1) / BT) * nz;
     const bool pad64 = ((g.N + 63) / 64) * 64 < ((g.N + 127) / 128) * 128;
     const bool bn64 = force ? force == 64 : (pad64 || t128 < 1024);
-    if (bn64)
-        hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 64>), dim3((g.N + 63) / 64, (g.M + BT - 1) / BT, (unsigned)nz), dim3(256), 0, st, g);
-    else
-        hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 128>), dim3((g.N + 127) / 128, (g.M + BT - 1) / BT, (unsigned)nz), dim3(256), 0, st, g);
+    // measured in the HAT / SwinIR training steps: the remap pays for plain GEMMs (one A panel per m-tile: -20..25 % per launch), not for
+    // batched / split-K launches, which keep the x-fastest order.  SR_BGEMM_NATURAL=1 switches it off everywhere (A/B knob).
+    static const int natural = getenv("SR_BGEMM_NATURAL") ? atoi(getenv("SR_BGEMM_NATURAL")) : 2;
+    const int nat = natural == 1 || (natural == 2 && nz > 1);
+    const BgemmGrid g64{(g.N + 63) / 64, (g.M + BT - 1) / BT, (int)nz, nat}, g128{(g.N + 127) / 128, (g.M + BT - 1) / BT, (int)nz, nat};
+    if (bgemm_row_major_out(g)) {
+        if (bn64)
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 64, true>), dim3(g64.blocks()), dim3(256), 0, st, g, g64);
+        else
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 128, true>), dim3(g128.blocks()), dim3(256), 0, st, g, g128);
+    } else {
+        if (bn64)
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 64, false>), dim3(g64.blocks()), dim3(256), 0, st, g, g64);
+        else
+            hipLaunchKernelGGL((sr_bgemm_bf16_kernel<MA, MB, 128, false>), dim3(g128.blocks()), dim3(256), 0, st, g, g128);
+    }
 }
 
 // ----------------------------------------------------------------------------- im2col / col2im, column order (tap, c)
@@ -1055,13 +1098,13 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
         const int ma = g.sa_k == 1 ? 0 : (vec_rows(g.A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2) ? 1 : 2);
         const int mb = g.sb_k == 1 ? 0 : (vec_rows(g.B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2) ? 1 : 2);
         if (ma == 2 || mb == 2) {  // rare: generic strides on either side -> both operands through the scalar staging, 128 x 128 tiles
-            const dim3 grid((g.N + 127) / 128, (g.M + BT - 1) / BT, (unsigned)nz);
+            const BgemmGrid gg{(g.N + 127) / 128, (g.M + BT - 1) / BT, (int)nz, nz > 1};
             if (ma == 0)
-                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 2, 128>), grid, dim3(256), 0, ST, g);
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<0, 2, 128, false>), dim3(gg.blocks()), dim3(256), 0, ST, g, gg);
             else if (mb == 0)
-                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 0, 128>), grid, dim3(256), 0, ST, g);
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 0, 128, false>), dim3(gg.blocks()), dim3(256), 0, ST, g, gg);
             else
-                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 2, 128>), grid, dim3(256), 0, ST, g);
+                hipLaunchKernelGGL((sr_bgemm_bf16_kernel<2, 2, 128, false>), dim3(gg.blocks()), dim3(256), 0, ST, g, gg);
         } else if (ma == 0 && mb == 0)
             launch_bf16<0, 0>(g, nz, ST);
         else if (ma == 0)
