@@ -84,6 +84,13 @@ typedef struct SrGemm {
                            * [B][H+2p][W+2p][heads][hd_p]; v -> transposed zero-bordered [B][heads][hd_p][(H+2p)*(W+2p)]; p = oca_pad = physical border (multiple of 4).
                            * Rows must be in window order (a_map = SR_MAP_WINDOW, shift 0); the borders are zeroed by the caller. */
     int y_mode;           /* SR_Y_* (window maps only) */
+    /* Optional gated second residual of the SR_EPI_STD epilogue (ABI v4; HAT, hat.py:192: x = shortcut + attn + conv_scale * CAB(x)):
+     *   out[row][n] += skip2[row][n] * skip2_gate[row / gate_rows][n]
+     * skip2 = the CAB conv output (NHWC, skip2_dtype, row stride ldskip2) addressed like `out`; skip2_gate = per-image channel gates
+     * from sr_channel_gate (row stride ld_gate).  Replaces a separate sr_channel_attention pass over the stream. */
+    const void* skip2;
+    const float* skip2_gate;
+    int skip2_dtype, ldskip2, gate_rows, ld_gate;
 } SrGemm;
 int sr_gemm(const SrGemm* a, void* stream);
 
@@ -250,6 +257,10 @@ typedef struct SrChannelAttn {
     int skip2_dtype;
 } SrChannelAttn;
 int sr_channel_attention(const SrChannelAttn* a, void* stream);
+/* The squeeze half alone: gate[b][c] = y_scale * sigmoid(W2 relu(W1 mean_b + b1) + b2) for c < C, 0 for C <= c < C_p (fp32 [B, C_p]);
+ * same arithmetic as sr_channel_attention.  Consumed by sr_gemm's gated second residual.  Only pool_partial, w1, b1, w2, b2, B, H, W, C,
+ * C_p, Cr, n_tiles and y_scale of the struct are read. */
+int sr_channel_gate(const SrChannelAttn* a, float* gate, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class SrGemm(C.Structure):
         ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
         ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
         ("ln_eps", _f), ("ln_norm_only", _i), ("oca_pad", _i), ("y_mode", _i),
+        ("skip2", _vp), ("skip2_gate", _vp), ("skip2_dtype", _i), ("ldskip2", _i), ("gate_rows", _i), ("ld_gate", _i),
     ]
 
 
@@ -141,6 +142,7 @@ SYMBOLS = {
     "sr_u8_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_nchw_to_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sr_channel_attention": (_i, [C.POINTER(SrChannelAttn), _vp]),
+    "sr_channel_gate": (_i, [C.POINTER(SrChannelAttn), _vp, _vp]),
     # training engine (ABI v3)
     "sr_bgemm": (_i, [C.POINTER(SrBgemm), _vp]),
     "sr_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp]),

@@ -178,19 +178,18 @@ SR_DEV f32x4 ld4(const void* p, size_t off, int dtype) {
     return dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(p) + off) : load4(reinterpret_cast<const float*>(p) + off);
 }
 
-__global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
-    extern __shared__ float sm[];
+// The squeeze half (pool partials -> mean -> 2-layer MLP -> sigmoid) for image b; leaves y_scale * gate in sm + C_p + Cr (C_p floats).
+// Recomputed by every workgroup that needs it, so it must be short: every step spreads its (independent) loads over all 256 threads
+// instead of walking n_tiles / C / Cr dependent loads in a few of them.
+SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
     float* mean = sm;                 // [C_p]
     float* hid = sm + a.C_p;          // [Cr]
     float* gate = hid + a.Cr;         // [C_p]
     float* part = gate + a.C_p;       // [CA_SLICES][C_p] partial channel sums
     constexpr int CA_SLICES = 8;
-    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / (float)(a.H * a.W);
-    // The squeeze MLP is recomputed by every workgroup, so it must be short: every step spreads its (independent) loads
-    // over all 256 threads instead of walking n_tiles / C / Cr dependent loads in a few of them.
     for (int idx = tid; idx < CA_SLICES * a.C_p; idx += 256) {
         const int sl = idx / a.C_p, c = idx - sl * a.C_p;
         float s = 0.f;
@@ -227,6 +226,20 @@ __global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
         gate[c] = s * a.y_scale;
     }
     __syncthreads();
+    return gate;
+}
+
+__global__ __launch_bounds__(256) void sr_channel_gate_kernel(SrChannelAttn a, float* __restrict__ out) {
+    extern __shared__ float sm[];
+    const float* gate = ca_squeeze(a, blockIdx.x, sm);
+    for (int c = threadIdx.x; c < a.C_p; c += 256) out[(size_t)blockIdx.x * a.C_p + c] = gate[c];
+}
+
+__global__ __launch_bounds__(256) void sr_channel_attn_kernel(SrChannelAttn a) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float* gate = ca_squeeze(a, b, sm);
     const int groups = a.C_p >> 2;
     const long per_img = (long)a.H * a.W * groups;
     for (long i = (long)blockIdx.x * 256 + tid; i < per_img; i += (long)gridDim.x * 256) {
@@ -336,6 +349,16 @@ extern "C" int sr_pixel_shuffle_nchw(const void* in, void* out, int elem_size, i
         hipLaunchKernelGGL(sr_pixel_shuffle_kernel<uint32_t>, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(in),
                            reinterpret_cast<uint32_t*>(out), B, C_out, H, W, r);
     SR_CHECK_LAUNCH("sr_pixel_shuffle_nchw");
+    return SR_OK;
+}
+
+extern "C" int sr_channel_gate(const SrChannelAttn* p, float* gate, void* stream) {
+    SR_REQUIRE(p && gate && p->pool_partial && p->w1 && p->b1 && p->w2 && p->b2, "sr_channel_gate: null pointer");
+    const SrChannelAttn& a = *p;
+    SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= a.C_p && a.C_p % 4 == 0 && a.Cr > 0 && a.n_tiles > 0, "sr_channel_gate: bad geometry");
+    const int lds = (2 * a.C_p + a.Cr + 8 * a.C_p) * (int)sizeof(float);
+    hipLaunchKernelGGL(sr_channel_gate_kernel, dim3(a.B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a, gate);
+    SR_CHECK_LAUNCH("sr_channel_gate");
     return SR_OK;
 }
 

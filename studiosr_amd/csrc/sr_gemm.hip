@@ -176,6 +176,13 @@ SR_DEV void gemm_body(const SrGemm& g, const Frag<TC>* As, int m0, const WinMap&
                         store4(reinterpret_cast<float*>(base) + off, v);
                 } else {
                     if (g.skip) v += load4(g.skip + (size_t)orow * g.ldskip + col);
+                    if (g.skip2) {  // gated second residual (HAT: + conv_scale * CAB): one fma per element
+                        const size_t o2 = (size_t)orow * g.ldskip2 + col;
+                        const f32x4 y2 = g.skip2_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(g.skip2) + o2) : load4(reinterpret_cast<const float*>(g.skip2) + o2);
+                        const f32x4 gt = load4(g.skip2_gate + (size_t)(orow / g.gate_rows) * g.ld_gate + col);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(y2[r], gt[r], v[r]);
+                    }
                     const size_t off = (size_t)orow * g.ldo + col;
                     if (g.out_dtype == SR_BF16)
                         store4(reinterpret_cast<bf16*>(g.out) + off, v);
@@ -285,10 +292,11 @@ extern "C" int sr_gemm(const SrGemm* a, void* stream) {
         SR_REQUIRE(g.out_k && g.out_vt && g.heads > 0 && g.hd_p % 16 == 0 && g.N == 3 * g.heads * g.hd_p && g.ntok % 16 == 0 && g.M % g.ntok == 0 &&
                        (g.heads * g.hd_p) % 64 == 0,
                    "sr_gemm: bad QKV epilogue geometry");
-        SR_REQUIRE(g.skip == nullptr, "sr_gemm: QKV epilogue takes no residual");
+        SR_REQUIRE(g.skip == nullptr && g.skip2 == nullptr, "sr_gemm: QKV epilogue takes no residual");
     } else {
         SR_REQUIRE(g.ldo >= g.N, "sr_gemm: ldo %d < N %d", g.ldo, g.N);
         SR_REQUIRE(!g.skip || g.ldskip >= g.N, "sr_gemm: ldskip");
+        SR_REQUIRE(!g.skip2 || (g.skip2_gate && g.ldskip2 >= g.N && g.ld_gate >= g.N && g.gate_rows > 0), "sr_gemm: gated second residual: gate, ldskip2, ld_gate >= N, gate_rows > 0");
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {

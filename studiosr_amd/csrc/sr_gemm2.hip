@@ -271,6 +271,13 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
                     store4(reinterpret_cast<bf16*>(part == 0 ? g.out : g.out_k) + off, v);
                 } else {
                     if (g.skip && !a.acc_from_skip) v += load4(g.skip + (size_t)orow[m] * g.ldskip + col);
+                    if (g.skip2) {  // gated second residual (HAT: + conv_scale * CAB): one fma per element
+                        const size_t o2 = (size_t)orow[m] * g.ldskip2 + col;
+                        const f32x4 y2 = g.skip2_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(g.skip2) + o2) : load4(reinterpret_cast<const float*>(g.skip2) + o2);
+                        const f32x4 gt = load4(g.skip2_gate + (size_t)(orow[m] / g.gate_rows) * g.ld_gate + col);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(y2[r], gt[r], v[r]);
+                    }
                     const size_t off = (size_t)orow[m] * g.ldo + col;
                     if (g.out_dtype == SR_BF16)
                         store4(reinterpret_cast<bf16*>(g.out) + off, v);

@@ -268,27 +268,43 @@ class HAT(Model):
         f32 = torch.float32
         # conv branch on LayerNorm1(x)  (hat.py:165-170)
         n1 = ws_.get("hab.n1", (B, H, W, Cp), cdt)  # consumed only by the conv, which rounds to the compute dtype anyway
-        ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+        unfused = not (ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sr_dtype(cdt)))  # run_window_msa will take its GEMM path
+        if not unfused:  # the one-kernel attention half writes t (= t_in when in place) before any join: LayerNorm1 must run ahead of it
+            ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
         n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt))
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
-        # The conv branch (2 launches) and the attention branch (3 launches) only share their input, and at the tile sizes of this model
-        # every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention branch (fork after
-        # LayerNorm1 -- the in-place projection must not overtake it -- join before the combine).  Also valid under HIP-graph capture.
+        # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
+        # tile sizes of this model every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention
+        # branch and joins before the projection GEMM -- the first writer of t (which may be t_in) and the consumer of the conv branch.
+        # Also valid under HIP-graph capture.
         main = torch.cuda.current_stream(t_in.device)
         side = self._side_stream(t_in.device) if self.dual_stream else main
+        gate = ws_.get("hab.gate", (B, Cp), f32)
+        w1, b1, w2, b2 = bp["ca"]
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
+            if unfused:
+                ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
             conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
             conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
-        # attention branch + shortcut -> t   (hat.py:172-188)
-        run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab")
-        if side is not main:
-            main.wait_stream(side)
-        # x = shortcut + attn + conv_scale * CA(cab)   (hat.py:192)
-        run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
+            # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
+            ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
+                             C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
+
+        def join():  # the projection is the first launch that needs the conv branch
+            if side is not main:
+                main.wait_stream(side)
+            return dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
+
+        # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
+        if not run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join):
+            # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
+            if side is not main:
+                main.wait_stream(side)
+            run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
         run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")
 
     def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt) -> None:

@@ -162,9 +162,11 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL) -> None:
+                   y_mode: int = L.Y_ROLL, before_proj=None) -> bool:
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
-    t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip)."""
+    t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
+    before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
+    second residual).  Returns True iff it was used (the one-kernel attention half has no hook)."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -175,7 +177,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
             bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
             hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode,
         )
-        return
+        return False
     q = ws_.get(name + ".q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
@@ -190,11 +192,13 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
         q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
         hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
     )
+    extra = before_proj() if before_proj is not None else {}
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,
-        out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_STD, y_mode=y_mode,
+        out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_WINDOW, H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_STD, y_mode=y_mode, **extra,
     )
+    return before_proj is not None
 
 
 def run_mlp(p: Dict, ln, geo: SwinGeometry, t: Tensor, ws_, cdt: torch.dtype, name: str = "mlp") -> None:

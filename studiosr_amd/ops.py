@@ -124,6 +124,13 @@ def channel_attention(**kw) -> None:
     L.check(L.lib().sr_channel_attention(C.byref(a), _stream()), "sr_channel_attention")
 
 
+def channel_gate(gate: Tensor, **kw) -> None:
+    a = L.SrChannelAttn()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_channel_gate(C.byref(a), gate.data_ptr(), _stream()), "sr_channel_gate")
+
+
 def pixel_shuffle(x: Tensor, r: int) -> Tensor:
     """nn.PixelShuffle(r) on an NCHW device tensor (bit-exact copy kernel)."""
     B, Cin, H, W = x.shape
