@@ -509,6 +509,61 @@ def test_gated_rcab_equals_channel_attention_then_conv_pair():
                            pool_partial=pool_got.data_ptr(), **kw)
 
 
+@pytest.mark.parametrize("cin,shape", [(64, (3, 37, 45)), (256, (2, 19, 50)), (64, (1, 8, 16))])
+def test_rgb_tail_conv_persistent_kernel_against_conv2d(cin, shape):
+    """sr_conv_narrow.hip (persistent workgroups, register-resident weights, K split over waves for 256 channels) through sr_conv3x3's
+    final-NCHW mode, on images that are no multiple of the tile in either direction, against F.conv2d on the bf16-rounded operands
+    (fp32 accumulate on both sides: only the summation order differs) incl. the un-normalise affine and the crop."""
+    torch.manual_seed(cin)
+    B, H, W = shape
+    w = (torch.randn(3, cin, 3, 3) * 0.05).to(DEV)
+    b = torch.randn(3).to(DEV)
+    x = torch.randn(B, H, W, cin, device=DEV).to(torch.bfloat16)
+    wp, bp = packing.pack_conv3x3(w, b, cin, packing.identity_idx(3, 16), torch.bfloat16)
+    fs, fb = torch.tensor([2.0, 0.5, 1.5], device=DEV), torch.tensor([0.1, -0.2, 0.3], device=DEV)
+    fh, fw = H - 1, W - 2  # cropped output
+    out = torch.full((B, 3, fh, fw), float("nan"), device=DEV)
+    conv_call(x, wp, bp, out, torch.bfloat16, out_mode=L.OUT_FINAL_NCHW, fin=(fs, fb, 3, fh, fw), cout_p=16)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, padding=1)
+    ref = (ref * fs.view(1, 3, 1, 1) + fb.view(1, 3, 1, 1))[:, :, :fh, :fw]
+    assert not torch.isnan(out).any()
+    assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_gated_second_residual_of_the_projection_gemm_equals_channel_attention():
+    """HAT's combine x = shortcut + attn + conv_scale * CA(cab) (hat.py:192): sr_channel_gate + sr_gemm's gated second residual against the
+    two-pass form (projection GEMM with the shortcut, then sr_channel_attention over the stream)."""
+    from studiosr_amd.models.rcan import pack_ca, run_channel_attention
+
+    torch.manual_seed(21)
+    B, H, W, C, Cp, Cr = 2, 16, 16, 180, 192, 6
+    M = B * H * W
+    a = torch.randn(M, Cp, device=DEV).to(torch.bfloat16)
+    wl = torch.randn(C, C, device=DEV) * 0.05
+    wp, bp = packing.pack_linear(wl, torch.randn(C, device=DEV) * 0.1, packing.identity_idx(C, Cp), packing.identity_idx(C, Cp), torch.bfloat16)
+    shortcut = torch.randn(B, H, W, Cp, device=DEV)
+    shortcut[..., C:] = 0
+    y = torch.randn(B, H, W, Cp, device=DEV).to(torch.bfloat16)
+    y[..., C:] = 0
+    n_tiles = 5
+    pool = torch.randn(B, n_tiles, Cp, device=DEV)
+    ca = pack_ca(torch.randn(Cr, C, 1, 1, device=DEV) * 0.3, torch.randn(Cr, device=DEV) * 0.1, torch.randn(C, Cr, 1, 1, device=DEV) * 0.3, torch.randn(C, device=DEV) * 0.1)
+    gkw = dict(A=a.data_ptr(), Wp=wp.data_ptr(), bias=bp.data_ptr(), M=M, K=Cp, N=Cp, lda=Cp, ldo=Cp, ldskip=Cp, a_dtype=L.SR_BF16, out_dtype=L.SR_F32,
+               compute_dtype=L.SR_BF16, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_IDENTITY, o_map=L.MAP_IDENTITY, epi=L.EPI_STD)
+    want = torch.empty(B, H, W, Cp, device=DEV)
+    ops.gemm(out=want.data_ptr(), skip=shortcut.data_ptr(), **gkw)
+    run_channel_attention(ca, y, pool, n_tiles, C, want, skip=want, y_scale=0.01)
+    gate = torch.full((B, Cp), float("nan"), device=DEV)
+    w1, b1, w2, b2 = ca
+    ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W, C=C, C_p=Cp,
+                     Cr=Cr, n_tiles=n_tiles, y_scale=0.01)
+    assert float(gate[:, C:].abs().max()) == 0.0 and float(gate[:, :C].min()) > 0.0 and float(gate[:, :C].max()) < 0.01
+    got = torch.full_like(want, float("nan"))
+    ops.gemm(out=got.data_ptr(), skip=shortcut.data_ptr(), skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=L.SR_BF16, ldskip2=Cp, gate_rows=H * W,
+             ld_gate=Cp, **gkw)
+    assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))  # same products, one rounding order apart
+
+
 def test_errors_are_loud():
     m = S.EDSR(scale=2, n_feats=32, n_resblocks=1).to(DEV).eval()
     with pytest.raises(RuntimeError):
