@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
 //   * the 4 waves of a workgroup are 4 consecutive windows of the same (head, query block): they read the same bias
 //     tiles, which therefore come from the CU's L1.
 template <typename TC, int KT, int QT, int DC>
-__global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn a) {
+__global__ __launch_bounds__(256, 2) void sr_window_attn_flash_kernel(SrWindowAttn a) {
     static_assert(KT % 4 == 0 && KT % QT == 0, "key blocks of 64");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -244,20 +244,49 @@ __global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn 
         for (int dt = 0; dt < 2 * DC; ++dt) o[dt][t] = (f32x4)(0.0f);
     }
 
+    // bf16: the bias tiles and K fragments of key block kb + 1 and the V fragments of block kb are requested before the MFMAs / softmax of
+    // block kb (the first version fetched each right before its use: three exposed L2 round trips per key block, 20+ us per wave)
+    constexpr bool PF = sizeof(TC) == 2;
+    constexpr int NB = PF ? 2 : 1;
+    f32x4 bb[NB][4][QT];
+    Frag<TC> kk[NB][4][DC];
+    auto fetch = [&](int kb, f32x4 (&b)[4][QT], Frag<TC> (&kf)[4][DC]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) b[j][t] = bfrag[((size_t)t * KT + kb * 4 + j) * 64];
+#pragma unroll
+            for (int c = 0; c < DC; ++c) kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
+        }
+    };
+    if constexpr (PF) fetch(0, bb[0], kk[0]);
+#pragma unroll
     for (int kb = 0; kb < KT / 4; ++kb) {
+        const int cur = PF ? (kb & 1) : 0;
+        Frag<TC> vf[2 * DC][2];
+        if constexpr (PF) {
+#pragma unroll
+            for (int dt = 0; dt < 2 * DC; ++dt) {
+                const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+            }
+            if (kb + 1 < KT / 4) fetch(kb + 1, bb[(kb + 1) & 1], kk[(kb + 1) & 1]);
+        } else {
+            fetch(kb, bb[0], kk[0]);
+        }
         // ---- S^T tiles of this key block: bias tile + K Q^T
         f32x4 s[4][QT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < QT; ++t) s[j][t] = bfrag[((size_t)t * KT + kb * 4 + j) * 64];
+            for (int t = 0; t < QT; ++t) s[j][t] = bb[cur][j][t];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-                const Frag<TC> kf = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
 #pragma unroll
-                for (int t = 0; t < QT; ++t) mma(kf, qf[t][c], s[j][t]);
+                for (int t = 0; t < QT; ++t) mma(kk[cur][j][c], qf[t][c], s[j][t]);
             }
         if (masked) {
 #pragma unroll
@@ -309,11 +338,11 @@ __global__ __launch_bounds__(256) void sr_window_attn_flash_kernel(SrWindowAttn 
             const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const Frag<TC> vf = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+                if constexpr (!PF) vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     const Frag<TC> pf = pack_p<TC>(s[2 * ks][t], s[2 * ks + 1][t]);
-                    mma(vf, pf, o[dt][t]);
+                    mma(vf[dt][ks], pf, o[dt][t]);
                 }
             }
         }
