@@ -1,8 +1,10 @@
 """HAN on the HIP path (reference: studiosr/models/han.py): RCAN's residual groups plus a layer-attention module over the 11 group
 outputs (LAM, han.py:12-33) and a channel-spatial attention module (CSAM: a 3x3x3 Conv3d over the (C, H, W) volume, han.py:36-53).
 
-Same constructor kwargs / state_dict keys as the reference.  The forward runs on the generic fp32 engine (studiosr_amd/autograd.py) in
-eval and train mode and is differentiable end to end.
+Same constructor kwargs / state_dict keys as the reference.  Inference runs RCAN's launch sequence for the head and the residual groups
+(one fused launch per RCAB in bf16) and for the upsampler / tail, and the generic engine (studiosr_amd/autograd.py) for the attention
+tail between them (LAM, CSAM, the two fusing convs); whenever autograd is recording the whole model runs on that engine and is
+differentiable end to end.
 """
 from __future__ import annotations
 
@@ -12,9 +14,12 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from .common import Model, Upsampler, conv2d
+from .. import _lib as L
+from .. import ops
+from ..runtime import compute_dtype
+from .common import Model, Upsampler, conv2d, conv_call, run_upsampler
 from .edsr import MeanShift
-from .rcan import ResidualGroup
+from .rcan import RCAN, ResidualGroup
 
 
 class LAM_Module(nn.Module):
@@ -46,10 +51,41 @@ class HAN(Model):
         self.last_conv = nn.Conv2d(n_feats * (n_resgroups + 1), n_feats, 3, 1, 1)  # han.py:87 hard-codes 11 = the default n_resgroups + 1
         self.last = nn.Conv2d(n_feats * 2, n_feats, 3, 1, 1)
 
+    _pack = RCAN._pack            # head / residual groups / body conv / upsampler / tail are RCAN's modules under the same names
+    _run_groups = RCAN._run_groups
+
     def forward(self, x):
+        y = self._train_forward(x)
+        if y is not None:
+            return y
+        from .. import autograd as A
         from . import train
 
-        return train.han_forward(self, self._check_input(x))
+        x = self._check_input(x)
+        cdt = compute_dtype(self.precision)
+        P = self._get_packed(cdt)
+        ws_ = self._workspace(x.device)
+        B, _, H, W = x.shape
+        Fp, F, f32 = P["Fp"], self.n_feats, torch.float32
+        xin = ws_.get("xin", (B, H, W, 32), cdt)
+        ops.ingest_nchw(x, xin, L.PAD_NONE, *P["ing"])
+        h = ws_.get("head", (B, H, W, Fp), f32)
+        conv_call(xin, *P["head"], h, cdt)
+        g, feats = self._run_groups(P, h, ws_, cdt, keep_all=True)
+        last = ws_.get(f"feat{len(feats)}", (B, H, W, Fp), f32)
+        conv_call(g, *P["body_last"], last, cdt)  # han.py:99: no long skip here, it follows the attention tail
+        unpad = (lambda t: t) if Fp == F else (lambda t: t[..., :F].contiguous())
+        with torch.no_grad(), A.autocast_state(cdt == torch.bfloat16):  # LAM, CSAM, last_conv, last (han.py:96-113)
+            r = train.han_attention(self, [unpad(t) for t in feats + [last]], unpad(h))
+        res = ws_.get("res", (B, H, W, Fp), cdt)
+        res[..., :F] = r
+        if Fp != F:
+            res[..., F:] = 0
+        up = run_upsampler(P["up"], res, ws_, cdt, "han")
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=f32, device=x.device)
+        conv_call(up, *P["tail"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(*P["fin"], self.n_colors, H * s, W * s), cout_p=16)
+        return out
 
     def get_model_config(self) -> Dict:
         config = super().get_model_config()

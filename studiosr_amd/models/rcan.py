@@ -90,28 +90,18 @@ class RCAN(Model):
         P["tail"] = packing.pack_conv3x3(self.tail[1].weight, self.tail[1].bias, P["up"][-1][3], packing.identity_idx(self.n_colors, 16), dt)
         return P
 
-    def forward(self, x: Tensor) -> Tensor:
-        y = self._train_forward(x)
-        if y is not None:
-            return y
-        x = self._check_input(x)
-        cdt = compute_dtype(self.precision)
-        P = self._get_packed(cdt)
-        ws_ = self._workspace(x.device)
-        B, _, H, W = x.shape
-        Fp = P["Fp"]
+    def _run_groups(self, P: Dict, h: Tensor, ws_, cdt, keep_all: bool = False):
+        """The residual groups (rcan.py:27-36) on the fp32 NHWC stream h; returns (last group output, [every group output]).
+        keep_all: every group output gets its own buffer (HAN's layer attention reads all of them)."""
+        B, H, W, Fp = h.shape
         f32 = torch.float32
-        xin = ws_.get("xin", (B, H, W, 32), cdt)
-        ops.ingest_nchw(x, xin, L.PAD_NONE, *P["ing"])
-        h = ws_.get("head", (B, H, W, Fp), f32)
-        conv_call(xin, *P["head"], h, cdt)
         # bf16, 64 (padded) channels: conv-ReLU-conv of an RCAB is ONE launch (sr_rcab_conv_pair, the intermediate stays in LDS)
         fused_pair = cdt == torch.bfloat16 and Fp == 64
         n_tiles = ops.rcab_pool_tiles(H, W) if fused_pair else ops.conv_pool_tiles(H, W, Fp, sr_dtype(cdt))
         pool = ws_.get("pool", (B, n_tiles, Fp), f32)
         mid = ws_.get("mid", (B, H, W, Fp), cdt)
         y = ws_.get("y", (B, H, W, Fp), f32)
-        ga, gb = ws_.get("ga", (B, H, W, Fp), f32), ws_.get("gb", (B, H, W, Fp), f32)
+        ga, gb = (None, None) if keep_all else (ws_.get("ga", (B, H, W, Fp), f32), ws_.get("gb", (B, H, W, Fp), f32))
         ra, rb = ws_.get("ra", (B, H, W, Fp), f32), ws_.get("rb", (B, H, W, Fp), f32)
         # one launch per RCAB: block n+1 applies block n's channel-attention tail (gate * y + skip) while it stages its halo
         # (sr_rcab_conv_pair's gated input); y / pool alternate because block n+1 reads block n's while writing its own
@@ -121,7 +111,8 @@ class RCAN(Model):
             # read once, multiplied by the gate and added to the fp32 skip stream -- 25 % less HBM traffic per block, >= 50 dB kept
             y, y2, pool2 = ws_.get("yc", (B, H, W, Fp), cdt), ws_.get("y2", (B, H, W, Fp), cdt), ws_.get("pool2", (B, n_tiles, Fp), f32)
         g = h
-        for blocks, gconv in P["groups"]:
+        feats = []
+        for gi, (blocks, gconv) in enumerate(P["groups"]):
             r = g
             if chained:
                 ys, pools, prev = (y, y2), (pool, pool2), None  # prev = (skip, y, pool, ca) of the block whose tail is still pending
@@ -155,9 +146,28 @@ class RCAN(Model):
                     nxt = ra if (r is not ra) else rb
                     run_channel_attention(ca, y, pool, n_tiles, self.n_feats, nxt, skip=r)
                     r = nxt
-            gn = ga if (g is not ga) else gb
+            gn = ws_.get(f"feat{gi}", (B, H, W, Fp), f32) if keep_all else (ga if (g is not ga) else gb)
             conv_call(r, *gconv, gn, cdt, skip=g)  # group conv + skip (rcan.py:33-36)
             g = gn
+            feats.append(gn)
+        return g, feats
+
+    def forward(self, x: Tensor) -> Tensor:
+        y = self._train_forward(x)
+        if y is not None:
+            return y
+        x = self._check_input(x)
+        cdt = compute_dtype(self.precision)
+        P = self._get_packed(cdt)
+        ws_ = self._workspace(x.device)
+        B, _, H, W = x.shape
+        Fp = P["Fp"]
+        f32 = torch.float32
+        xin = ws_.get("xin", (B, H, W, 32), cdt)
+        ops.ingest_nchw(x, xin, L.PAD_NONE, *P["ing"])
+        h = ws_.get("head", (B, H, W, Fp), f32)
+        conv_call(xin, *P["head"], h, cdt)
+        g, _ = self._run_groups(P, h, ws_, cdt)
         res = ws_.get("res", (B, H, W, Fp), cdt)
         conv_call(g, *P["body_last"], res, cdt, skip=h)
         up = run_upsampler(P["up"], res, ws_, cdt, "rcan")

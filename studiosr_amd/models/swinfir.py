@@ -2,14 +2,15 @@
 a spatial conv branch plus a spectral branch (1x1 conv -> rfftn -> 1x1 conv on (real | imag) -> irfftn -> 1x1 conv), fused by a 1x1 conv.
 
 Same constructor kwargs and state_dict keys as the reference (`layers.i.conv.S.body.0.weight`, `...F.fu.conv_layer.weight`, ...).
-The forward runs on the generic fp32 engine (studiosr_amd/autograd.py) in eval AND train mode: the 2-D real FFT is two DFT matrix
-products on the fp32 matrix cores, so the model is differentiable end to end.  (The fused bf16 block kernels of SwinIR are not wired
-into this class yet: > 95 % of its FLOPs are the same Swin blocks, the remaining work is layout glue.)
+Inference is SwinIR's launch sequence -- the 36 Swin blocks are the one-launch block kernel (bf16) or the exact-fp32 GEMM / attention
+kernels -- with the 7 SFBs evaluated on the generic engine (studiosr_amd/autograd.py: the 2-D real FFT is two DFT matrix products on
+the fp32 matrix cores) between them; whenever autograd is recording the whole model runs on that engine and is differentiable end to end.
 """
 from __future__ import annotations
 
 from typing import Dict, List
 
+import torch
 import torch.nn as nn
 
 from .swinir import SwinIR
@@ -55,10 +56,26 @@ class SwinFIR(SwinIR):
             layer.conv = SFB(embed_dim)
         self.conv_after_body = SFB(embed_dim)  # swinfir.py:114
 
-    def forward(self, x):
+    def _pack_resi(self, m, C, Cp, dt):
+        return m  # the SFB's own parameters are read in place by the generic engine
+
+    def _run_resi(self, m, src, dst, skip, cdt) -> None:
+        """dst = SFB(src) + skip on the padded NHWC buffers of SwinIR.forward (swinfir.py:68-81, swinir.py:245-246,362)."""
+        from .. import autograd as A
         from . import train
 
-        return train.swinir_forward(self, self._check_input(x))
+        C = self.embed_dim
+        x = src[..., :C].float().contiguous()
+        with torch.no_grad(), A.autocast_state(cdt == torch.bfloat16):  # bf16 precision: bf16-operand contractions, as the Swin blocks
+            y = train._sfb(m, x)
+        if dst is skip:
+            dst[..., :C] += y
+        else:
+            dst[..., :C] = y + skip[..., :C]
+            dst[..., C:] = 0  # pad lanes stay zero end to end
+
+    def forward_strips(self, x, comm):
+        raise NotImplementedError("SwinFIR's spectral branch is a whole-image FFT: row strips with halo exchange do not apply")
 
     def get_training_config(self) -> Dict:  # swinfir.py:116-128
         return dict(batch_size=32, learning_rate=0.0002, beta1=0.9, beta2=0.99, weight_decay=0.0, max_iters=500000, gamma=0.5,

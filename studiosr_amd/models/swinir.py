@@ -320,10 +320,9 @@ class SwinIR(Model):
                 e.update(pack_attention(blk.attn, geo, dt, norm=blk.norm1))
                 e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
                 blocks.append(e)
-            conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, packing.identity_idx(C, Cp), dt)
-            P["layers"].append(dict(blocks=blocks, conv=conv, geo=geo))
+            P["layers"].append(dict(blocks=blocks, conv=self._pack_resi(layer.conv, C, Cp, dt), geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)
-        P["after_body"] = packing.pack_conv3x3(self.conv_after_body.weight, self.conv_after_body.bias, Cp, packing.identity_idx(C, Cp), dt)
+        P["after_body"] = self._pack_resi(self.conv_after_body, C, Cp, dt)
         P["fin"] = final_affine(self.img_range, self.n_colors, dev)
         P["ing"] = ingest_affine(self.img_range, self.n_colors, dev)
         if self.upsampler == "pixelshuffle":
@@ -334,6 +333,14 @@ class SwinIR(Model):
         elif self.upsampler == "pixelshuffledirect":
             P["up"] = pack_upsampler(self.upsample, Cp, dt, last_cps_p=direct_cps_p(self.n_colors, self.scale))
         return P
+
+    # ------------------------------------------------------------------ residual connection of an RSTB / conv_after_body (swinir.py:241,316)
+    def _pack_resi(self, m: nn.Module, C: int, Cp: int, dt: torch.dtype):
+        return packing.pack_conv3x3(m.weight, m.bias, Cp, packing.identity_idx(C, Cp), dt)
+
+    def _run_resi(self, packed, src: Tensor, dst: Tensor, skip: Tensor, cdt: torch.dtype) -> None:
+        """dst = resi(src) + skip on padded NHWC buffers (dst may be skip).  SwinIR: one 3x3 conv launch; SwinFIR overrides it with its SFB."""
+        conv_call(src, *packed, dst, cdt, skip=skip)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor) -> Tensor:
@@ -373,11 +380,11 @@ class SwinIR(Model):
             if cur is ta:
                 cur = ws_.get("tc", (B, Hp, Wp, Cp), torch.float32)
                 cur.copy_(ta)
-            conv_call(cur, *lp["conv"], ta, cdt, skip=ta)
+            self._run_resi(lp["conv"], cur, ta, ta, cdt)
         normed = ws_.get("normed", (B, Hp, Wp, Cp), cdt)  # read only by the conv, which rounds to the compute dtype anyway
         ops.layernorm(ta, normed, *P["norm"], self.embed_dim)
         body = ws_.get("body", (B, Hp, Wp, Cp), cdt)
-        conv_call(normed, *P["after_body"], body, cdt, skip=first)  # conv_after_body(features) + x  (swinir.py:362)
+        self._run_resi(P["after_body"], normed, body, first, cdt)  # conv_after_body(features) + x  (swinir.py:362)
 
         s = self.scale
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)

@@ -213,6 +213,23 @@ def rcan_forward(model, x: Tensor) -> Tensor:
     return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
 
 
+def han_attention(model, feats: List[Tensor], h: Tensor) -> Tensor:
+    """HAN's attention tail (han.py:96-113) on fp32 NHWC tensors: layer attention over the group outputs + channel-spatial attention on
+    the last one, fused by two 3x3 convs, + the head feature.  feats = [group outputs..., body conv output]."""
+    B, H, W, F = h.shape
+    out1 = feats[-1]
+    # LAM over the N = n_resgroups + 1 features, newest first (han.py:96-103): each feature is one vector of H*W*C values
+    N = len(feats)
+    stack = A.concat(*[f.reshape(B, H * W * F) for f in reversed(feats)]).reshape(B, N, H * W * F)
+    la = A.add(A.scale_param(A.layer_attention(stack), model.la.gamma), stack)                      # gamma * out + x  (han.py:31)
+    la = A.concat(*[A.slice_channels(la.reshape(B, N * H * W * F), n * H * W * F, H * W * F).reshape(B * H * W, F) for n in range(N)]).reshape(B, H, W, N * F)
+    out2 = _conv(la, model.last_conv)
+    # CSAM (han.py:44-53): x * (gamma * sigmoid(conv3d(x))) + x
+    att = A.scale_param(A.sigmoid(A.conv3d_27(out1, model.csa.conv.weight, model.csa.conv.bias)), model.csa.gamma)
+    out1 = A.add(A.mul(out1, att), out1)
+    return A.add(_conv(A.concat(out1, out2), model.last), h)
+
+
 def han_forward(model, x: Tensor) -> Tensor:
     """HAN.forward (han.py:92-115)."""
     B, _, H, W = x.shape
@@ -232,17 +249,7 @@ def han_forward(model, x: Tensor) -> Tensor:
         feats.append(res)
     res = _conv(res, model.body[model.n_resgroups])
     feats.append(res)
-    out1 = res
-    # LAM over the N = n_resgroups + 1 features, newest first (han.py:96-103): each feature is one vector of H*W*C values
-    N = len(feats)
-    stack = A.concat(*[f.reshape(B, H * W * F) for f in reversed(feats)]).reshape(B, N, H * W * F)
-    la = A.add(A.scale_param(A.layer_attention(stack), model.la.gamma), stack)                      # gamma * out + x  (han.py:31)
-    la = A.concat(*[A.slice_channels(la.reshape(B, N * H * W * F), n * H * W * F, H * W * F).reshape(B * H * W, F) for n in range(N)]).reshape(B, H, W, N * F)
-    out2 = _conv(la, model.last_conv)
-    # CSAM (han.py:44-53): x * (gamma * sigmoid(conv3d(x))) + x
-    att = A.scale_param(A.sigmoid(A.conv3d_27(out1, model.csa.conv.weight, model.csa.conv.bias)), model.csa.gamma)
-    out1 = A.add(A.mul(out1, att), out1)
-    res = A.add(_conv(A.concat(out1, out2), model.last), h)
+    res = han_attention(model, feats, h)
     y = _conv(_upsampler(model.tail[0], res), model.tail[1])
     return A.nhwc_out(y, *_mean_shift(model.add_mean), H * s, W * s)
 

@@ -68,6 +68,13 @@ def test_gradients_against_the_reference(tag, kind):
         assert float((ye - ref_e).abs().max()) <= 2e-5 * max(1.0, float(ref_e.abs().max()))
         img = (np.random.default_rng(0).integers(0, 256, size=(9, 11, 3))).astype(np.uint8)
         assert m.inference(img).shape == (9 * cfg["scale"], 11 * cfg["scale"], 3)
+        # the bf16 inference path of these two (fused Swin-block / RCAB kernels + the generic engine for SFB / LAM / CSAM): >= 45 dB
+        m.set_precision("bf16")
+        with torch.no_grad():
+            yb = m(x).cpu()
+        m.set_precision("auto")
+        rng_ = max(1.0, float(ref_e.abs().max()))
+        assert 10 * np.log10(rng_ * rng_ / max(float(((yb - ref_e) ** 2).mean()), 1e-30)) >= 45.0
 
 
 @pytest.mark.parametrize("tag,kind", [("hat", "HAT"), ("edsr", "EDSR"), ("swinir", "SwinIR"), ("rcan", "RCAN")])
