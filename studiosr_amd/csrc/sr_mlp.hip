@@ -16,6 +16,8 @@
 #include "sr_common.h"
 #include "sr_host.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ unsigned long long sr_dbg_mlp[16];
@@ -32,9 +34,9 @@ __device__ unsigned long long sr_dbg_mlp[16];
 //   * one sched_barrier per K-chunk keeps hipcc from sinking the ring loads or hoisting 50 of them at once;
 //   * GELU is the sigmoid form (sr_common.h gelu_bf16): with the erf polynomial the VALU time of this kernel
 //     exceeded its MFMA time.
-template <int KC1, int KC2>
-__global__ __launch_bounds__(256, 2) void sr_mlp_kernel(SrMlp a) {
-    constexpr int M_T = 64, MT = 4;
+template <int KC1, int KC2, int M_T>
+__global__ __launch_bounds__(256, M_T == 64 ? 2 : 1) void sr_mlp_kernel(SrMlp a) {
+    constexpr int MT = M_T / 16;
     constexpr int NT1 = KC2 * 2 / 4;  // fc1 n-tiles per wave (hidden/16/4) = 6
     constexpr int NH = NT1 / 2;       // per half = 3
     constexpr int NT2 = KC1 * 2 / 4;  // fc2 n-tiles per wave (Cp/16/4) = 3
@@ -233,13 +235,23 @@ extern "C" int sr_mlp_fused(const SrMlp* p, void* stream) {
     const SrMlp& a = *p;
     SR_REQUIRE(a.M > 0 && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp, "sr_mlp_fused: bad geometry");
     SR_REQUIRE(sr_mlp_fused_supported(a.Cp, a.Hp, SR_BF16), "sr_mlp_fused: unsupported Cp=%d Hp=%d (use two sr_gemm calls)", a.Cp, a.Hp);
+    static const bool rows128 = getenv("SR_MLP_ROWS") && atoi(getenv("SR_MLP_ROWS")) == 128;  // experiment: 128 rows per workgroup (8 MFMAs per weight fragment)
+    if (rows128) {
+        constexpr int lds = (6 + 12) * 4 * 128 * 16;  // 144 KiB
+        static SrDeviceOnce attr_once128;
+        const hipError_t e = sr_once_per_device(attr_once128, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12, 128>, lds); });
+        SR_REQUIRE(e == hipSuccess, "sr_mlp_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_mlp_kernel<6, 12, 128>), dim3((a.M + 127) / 128), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+        SR_CHECK_LAUNCH("sr_mlp_fused");
+        return SR_OK;
+    }
     constexpr int lds = (6 + 12) * 4 * 64 * 16;  // 72 KiB
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12, 64>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_mlp_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((sr_mlp_kernel<6, 12>), dim3((a.M + 63) / 64), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((sr_mlp_kernel<6, 12, 64>), dim3((a.M + 63) / 64), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_mlp_fused");
     return SR_OK;
 }
