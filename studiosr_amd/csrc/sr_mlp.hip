@@ -35,7 +35,7 @@ __device__ unsigned long long sr_dbg_mlp[16];
 //   * GELU is the sigmoid form (sr_common.h gelu_bf16): with the erf polynomial the VALU time of this kernel
 //     exceeded its MFMA time.
 template <int KC1, int KC2, int M_T>
-__global__ __launch_bounds__(256, M_T == 64 ? 2 : 1) void sr_mlp_kernel(SrMlp a) {
+__global__ __launch_bounds__(256, M_T == 128 ? 1 : (M_T == 64 ? 2 : 4)) void sr_mlp_kernel(SrMlp a) {
     constexpr int MT = M_T / 16;
     constexpr int NT1 = KC2 * 2 / 4;  // fc1 n-tiles per wave (hidden/16/4) = 6
     constexpr int NH = NT1 / 2;       // per half = 3
@@ -235,8 +235,17 @@ extern "C" int sr_mlp_fused(const SrMlp* p, void* stream) {
     const SrMlp& a = *p;
     SR_REQUIRE(a.M > 0 && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp, "sr_mlp_fused: bad geometry");
     SR_REQUIRE(sr_mlp_fused_supported(a.Cp, a.Hp, SR_BF16), "sr_mlp_fused: unsupported Cp=%d Hp=%d (use two sr_gemm calls)", a.Cp, a.Hp);
-    static const bool rows128 = getenv("SR_MLP_ROWS") && atoi(getenv("SR_MLP_ROWS")) == 128;  // experiment: 128 rows per workgroup (8 MFMAs per weight fragment)
-    if (rows128) {
+    static const int rows = getenv("SR_MLP_ROWS") ? atoi(getenv("SR_MLP_ROWS")) : 64;  // experiments: 128 rows per workgroup (8 MFMAs per weight fragment), 32 rows (2)
+    if (rows == 32) {
+        constexpr int lds = (6 + 12) * 4 * 32 * 16;  // 36 KiB
+        static SrDeviceOnce attr_once32;
+        const hipError_t e = sr_once_per_device(attr_once32, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12, 32>, lds); });
+        SR_REQUIRE(e == hipSuccess, "sr_mlp_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_mlp_kernel<6, 12, 32>), dim3((a.M + 31) / 32), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+        SR_CHECK_LAUNCH("sr_mlp_fused");
+        return SR_OK;
+    }
+    if (rows == 128) {
         constexpr int lds = (6 + 12) * 4 * 128 * 16;  // 144 KiB
         static SrDeviceOnce attr_once128;
         const hipError_t e = sr_once_per_device(attr_once128, [&] { return sr_allow_lds(sr_mlp_kernel<6, 12, 128>, lds); });
