@@ -11,6 +11,7 @@ reference's state_dict layouts, so torch.optim and DistributedDataParallel see o
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -57,13 +58,13 @@ def bgemm(A: Tensor, B: Tensor, Cc: Tensor, M: int, N: int, K: int, sa: Tuple[in
     L.check(L.lib().sr_bgemm(C.byref(g), _st()), "sr_bgemm")
 
 
-_AUTOCAST_STATE = {"fwd": False}
+_AUTOCAST_STATE = threading.local()  # per thread: autograd runs backward nodes on its own worker threads
 
 
 def _autocast_bf16() -> bool:
     """bf16 autocast active for THIS launch: read live in forward; backward runs outside the context manager, so every Function records
     the state it was built under (torch does the same: autocast backward ops run in the dtype their forward ran in)."""
-    return _AUTOCAST_STATE["fwd"]
+    return getattr(_AUTOCAST_STATE, "on", False)
 
 
 class autocast_state:
@@ -73,11 +74,11 @@ class autocast_state:
         self.flag = flag
 
     def __enter__(self):
-        self.prev = _AUTOCAST_STATE["fwd"]
-        _AUTOCAST_STATE["fwd"] = self.flag
+        self.prev = getattr(_AUTOCAST_STATE, "on", False)
+        _AUTOCAST_STATE.on = bool(self.flag)
 
     def __exit__(self, *exc):
-        _AUTOCAST_STATE["fwd"] = self.prev
+        _AUTOCAST_STATE.on = self.prev
 
 
 def torch_autocast_bf16() -> bool:
@@ -127,15 +128,22 @@ class _ZeroArena:
         return v
 
 
-_ARENA = _ZeroArena()
+_ARENA_TLS = threading.local()  # one arena per thread (autograd's backward worker of a device)
+
+
+def _arena() -> _ZeroArena:
+    a = getattr(_ARENA_TLS, "arena", None)
+    if a is None:
+        a = _ARENA_TLS.arena = _ZeroArena()
+    return a
 
 
 def _zeros(shape, device) -> Tensor:
-    return _ARENA.take(shape, device)
+    return _arena().take(shape, device)
 
 
 def _zeros_like(t: Tensor) -> Tensor:
-    return _ARENA.take(t.shape, t.device)
+    return _arena().take(t.shape, t.device)
 
 
 # --------------------------------------------------------------------------- nn.Linear / conv

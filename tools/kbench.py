@@ -83,7 +83,7 @@ def conv_bench():
             out = torch.empty(B, 2 * H, 2 * W, cout // 4, device=dev, dtype=cdt)
             fn = lambda: conv_call(x, wp, bp, out, cdt, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=2, cps_p=cout // 4)
         else:
-            out = torch.empty(B, H, W, cout, device=dev, dtype=torch.float32 if mode == "nhwc_f32" else cdt)
+            out = torch.empty(B, H, W, cout, device=dev, dtype=torch.float32 if (mode == "nhwc_f32" or os.environ.get("KB_F32OUT")) else cdt)
             pool = None
             if os.environ.get("KB_POOL"):
                 pool = torch.zeros(B, ops.conv_pool_tiles(H, W, out.shape[-1], L.SR_BF16), out.shape[-1], device=dev)
