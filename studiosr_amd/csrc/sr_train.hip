@@ -825,30 +825,37 @@ __global__ __launch_bounds__(256) void sr_colsum_kernel(const float* __restrict_
     __syncthreads();
     if (rg == 0 && c < C) atomicAdd(out + b * C + c, alpha * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]));
 }
-// C % 4 == 0, 16-byte aligned rows: a lane owns 4 consecutive columns (one 16-byte load per row), 4 row groups x 2 rows in flight,
-// 128 rows per workgroup -- 3-4x the workgroups and a quarter of the load instructions of the scalar kernel above
-constexpr int COLSUM4_ROWS = 64;
-__global__ __launch_bounds__(256) void sr_colsum4_kernel(const float* __restrict__ x, float* __restrict__ out, long long P, int C, float alpha) {
-    __shared__ f32x4 red[4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = (blockIdx.y * 64 + cl) * 4;
+// C % 4 == 0, 16-byte aligned rows: a thread owns 4 consecutive columns (one 16-byte load per row) of every R-th row of its workgroup's
+// row block; the 256 threads are laid out as R rows x QB column quads (QB <= 64: all lanes busy also for C = 60 or 180), 16 independent loads
+// in flight per thread.  rows_wg is chosen by the launcher: every workgroup of a column block ends in atomicAdds on the SAME addresses, which
+// serialise in L2, so the row blocks are few and long.
+__global__ __launch_bounds__(256) void sr_colsum4_kernel(const float* __restrict__ x, float* __restrict__ out, long long P, int C, float alpha, int QB, int rows_wg) {
+    __shared__ f32x4 red[256];
+    const int q = C >> 2;
+    const int R = 256 / QB;
+    const int cq = threadIdx.x % QB, r = threadIdx.x / QB;
+    const int quad = blockIdx.y * QB + cq;
     const long long b = blockIdx.z;
-    const long long p0 = (long long)blockIdx.x * COLSUM4_ROWS, p1 = min(P, p0 + COLSUM4_ROWS);
-    const float* xb = x + b * P * C;
+    const long long p0 = (long long)blockIdx.x * rows_wg, p1 = min(P, p0 + rows_wg);
+    const float* xb = x + b * P * C + 4 * quad;
     f32x4 acc[4] = {(f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f)};
-    if (c < C) {  // this thread's 16 rows: every load is independent, all of them can be in flight together
+    const bool live = r < R && quad < q;
+    if (live) {
+        for (long long pc = p0 + r; pc < p1; pc += 16LL * R) {
+            f32x4 v[16];  // unconditional loads from clamped addresses: a branch per load would serialise them (load, wait, add, next)
 #pragma unroll
-        for (int k = 0; k < COLSUM4_ROWS / 4; ++k) {
-            const long long p = p0 + rg + 4 * k;
-            if (p < p1) acc[k & 3] += *reinterpret_cast<const f32x4*>(xb + p * C + c);
+            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + min(pc + (long long)k * R, p1 - 1) * C);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k & 3] += (pc + (long long)k * R < p1) ? v[k] : (f32x4)(0.0f);
         }
     }
-    red[rg][cl] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    red[threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
-    if (rg == 0 && c < C) {
-        const f32x4 t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    if (r == 0 && quad < q) {
+        f32x4 t = red[cq];
+        for (int i = 1; i < R; ++i) t += red[i * QB + cq];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(out + b * C + c + r, alpha * t[r]);
+        for (int j = 0; j < 4; ++j) atomicAdd(out + b * C + 4 * quad + j, alpha * t[j]);
     }
 }
 // out[i] = sum_b x[b][i]  (relative-position-bias gradient: sum of dS over windows; deterministic, no atomics)
@@ -1187,9 +1194,16 @@ extern "C" int sr_layernorm_bwd(const float* x, const float* stats, const float*
 }
 extern "C" int sr_colsum(const float* x, float* out, int nb, long long P, int C, float alpha, void* stream) {
     SR_REQUIRE(x && out && nb > 0 && nb <= 65535 && P > 0 && C > 0, "sr_colsum: bad arguments");
-    if ((C & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && P >= 64)
-        hipLaunchKernelGGL(sr_colsum4_kernel, dim3((unsigned)((P + COLSUM4_ROWS - 1) / COLSUM4_ROWS), (C / 4 + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
-    else
+    if ((C & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && P >= 64) {
+        const int q = C / 4, ny = (q + 63) / 64, QB = (q + ny - 1) / ny, R = 256 / QB;
+        static const int env_blocks = getenv("SR_COLSUM_BLOCKS") ? atoi(getenv("SR_COLSUM_BLOCKS")) : 0;  // tools/colsum_bench.py sweep
+        // row blocks per column block: enough workgroups to stream (a workgroup moves ~30-60 GB/s), few enough that the same-address
+        // atomics at the end do not dominate (tools/colsum_bench.py: 16,384 rows 64 blocks, 262,144 rows 128; 256 blocks lose 2x)
+        const long long target = env_blocks > 0 ? env_blocks : std::min<long long>(128, std::max<long long>(32, P / 256));
+        long long rows_wg = (P + target - 1) / target;
+        rows_wg = (rows_wg + 16LL * R - 1) / (16LL * R) * (16LL * R);  // whole 16-load rounds
+        hipLaunchKernelGGL(sr_colsum4_kernel, dim3((unsigned)((P + rows_wg - 1) / rows_wg), ny, nb), dim3(256), 0, ST, x, out, P, C, alpha, QB, (int)rows_wg);
+    } else
         hipLaunchKernelGGL(sr_colsum_kernel, dim3((unsigned)((P + COLSUM_ROWS - 1) / COLSUM_ROWS), (C + 63) / 64, nb), dim3(256), 0, ST, x, out, P, C, alpha);
     SR_CHECK_LAUNCH("sr_colsum");
     return SR_OK;
