@@ -88,7 +88,27 @@ def torch_autocast_bf16() -> bool:
 def _ksplit(rows: int, cols: int, K: int) -> int:
     """Workgroups for a weight-gradient GEMM whose contraction runs over K tokens: enough slices to fill 256 CUs, each >= 256 long."""
     tiles = ((rows + 63) // 64) * ((cols + 63) // 64)
-    return max(1, min(1024 // max(tiles, 1), (K + 255) // 256, 512))
+    ks = max(1, min(1024 // max(tiles, 1), (K + 255) // 256, 512))
+    p2 = 1 << (ks.bit_length() - 1)  # token counts are B * H * W: a power-of-two slice count usually divides them (wgrad's atomic-free path)
+    return p2 if (ks >= 2 and K % p2 == 0 and 4 * p2 >= 3 * ks) else ks
+
+
+def wgrad(dy: Tensor, x: Tensor, rows: int, cols: int, T: int) -> Tensor:
+    """dW[rows, cols] = dy[T, rows]^T x[T, cols]: the contraction runs over the T tokens.  Split over token slices so that the launch fills
+    the chip; when T divides into equal slices each slice is one batch entry of a plain GEMM into a scratch stack that sr_batch_sum adds
+    up -- no atomics (each workgroup's result tile goes out in 16-byte stores; same-address fp32 atomics cost ~14 us of a 55-us launch) and
+    a deterministic gradient; otherwise split-K with atomics into a zeroed accumulator."""
+    ks = _ksplit(rows, cols, T)
+    chunk = T // ks if ks > 1 and T % ks == 0 else 0
+    if chunk and chunk % 32 == 0:
+        stack = torch.empty(ks, rows, cols, device=dy.device, dtype=torch.float32)
+        bgemm(dy, x, stack, rows, cols, chunk, (1, rows), (cols, 1), (cols, 1), nb=(ks, 1), sab=(chunk * rows, 0), sbb=(chunk * cols, 0), scb=(rows * cols, 0))
+        dw = torch.empty(rows, cols, device=dy.device, dtype=torch.float32)
+        L.check(L.lib().sr_batch_sum(stack.data_ptr(), dw.data_ptr(), ks, rows * cols, rows * cols, _st()), "sr_batch_sum")
+        return dw
+    dw = _zeros((rows, cols), dy.device)
+    bgemm(dy, x, dw, rows, cols, T, (1, rows), (cols, 1), (cols, 1), ksplit=ks)
+    return dw
 
 
 def eltwise(op: int, x: Optional[Tensor], out: Tensor, *, y: Optional[Tensor] = None, s: Optional[Tensor] = None, inner: int = 1, Cn: int = 1, a: float = 0.0, b: float = 0.0) -> Tensor:
@@ -177,8 +197,7 @@ class _Linear(Fn):
                 dx = torch.empty_like(x)
                 bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
             if ctx.needs_input_grad[1]:
-                dw = _zeros_like(w)
-                bgemm(dy, x, dw, N, K, M, (1, N), (K, 1), (K, 1), ksplit=_ksplit(N, K, M))
+                dw = wgrad(dy, x, N, K, M).view_as(w)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy, _zeros((N,), dy.device), 1, M, N)
             return dx, dw, db
@@ -235,8 +254,7 @@ class _Conv3x3(Fn):
                 L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
             if ctx.needs_input_grad[1]:
                 col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-                dw2 = _zeros((Cout, K), dy.device)
-                bgemm(dy, col, dw2, Cout, K, M, (1, Cout), (K, 1), (K, 1), ksplit=_ksplit(Cout, K, M))
+                dw2 = wgrad(dy, col, Cout, K, M)
                 dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy, _zeros((Cout,), dy.device), 1, M, Cout)
