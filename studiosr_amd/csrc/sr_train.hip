@@ -866,6 +866,23 @@ __global__ void sr_batch_sum_kernel(const float* __restrict__ x, float* __restri
     for (long long b = 0; b < nb; ++b) s += x[b * stride_b + i];
     out[i] = s;
 }
+// n, stride_b multiples of 4 and 16-byte aligned pointers: 4 elements per thread, 8 batch entries in flight; same summation order (b ascending)
+__global__ void sr_batch_sum4_kernel(const float* __restrict__ x, float* __restrict__ out, long long nb, long long n4, long long stride_b) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float* p = x + 4 * i;
+    f32x4 s = (f32x4)(0.0f);
+    long long b = 0;
+    for (; b + 8 <= nb; b += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(p + (b + k) * stride_b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; b < nb; ++b) s += *reinterpret_cast<const f32x4*>(p + b * stride_b);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = s;
+}
 
 // ----------------------------------------------------------------------------- flat elementwise ops
 enum {
@@ -1210,7 +1227,10 @@ extern "C" int sr_colsum(const float* x, float* out, int nb, long long P, int C,
 }
 extern "C" int sr_batch_sum(const float* x, float* out, long long nb, long long n, long long stride_b, void* stream) {
     SR_REQUIRE(x && out && nb > 0 && n > 0, "sr_batch_sum: bad arguments");
-    hipLaunchKernelGGL(sr_batch_sum_kernel, flat_grid(n), dim3(256), 0, ST, x, out, nb, n, stride_b);
+    if ((n & 3) == 0 && (stride_b & 3) == 0 && ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(sr_batch_sum4_kernel, flat_grid(n / 4), dim3(256), 0, ST, x, out, nb, n / 4, stride_b);
+    else
+        hipLaunchKernelGGL(sr_batch_sum_kernel, flat_grid(n), dim3(256), 0, ST, x, out, nb, n, stride_b);
     SR_CHECK_LAUNCH("sr_batch_sum");
     return SR_OK;
 }
