@@ -263,6 +263,27 @@ def test_graphed_forward_keeps_its_buffers_alive():
     del junk
 
 
+@pytest.mark.parametrize("kind,cfg", [
+    ("HAT", dict(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=16)),            # side stream for the conv branch of a HAB
+    ("SwinFIR", dict(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=8)),         # torch glue + generic-engine SFB between fused blocks
+    ("HAN", dict(scale=2, n_feats=64, n_resblocks=3, n_resgroups=2, reduction=16)),             # chained RCABs + LAM / CSAM on the generic engine
+    ("RCAN", dict(scale=2, n_feats=64, n_resblocks=3, n_resgroups=2, reduction=16)),
+])
+def test_forwards_with_side_streams_or_torch_glue_replay_from_a_hip_graph(kind, cfg):
+    """Every model's inference forward must be capturable: the second stream of HAT joins the capture, SwinFIR's / HAN's torch ops and
+    generic-engine launches allocate from the graph's pool; three replays on fresh inputs equal the eager forward bit for bit."""
+    from studiosr_amd.runtime import GraphedForward
+
+    torch.manual_seed(5)
+    m = _randomised(getattr(S, kind)(**cfg), seed=5).to(DEV).eval().set_precision("bf16")
+    xs = [torch.rand(2, 3, 32, 32, device=DEV) for _ in range(3)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+        gf = GraphedForward(lambda t: m(t), xs[0])
+        for x, w in zip(xs, want):
+            assert torch.equal(gf(x), w)
+
+
 def test_edsr_x4_batch16_invariants():
     """BASELINE config 2 (EDSR x4, batch 16, 64x64): batch independence + eval-pad-free shape; fp32 vs bf16 PSNR."""
     torch.manual_seed(0)
