@@ -160,6 +160,7 @@ typedef struct SrConv3x3 {
     int ps_r;             /* PIXEL_SHUFFLE factor r: packed channel n = (i*r + j)*Cps_p + c */
     int cps_p;            /* PIXEL_SHUFFLE: padded channel count of the shuffled output */
     int fin_c, fin_h, fin_w; /* FINAL_NCHW: real channels and cropped size */
+    float act_slope;      /* SR_ACT_LRELU: negative slope; 0 = nn.LeakyReLU's default 0.01 (ABI v4; SwinFIR's SFB uses 0.2, swinfir.py:59) */
 } SrConv3x3;
 int sr_conv3x3(const SrConv3x3* a, void* stream);
 int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype); /* n_tiles of pool_partial for this geometry */

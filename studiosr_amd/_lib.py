@@ -66,7 +66,7 @@ class SrConv3x3(C.Structure):
         ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cout_p", _i),
         ("x_dtype", _i), ("out_dtype", _i), ("skip_dtype", _i), ("compute_dtype", _i),
         ("act", _i), ("out_scale", _f), ("out_mode", _i), ("ps_r", _i), ("cps_p", _i),
-        ("fin_c", _i), ("fin_h", _i), ("fin_w", _i),
+        ("fin_c", _i), ("fin_h", _i), ("fin_w", _i), ("act_slope", _f),
     ]
 
 

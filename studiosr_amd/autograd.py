@@ -82,7 +82,9 @@ class autocast_state:
 
 
 def torch_autocast_bf16() -> bool:
-    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    """What a Function records at forward time: torch's bf16 autocast context, or an enclosing autocast_state(True) (the bf16 inference
+    paths of SwinFIR / HAN run their generic-engine modules under it without touching torch's autocast)."""
+    return _autocast_bf16() or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
 def _ksplit(rows: int, cols: int, K: int) -> int:

@@ -217,9 +217,9 @@ SR_DEV float apply_act(float x, int act) {
 // Compile-time activation (the run-time switch above gets if-converted by hipcc: every element then
 // pays for erff even when act == NONE).  Kernels dispatch ONCE per wave with act_dispatch().
 template <int ACT>
-SR_DEV float act_ct(float x) {
+SR_DEV float act_ct(float x, float slope = 0.01f) {
     if constexpr (ACT == SR_ACT_RELU) return x > 0.f ? x : 0.f;
-    if constexpr (ACT == SR_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
+    if constexpr (ACT == SR_ACT_LRELU) return x > 0.f ? x : slope * x;
     if constexpr (ACT == SR_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     return x;
 }

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         }
     }
     const bool scaled = c.out_scale != 1.0f;
+    const float lrelu_slope = c.act_slope != 0.0f ? c.act_slope : 0.01f;
     act_dispatch(c.act, [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             for (int n = 0; n < NW; ++n) {
                 f32x4 v = acc[m][n] + bias_r[n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r], lrelu_slope);
                 if (scaled) v *= c.out_scale;
                 const size_t off = c.out_mode == SR_OUT_PIXEL_SHUFFLE ? ((ps_row + ps_i[n]) * ((size_t)c.W * c.ps_r) + ps_col + ps_j[n]) * c.cps_p + nch[n]
                                                                      : pix_nhwc + nch[n];

@@ -13,6 +13,9 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
+from .. import packing
+from .common import conv_call
 from .swinir import SwinIR
 
 
@@ -57,17 +60,28 @@ class SwinFIR(SwinIR):
         self.conv_after_body = SFB(embed_dim)  # swinfir.py:114
 
     def _pack_resi(self, m, C, Cp, dt):
-        return m  # the SFB's own parameters are read in place by the generic engine
+        """The spatial branch's two 3x3 convs run on the fused conv kernels (packed here); the spectral branch and the fusing 1x1 conv read
+        the SFB's own parameters in place on the generic engine."""
+        ident = packing.identity_idx(C, Cp)
+        body = m.S.body
+        return dict(m=m, c1=packing.pack_conv3x3(body[0].weight, body[0].bias, Cp, ident, dt), c2=packing.pack_conv3x3(body[2].weight, body[2].bias, Cp, ident, dt))
 
-    def _run_resi(self, m, src, dst, skip, cdt) -> None:
+    def _run_resi(self, pk, src, dst, skip, cdt) -> None:
         """dst = SFB(src) + skip on the padded NHWC buffers of SwinIR.forward (swinfir.py:68-81, swinir.py:245-246,362)."""
         from .. import autograd as A
         from . import train
 
-        C = self.embed_dim
+        m, C = pk["m"], self.embed_dim
+        ws_ = self._ws
+        # S(x) = conv(LeakyReLU_0.2(conv(x))) + x  (swinfir.py:55-65) on the fused kernels, padded layout
+        mid = ws_.get("sfb.mid", tuple(src.shape), cdt)
+        sp = ws_.get("sfb.s", tuple(src.shape), torch.float32)
+        conv_call(src, *pk["c1"], mid, cdt, act=L.ACT_LRELU, act_slope=0.2)
+        conv_call(mid, *pk["c2"], sp, cdt, skip=src)
         x = src[..., :C].float().contiguous()
+        s_ = sp[..., :C].contiguous()
         with torch.no_grad(), A.autocast_state(cdt == torch.bfloat16):  # bf16 precision: bf16-operand contractions, as the Swin blocks
-            y = train._sfb(m, x)
+            y = train._sfb_tail(m, x, s_)
         if dst is skip:
             dst[..., :C] += y
         else:

@@ -72,6 +72,11 @@ def _sfb(m, x: Tensor) -> Tensor:
     """SwinFIR's SFB (swinfir.py:38-81): spatial branch conv-LeakyReLU(0.2)-conv + x; spectral branch 1x1 conv + LeakyReLU ->
     FourierUnit (rfftn -> 1x1 conv on (real | imag) + LeakyReLU -> irfftn) -> 1x1 conv(fu + y); 1x1 fusion conv of the concatenation."""
     s = A.add(_conv(A.leaky_relu(_conv(x, m.S.body[0]), 0.2), m.S.body[2]), x)
+    return _sfb_tail(m, x, s)
+
+
+def _sfb_tail(m, x: Tensor, s: Tensor) -> Tensor:
+    """The SFB after its spatial branch s = S(x): spectral branch on x, 1x1 fusion of (s | f)."""
     y = A.leaky_relu(_conv1x1(x, m.F.conv_before_fft[0]), 0.2)
     z = A.leaky_relu(_conv1x1(A.rfft2(y), m.F.fu.conv_layer), 0.2)
     f = _conv1x1(A.add(A.irfft2(z, y.shape[2]), y), m.F.conv_after_fft)
