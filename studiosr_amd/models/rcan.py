@@ -161,6 +161,37 @@ class RCAN(Model):
         P = self._get_packed(cdt)
         ws_ = self._workspace(x.device)
         B, _, H, W = x.shape
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
+        if self.pipeline_halves and B >= 16 and B % 2 == 0:
+            # Every RCAB launch is whole residency rounds whose load, MFMA and store phases run one after the other chip-wide; two half
+            # batches on two streams are out of phase, so one's HBM phases run under the other's MFMAs.  Measured (tools/rcan_ab.py,
+            # same box): b8 4.81 -> 5.58 ms (worse: off below 16), b16 6.43 -> 6.04 ms, b32 12.08 -> 9.13 ms.
+            from ..runtime import WorkspaceView
+
+            main = torch.cuda.current_stream(x.device)
+            side = self._side_stream(x.device)
+            h = B // 2
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._forward_into(P, x[h:], out[h:], WorkspaceView(ws_, "h1."), cdt)
+            self._forward_into(P, x[:h], out[:h], WorkspaceView(ws_, "h0."), cdt)
+            main.wait_stream(side)
+        else:
+            self._forward_into(P, x, out, ws_, cdt)
+        return out
+
+    pipeline_halves = True
+
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        st = getattr(self, "_side", None)
+        if st is None or st.device != torch.device(device):
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
+
+    def _forward_into(self, P: Dict, x: Tensor, out: Tensor, ws_, cdt) -> None:
+        B, _, H, W = x.shape
         Fp = P["Fp"]
         f32 = torch.float32
         xin = ws_.get("xin", (B, H, W, 32), cdt)
@@ -172,9 +203,7 @@ class RCAN(Model):
         conv_call(g, *P["body_last"], res, cdt, skip=h)
         up = run_upsampler(P["up"], res, ws_, cdt, "rcan")
         s = self.scale
-        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=f32, device=x.device)
         conv_call(up, *P["tail"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(*P["fin"], self.n_colors, H * s, W * s), cout_p=16)
-        return out
 
     def get_model_config(self) -> Dict:
         config = super().get_model_config()

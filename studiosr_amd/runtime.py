@@ -154,6 +154,17 @@ class Workspace:
         return bad
 
 
+class WorkspaceView:
+    """A Workspace seen through a name prefix: two concurrent sub-forwards (the two half batches of RCAN.forward) get disjoint buffers of
+    the same names and shapes from one bounded workspace."""
+
+    def __init__(self, ws: Workspace, prefix: str) -> None:
+        self.ws, self.prefix, self.device = ws, prefix, ws.device
+
+    def get(self, name: str, shape, dtype: torch.dtype) -> Tensor:
+        return self.ws.get(self.prefix + name, shape, dtype)
+
+
 class GraphedForward:
     """Capture `fn(static_input) -> static_output` once into a HIP graph and replay it.
 
