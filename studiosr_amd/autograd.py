@@ -345,8 +345,10 @@ class _Axpby(Fn):
     @staticmethod
     def backward(ctx, d):
         d = _chk(d)
-        dx = eltwise(L.EW_AXPBY, d, torch.empty_like(d), a=ctx.a) if ctx.needs_input_grad[0] else None
-        dy = eltwise(L.EW_AXPBY, d, torch.empty_like(d), a=ctx.b) if ctx.needs_input_grad[1] else None
+        # a coefficient of 1 (every plain residual add) passes the incoming gradient through: no launch, no copy (as torch's own add)
+        scaled = lambda c: d if c == 1.0 else eltwise(L.EW_AXPBY, d, torch.empty_like(d), a=c)  # noqa: E731
+        dx = scaled(ctx.a) if ctx.needs_input_grad[0] else None
+        dy = scaled(ctx.b) if ctx.needs_input_grad[1] else None
         return dx, dy, None, None
 
 
