@@ -10,7 +10,12 @@ torch.manual_seed(0)
 dev = "cuda"
 cases = [("SwinIR", S.SwinIR(scale=4), (8, 3, 64, 64)), ("SwinIR-small", S.SwinIR(scale=4), (1, 3, 13, 17)), ("EDSR", S.EDSR(scale=4, n_feats=64, n_resblocks=2), (2, 3, 20, 36)),
          ("EDSR-wide", S.EDSR(scale=4, n_resblocks=2), (6, 3, 50, 70)), ("HAT-w16", S.HAT(scale=4, depths=[2], num_heads=[6]), (3, 3, 64, 48)),
-         ("HAT", S.HAT(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=8), (1, 3, 24, 16)), ("RCAN", S.RCAN(scale=3, n_feats=32, n_resblocks=2, n_resgroups=2, reduction=8), (2, 3, 12, 12))]
+         ("HAT", S.HAT(scale=2, embed_dim=60, depths=[2], num_heads=[6], window_size=8), (1, 3, 24, 16)), ("RCAN", S.RCAN(scale=3, n_feats=32, n_resblocks=2, n_resgroups=2, reduction=8), (2, 3, 12, 12)),
+         ("RCAN-64 (chained RCABs)", S.RCAN(scale=2, n_feats=64, n_resblocks=3, n_resgroups=2), (3, 3, 33, 45)),
+         ("RCAN-64 b16 (two half batches)", S.RCAN(scale=2, n_feats=64, n_resblocks=3, n_resgroups=1), (16, 3, 20, 24)),
+         ("EDSR-256 tail (narrow conv, K split)", S.EDSR(scale=2, n_resblocks=1), (2, 3, 19, 50)),
+         ("HAN", S.HAN(scale=2, n_feats=64, n_resblocks=2, n_resgroups=2), (2, 3, 24, 20)),
+         ("SwinFIR", S.SwinFIR(scale=2, embed_dim=60, depths=[2], num_heads=[6]), (2, 3, 20, 28))]
 for name, m, shp in cases:
     m = m.to(dev).eval()
     for prec in ("bf16", "fp32"):
