@@ -161,9 +161,12 @@ typedef struct SrConv3x3 {
     int cps_p;            /* PIXEL_SHUFFLE: padded channel count of the shuffled output */
     int fin_c, fin_h, fin_w; /* FINAL_NCHW: real channels and cropped size */
     float act_slope;      /* SR_ACT_LRELU: negative slope; 0 = nn.LeakyReLU's default 0.01 (ABI v4; SwinFIR's SFB uses 0.2, swinfir.py:59) */
+    int tile_rows;        /* bf16 tile height: 0 = chosen by the library (8, or 4 when the launch would leave the chip under-filled; always 8
+                           * with pool_partial), 4 / 8 = as given -- with pool_partial the caller sizes it with sr_conv3x3_pool_tiles_rows */
 } SrConv3x3;
 int sr_conv3x3(const SrConv3x3* a, void* stream);
-int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype); /* n_tiles of pool_partial for this geometry */
+int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype); /* n_tiles of pool_partial for this geometry (tile_rows = 0) */
+int sr_conv3x3_pool_tiles_rows(int H, int W, int Cout_p, int tile_rows); /* the same for an explicit bf16 tile height (4 or 8) */
 
 typedef struct SrRcab {
     /* y = conv2(ReLU(conv1(x))): the conv-ReLU-conv body of an RCAB (rcan.py:11-24, common.py:140-153 without the residual) for 64

@@ -66,7 +66,7 @@ class SrConv3x3(C.Structure):
         ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cout_p", _i),
         ("x_dtype", _i), ("out_dtype", _i), ("skip_dtype", _i), ("compute_dtype", _i),
         ("act", _i), ("out_scale", _f), ("out_mode", _i), ("ps_r", _i), ("cps_p", _i),
-        ("fin_c", _i), ("fin_h", _i), ("fin_w", _i), ("act_slope", _f),
+        ("fin_c", _i), ("fin_h", _i), ("fin_w", _i), ("act_slope", _f), ("tile_rows", _i),
     ]
 
 
@@ -134,6 +134,7 @@ SYMBOLS = {
     "sr_mlp_fused": (_i, [C.POINTER(SrMlp), _vp]),
     "sr_conv3x3": (_i, [C.POINTER(SrConv3x3), _vp]),
     "sr_conv3x3_pool_tiles": (_i, [_i, _i, _i, _i]),
+    "sr_conv3x3_pool_tiles_rows": (_i, [_i, _i, _i, _i]),
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
     "sr_oca_attention": (_i, [C.POINTER(SrOcaAttn), _vp]),
     "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

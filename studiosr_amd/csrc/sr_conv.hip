@@ -24,16 +24,17 @@ constexpr int HALO_W = 18;
 __device__ unsigned long long sr_dbg_conv[16];
 #define STAMP(i) SR_STAMP(sr_dbg_conv, i)
 
-template <int TH>
+// halo rows of the LDS image: bf16 stages 64 rows per step (two passes of 32), so its images are whole steps
+template <int TH, int ESZ = 4>
 struct ConvGeo {
     static constexpr int HH = TH + 2;
-    static constexpr int ROWS = ((HH * HALO_W + 15) / 16) * 16;
+    static constexpr int ROWS = ESZ == 2 ? ((HH * HALO_W + 63) / 64) * 64 : ((HH * HALO_W + 15) / 16) * 16;
 };
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
-    constexpr int ROWS = ConvGeo<TH>::ROWS;
+    constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
     constexpr int HH = ConvGeo<TH>::HH;
     constexpr int MTW = TH / WM;  // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
-    constexpr int ROWS = ConvGeo<TH>::ROWS;
+    constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
     const int lds = c.Cin_p * ROWS * (int)sizeof(TC);
     SR_REQUIRE(lds <= 160 * 1024, "sr_conv3x3: Cin_p=%d needs %d B of LDS", c.Cin_p, lds);
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
@@ -356,6 +357,18 @@ int dispatch_conv(const SrConv3x3& c, hipStream_t st) {
     return launch_conv<TC, TIn, TH, 4, 1, 1>(c, st);
 }
 
+// bf16 tile height: 8 rows; 4 rows when 8-row tiles leave the chip under-filled (small batches / single images: every launch is one
+// latency chain per workgroup, so twice the workgroups of half the work each finish sooner).  Convs with a pool side output keep 8 unless
+// the caller asks for 4 (tile_rows) -- the number of pool slots follows the tile height (sr_conv3x3_pool_tiles_rows).
+int conv_tile_rows(const SrConv3x3& c) {
+    if (c.tile_rows == 4 || c.tile_rows == 8) return c.tile_rows;
+    if (c.pool_partial) return 8;
+    const int n = c.Cout_p;
+    const int ntile = (n % 256 == 0 && c.Cin_p >= 128) ? 256 : n % 192 == 0 ? 192 : n % 128 == 0 ? 128 : n % 64 == 0 ? 64 : n % 32 == 0 ? 32 : 16;
+    const long long wgs8 = (long long)((c.W + 15) / 16) * ((c.H + 7) / 8) * c.B * (n / ntile);
+    return wgs8 < 256 ? 4 : 8;
+}
+
 int conv_wm(int cout_p) {
     if (cout_p % 192 == 0 || cout_p % 128 == 0) return 1;
     if (cout_p % 32 == 0) return 2;
@@ -366,6 +379,10 @@ int conv_wm(int cout_p) {
 
 extern "C" int sr_debug_conv_stamps(unsigned long long* host16) {
     return hipMemcpyFromSymbol(host16, HIP_SYMBOL(sr_dbg_conv), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int sr_conv3x3_pool_tiles_rows(int H, int W, int Cout_p, int tile_rows) {
+    return ((W + 15) / 16) * ((H + tile_rows - 1) / tile_rows) * conv_wm(Cout_p);
 }
 
 extern "C" int sr_conv3x3_pool_tiles(int H, int W, int Cout_p, int compute_dtype) {
@@ -390,6 +407,10 @@ extern "C" int sr_conv3x3(const SrConv3x3* p, void* stream) {
     if (sr_conv3x3_narrow_supported(c)) return sr_conv3x3_narrow(c, st);
     if (sr_conv3x3_big_supported(c)) return sr_conv3x3_big(c, st);
     if (c.compute_dtype == SR_BF16) {
+        if (conv_tile_rows(c) == 4) {
+            if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 4>(c, st);
+            return dispatch_conv<bf16, bf16, 4>(c, st);
+        }
         if (c.x_dtype == SR_F32) return dispatch_conv<bf16, float, 8>(c, st);
         return dispatch_conv<bf16, bf16, 8>(c, st);
     }

@@ -212,8 +212,19 @@ SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
     for (int idx = tid; idx < CA_SLICES * a.C_p; idx += 256) {
         const int sl = idx / a.C_p, c = idx - sl * a.C_p;
         float s = 0.f;
-        if (c < a.C)
-            for (int t = sl; t < a.n_tiles; t += CA_SLICES) s += a.pool_partial[((size_t)b * a.n_tiles + t) * a.C_p + c];
+        if (c < a.C) {
+            // 8 partials in flight per thread (unconditional loads from clamped addresses, added in slot order: same sums as a plain loop);
+            // one load at a time made this prologue 12 us per 32 slots
+            const float* pp = a.pool_partial + (size_t)b * a.n_tiles * a.C_p + c;
+            for (int t0 = sl; t0 < a.n_tiles; t0 += 8 * CA_SLICES) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = pp[(size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (t0 + k * CA_SLICES < a.n_tiles) s += v[k];
+            }
+        }
         part[idx] = s;
     }
     __syncthreads();

@@ -255,7 +255,7 @@ def pack_upsampler(up: Upsampler, cin_p: int, dt: torch.dtype, last_cps_p: Optio
 
 def conv_call(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, cdt: torch.dtype, *, act: int = L.ACT_NONE,
               out_scale: float = 1.0, skip: Optional[Tensor] = None, out_mode: int = L.OUT_NHWC, ps_r: int = 0, cps_p: int = 0,
-              pool: Optional[Tensor] = None, fin=None, cout_p: Optional[int] = None, act_slope: float = 0.0) -> Tensor:
+              pool: Optional[Tensor] = None, fin=None, cout_p: Optional[int] = None, act_slope: float = 0.0, tile_rows: int = 0) -> Tensor:
     """One sr_conv3x3 launch on NHWC tensors (shapes are taken from the tensors)."""
     B, H, W, cin_p = x.shape
     if cout_p is None:
@@ -265,7 +265,7 @@ def conv_call(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, cdt: t
         skip=None if skip is None else skip.data_ptr(), pool_partial=None if pool is None else pool.data_ptr(),
         B=B, H=H, W=W, Cin_p=cin_p, Cout_p=cout_p,
         x_dtype=sr_dtype(x.dtype), out_dtype=sr_dtype(out.dtype), skip_dtype=sr_dtype(skip.dtype) if skip is not None else 0,
-        compute_dtype=sr_dtype(cdt), act=act, out_scale=out_scale, out_mode=out_mode, ps_r=ps_r, cps_p=cps_p, act_slope=act_slope,
+        compute_dtype=sr_dtype(cdt), act=act, out_scale=out_scale, out_mode=out_mode, ps_r=ps_r, cps_p=cps_p, act_slope=act_slope, tile_rows=tile_rows,
     )
     if fin is not None:
         fscale, fbias, fc, fh, fw = fin

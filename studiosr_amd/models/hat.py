@@ -258,7 +258,7 @@ class HAT(Model):
     def _side_stream(self, device) -> "torch.cuda.Stream":
         st = getattr(self, "_side", None)
         if st is None or st.device != torch.device(device):
-            st = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device, priority=-1)  # its small launches (channel gate: 4 workgroups) must not queue behind the attention grids
             object.__setattr__(self, "_side", st)
         return st
 
@@ -273,7 +273,9 @@ class HAT(Model):
             ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
-        n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt))
+        # small batches: 4-row conv tiles (twice the workgroups) also for the conv with the pool side output
+        th = 4 if (cdt == torch.bfloat16 and ((W + 15) // 16) * ((H + 7) // 8) * B < 256) else 0
+        n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th)
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
         # tile sizes of this model every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention
@@ -289,7 +291,7 @@ class HAT(Model):
             if unfused:
                 ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
             conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
-            conv_call(mid, *bp["cab2"], y, cdt, pool=pool)
+            conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
             # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
             ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
                              C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))

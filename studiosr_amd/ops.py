@@ -159,8 +159,10 @@ def nchw_to_u8(x: Tensor, mult: float) -> Tensor:
     return out
 
 
-def conv_pool_tiles(H: int, W: int, cout_p: int, compute_dtype: int) -> int:
-    return L.lib().sr_conv3x3_pool_tiles(H, W, cout_p, compute_dtype)
+def conv_pool_tiles(H: int, W: int, cout_p: int, compute_dtype: int, tile_rows: int = 0) -> int:
+    if tile_rows:
+        return int(L.lib().sr_conv3x3_pool_tiles_rows(H, W, cout_p, tile_rows))
+    return int(L.lib().sr_conv3x3_pool_tiles(H, W, cout_p, compute_dtype))
 
 
 # --------------------------------------------------------------------------- device-side weight packing (sr_pack_*)
