@@ -387,8 +387,10 @@ int sr_gemm_v2_try(const SrGemm& g, hipStream_t st) {
     }
     a.acc_from_skip = (g.skip != nullptr && g.act == SR_ACT_NONE && g.out_scale == 1.0f && g.epi == SR_EPI_STD) ? 1 : 0;
     if (g.K == 192) {
-        if (g.a_dtype == SR_F32) return launch2<float, 8, 6>(a, st);
-        return launch2<bf16, 8, 6>(a, st);
+        // 128-row tiles; 64-row tiles when those would leave CUs idle (small batches: every launch is one latency chain per workgroup)
+        const bool small = (long long)((g.M + 127) / 128) * (g.N / 192) < 256;
+        if (g.a_dtype == SR_F32) return small ? launch2<float, 4, 6>(a, st) : launch2<float, 8, 6>(a, st);
+        return small ? launch2<bf16, 4, 6>(a, st) : launch2<bf16, 8, 6>(a, st);
     }
     return launch2<bf16, 4, 12>(a, st);
 }
