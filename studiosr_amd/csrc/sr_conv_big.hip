@@ -14,6 +14,8 @@
 #include "sr_common.h"
 #include "sr_host.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BT = 16;                  // tile width (pixels) = one MFMA row tile
@@ -233,9 +235,12 @@ int dispatch_big(const SrConv3x3& c, hipStream_t st) {
 
 // true if sr_conv3x3_big covers this conv (bf16 compute, NHWC or PixelShuffle output, no pooling side output)
 bool sr_conv3x3_big_supported(const SrConv3x3& c) {
+    // Below ~224 workgroups the wide tile leaves too many CUs idle and the 8 x 16 / 4 x 16 kernel wins (192 -> 192: 4 x 64 x 64 33 vs 16.5 us,
+    // 8 x 64 x 64 34.7 vs 28.8 us; 8 x 72 x 72 = 240 workgroups 36.8 vs 46.0 us: wide tile).  SR_CONV_BIG_MIN overrides (tools/kbench.py conv).
+    static const int min_tiles = getenv("SR_CONV_BIG_MIN") ? atoi(getenv("SR_CONV_BIG_MIN")) : 224;
     if (c.compute_dtype != SR_BF16 || (c.out_mode != SR_OUT_NHWC && c.out_mode != SR_OUT_PIXEL_SHUFFLE) || c.pool_partial) return false;
     if (!((c.Cin_p == 192 && c.Cout_p % 192 == 0 && c.Cout_p % 256 != 0) || (c.Cin_p == 256 && c.Cout_p % 256 == 0))) return false;
-    return big_tiles(c, big_tile_rows(c)) >= 96;  // small launches keep the 8 x 16 tiles (more workgroups)
+    return big_tiles(c, big_tile_rows(c)) >= min_tiles;  // small launches keep the 8 x 16 tiles (more workgroups)
 }
 
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st) {
