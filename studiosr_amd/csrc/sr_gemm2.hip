@@ -347,7 +347,7 @@ int ilog2_exact(int v) {
 template <typename TIn, int MT, int KC>
 int launch2(const Gemm2& a, hipStream_t st) {
     dim3 grid((a.g.M + MT * 16 - 1) / (MT * 16), a.g.N / 192);
-    if (a.g.epi != SR_EPI_STD && a.g.N == 576 && a.g.heads * a.g.hd_p == 192 && grid.x >= 256) {  // fewer row tiles than CUs: three column blocks in parallel win
+    if (a.g.epi != SR_EPI_STD && a.g.N == 576 && a.g.heads * a.g.hd_p == 192 && grid.x >= 512) {  // fewer row tiles than CUs: three column blocks in parallel win
         grid.y = 1;
         hipLaunchKernelGGL((sr_gemm2_qkv_kernel<TIn, MT, KC>), grid, dim3(256), 0, st, a);
         SR_CHECK_LAUNCH("sr_gemm(v2 qkv)");
@@ -388,7 +388,7 @@ int sr_gemm_v2_try(const SrGemm& g, hipStream_t st) {
     a.acc_from_skip = (g.skip != nullptr && g.act == SR_ACT_NONE && g.out_scale == 1.0f && g.epi == SR_EPI_STD) ? 1 : 0;
     if (g.K == 192) {
         // 128-row tiles; 64-row tiles when those would leave CUs idle (small batches: every launch is one latency chain per workgroup)
-        const bool small = (long long)((g.M + 127) / 128) * (g.N / 192) < 256;
+        const bool small = (long long)((g.M + 127) / 128) * (g.N / 192) < 512;
         if (g.a_dtype == SR_F32) return small ? launch2<float, 4, 6>(a, st) : launch2<float, 8, 6>(a, st);
         return small ? launch2<bf16, 4, 6>(a, st) : launch2<bf16, 8, 6>(a, st);
     }
