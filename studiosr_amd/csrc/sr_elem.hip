@@ -209,23 +209,25 @@ SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
         for (int j = 0; j < 8; ++j) w2v[j] = (tid < a.C && j < a.Cr) ? a.w2[tid * a.Cr + j] : 0.f;
         if (tid < a.C) b2v = a.b2[tid];
     }
-    for (int idx = tid; idx < CA_SLICES * a.C_p; idx += 256) {
-        const int sl = idx / a.C_p, c = idx - sl * a.C_p;
-        float s = 0.f;
-        if (c < a.C) {
-            // 8 partials in flight per thread (unconditional loads from clamped addresses, added in slot order: same sums as a plain loop);
-            // one load at a time made this prologue 12 us per 32 slots
-            const float* pp = a.pool_partial + (size_t)b * a.n_tiles * a.C_p + c;
+    // slice sums: work item = (slice, channel quad); 16-byte loads, 8 partials in flight per item (unconditional loads from clamped
+    // addresses, added in slot order: the same sums as one scalar load at a time, which made this prologue 12 us per 32 slots)
+    {
+        const int quads = a.C_p >> 2;
+        for (int idx = tid; idx < CA_SLICES * quads; idx += 256) {
+            const int sl = idx / quads, q = idx - sl * quads;
+            f32x4 s = (f32x4)(0.0f);
+            const float* pp = a.pool_partial + (size_t)b * a.n_tiles * a.C_p + 4 * q;
             for (int t0 = sl; t0 < a.n_tiles; t0 += 8 * CA_SLICES) {
-                float v[8];
+                f32x4 v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = pp[(size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p];
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (t0 + k * CA_SLICES < a.n_tiles) s += v[k];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[sl * a.C_p + 4 * q + r] = (4 * q + r < a.C) ? s[r] : 0.f;
         }
-        part[idx] = s;
     }
     __syncthreads();
     for (int c = tid; c < a.C_p; c += 256) {

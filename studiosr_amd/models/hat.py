@@ -258,7 +258,7 @@ class HAT(Model):
     def _side_stream(self, device) -> "torch.cuda.Stream":
         st = getattr(self, "_side", None)
         if st is None or st.device != torch.device(device):
-            st = torch.cuda.Stream(device=device, priority=-1)  # its small launches (channel gate: 4 workgroups) must not queue behind the attention grids
+            st = torch.cuda.Stream(device=device)
             object.__setattr__(self, "_side", st)
         return st
 
