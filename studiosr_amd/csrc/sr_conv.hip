@@ -17,6 +17,8 @@
 #include "sr_common.h"
 #include "sr_host.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int HALO_W = 18;
@@ -366,7 +368,8 @@ int conv_tile_rows(const SrConv3x3& c) {
     const int n = c.Cout_p;
     const int ntile = (n % 256 == 0 && c.Cin_p >= 128) ? 256 : n % 192 == 0 ? 192 : n % 128 == 0 ? 128 : n % 64 == 0 ? 64 : n % 32 == 0 ? 32 : 16;
     const long long wgs8 = (long long)((c.W + 15) / 16) * ((c.H + 7) / 8) * c.B * (n / ntile);
-    return wgs8 < 256 ? 4 : 8;
+    static const int below = getenv("SR_CONV_TH4_BELOW") ? atoi(getenv("SR_CONV_TH4_BELOW")) : 256;  // A/B knob (tools/kbench.py conv)
+    return wgs8 < below ? 4 : 8;
 }
 
 int conv_wm(int cout_p) {
