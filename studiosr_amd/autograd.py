@@ -91,8 +91,13 @@ def _ksplit(rows: int, cols: int, K: int) -> int:
     """Workgroups for a weight-gradient GEMM whose contraction runs over K tokens: enough slices to fill 256 CUs, each >= 256 long."""
     tiles = ((rows + 63) // 64) * ((cols + 63) // 64)
     ks = max(1, min(1024 // max(tiles, 1), (K + 255) // 256, 512))
-    p2 = 1 << (ks.bit_length() - 1)  # token counts are B * H * W: a power-of-two slice count usually divides them (wgrad's atomic-free path)
-    return p2 if (ks >= 2 and K % p2 == 0 and 4 * p2 >= 3 * ks) else ks
+    if ks >= 2:  # token counts are B * H * W: the nearest power-of-two slice count usually divides them (wgrad's atomic-free path)
+        p2 = 1 << (ks.bit_length() - 1)
+        if ks * ks > 2 * p2 * p2:
+            p2 *= 2
+        if K % p2 == 0 and (K // p2) % 32 == 0:
+            return p2
+    return ks
 
 
 def wgrad(dy: Tensor, x: Tensor, rows: int, cols: int, T: int) -> Tensor:
