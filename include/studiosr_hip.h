@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 4
+#define SR_ABI_VERSION 5
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -121,6 +121,24 @@ typedef struct SrSwinAttn {
 } SrSwinAttn;
 int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype);
 int sr_swin_attn_fused(const SrSwinAttn* a, void* stream);
+
+typedef struct SrSwinBlock {
+    /* The WHOLE SwinTransformerBlock (swinir.py:146-174: norm1, roll, window_partition, WindowAttention :78-105 with bias table and
+     * calculate_mask, window_reverse, roll back, shortcut, norm2, Mlp common.py:173-195, shortcut) in ONE launch, ABI v5.  One window per
+     * 4-wave workgroup; every GEMM stage is a run of uniform [64 tokens x 192 columns x 32 k] steps fed from ONE packed weight stream
+     * (studiosr_amd/packing.py pack_swin_block_stream: 48 slots of 12 fragments in consumption order).  Every bias (q, v->proj, proj, fc1,
+     * fc2), both LayerNorm affines, the attention scale and log2(e) (softmax runs on exp2) are folded into that stream: biases ride on
+     * two constant-one pad channels (hi + lo bf16 split).  bf16 operands, fp32 stream / statistics / softmax; out may alias x. */
+    const float* x;        /* [B,H,W,ldx] fp32 stream */
+    float* out;
+    const void* wstream;   /* 48 * 12 * 64 * 8 bf16 */
+    const float* bias;     /* relative-position bias * log2(e) in fragment order [heads][qt][kt][lane][4] */
+    int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift, Hp;
+    float eps;
+    int y_mode;            /* SR_Y_* */
+} SrSwinBlock;
+int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
+int sr_swin_block(const SrSwinBlock* a, void* stream);
 
 typedef struct SrMlp {
     /* x_out = x + fc2(GELU(fc1(LayerNorm(x)))) in ONE kernel (common.py:173-195, swinir.py:172, hat.py:193,292):

@@ -1,0 +1,479 @@
+// One launch = one whole SwinTransformerBlock (swinir.py:146-174), round-3 kernel ("stream" form, C ABI v5 sr_swin_block):
+//     x1  = x + proj( softmax(q k^T + bias + mask) v ),   q,k,v = qkv( LayerNorm1(x) )
+//     out = x1 + fc2( GELU( fc1( LayerNorm2(x1) ) ) )
+// with window_partition, torch.roll and window_reverse folded into addressing.
+//
+// What the round-3 skeleton probe (tools/micro/skel.hip, profiles/r03_block_skeleton.txt) showed: the one-window / 4-wave / three
+// workgroups per CU shape of the round-2 kernel runs the block's GEMMs alone in 21-23 us (B = 8) -- two windows per workgroup with
+// shared weights (LDS ring or 128-row register tiles) are no faster -- and tolerates ~2,900 plain VALU per wave on top at 29 us.
+// The round-2 kernel needed 44-48 us because its QKV stage was 36 short steps (8 + 4 + 4 MFMAs) on one-deep rings, its biases,
+// accumulator initialisations and second x read were VALU / TA work, and q was projected twice.  Here:
+//   * EVERY GEMM stage is a run of the same step: 4 activation fragments (LDS) x 3 weight fragments (global, fragment order)
+//     -> 12 MFMAs, weights two steps ahead in a 3-slot register ring that never drains: the 48 slots of a block
+//     (per pass: 6 QKV + 2 proj; then 6 fc1 + 6 fc2 per hidden half) are ONE stream in consumption order, so the ring keeps
+//     prefetching through LayerNorm / softmax / GELU phases and every stage starts with its first two slots in registers.
+//   * QKV pass p (heads 2p, 2p+1): wave w = (head hh = w >> 1, half = w & 1) projects q, k and v of d-half `half` of its head
+//     for all 64 tokens (3 n-tiles x 4 m-tiles); q and k land in K-group-major images, v transposed in the key order the
+//     accumulator-as-operand trick needs.  The same wave then runs the attention atom (head hh, queries [32 half, +32)).
+//   * no bias anywhere in the kernel: the LayerNorm image carries 1.0 in its pad channels 180 / 181, the weight rows there hold
+//     the bias as a hi + lo bf16 pair (q, fc1); v's pad feature 30 is wired to 1.0 the same way, which makes row 30 of O^T the
+//     softmax denominator (as in round 2) and, after normalisation, a constant one that carries the proj bias; two hidden pad
+//     columns carry the fc2 bias.  Accumulators start as the C = 0 operand of their first MFMA.
+//   * LayerNorm1 runs in the accumulator layout like LayerNorm2 (one code path): x is read ONCE, straight into the registers
+//     that hold the residual, x1 and finally the output.
+//   * softmax on exp2: log2(e) is folded into the q rows and the bias table.
+#include "sr_common.h"
+#include "sr_host.h"
+
+namespace {
+
+__device__ unsigned long long sr_dbg_sw3[64];
+#ifdef SR_STAMPS
+#ifndef SR_STAMP_WAVE
+#define SR_STAMP_WAVE 0
+#endif
+#define STAMP(i)                                                                                                 \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (blockIdx.x == 7 && threadIdx.x == 64 * SR_STAMP_WAVE) sr_dbg_sw3[i] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+struct SwinBlock3Dev {
+    SrSwinBlock a;
+    FastDiv div_nw, div_nwx;  // windows per image, windows per row
+};
+
+constexpr int NTOK = 64, WS = 8, NSLOT = 48;
+constexpr int PAD_D = 30;  // first pad feature of a head: v[:, 30] = 1 -> row 30 of O^T = softmax denominator
+constexpr int ONE_C = 180; // first pad channel of the stream: the LayerNorm images carry 1.0 in channels 180, 181
+constexpr int LDS_A = 24 * 64 * 16;         // LayerNorm image [24 k-groups][64 tokens] of 16-B cells
+constexpr int LDS_Q = 2 * 4 * 64 * 16;      // Q image [2 heads][4 d-groups][64 tokens]; the attention output O overwrites it atom by atom
+constexpr int LDS_K = 2 * 4 * 64 * 16;      // K image [2 heads][4 d-groups][64 keys]
+constexpr int LDS_V = 2 * 2 * 4 * 32 * 16;  // V^T image [2 heads][2 key steps][4 key groups][32 d]
+constexpr int LDS_RED = 64 * 4 * 2 * 4;     // LayerNorm partial sums [64 tokens][4 waves][2]
+constexpr int LDS_TOTAL = LDS_A + LDS_Q + LDS_K + LDS_V + LDS_RED;
+static_assert(LDS_Q + LDS_K + LDS_V == LDS_A, "the hidden-half image reuses the Q / K / V region");
+static_assert(3 * LDS_TOTAL <= 160 * 1024, "three workgroups per CU");
+
+SR_DEV Frag<bf16> pack2(const f32x4& lo, const f32x4& hi) {
+    Frag<bf16> f;
+    f.v[0] = (bf16)lo[0]; f.v[1] = (bf16)lo[1]; f.v[2] = (bf16)lo[2]; f.v[3] = (bf16)lo[3];
+    f.v[4] = (bf16)hi[0]; f.v[5] = (bf16)hi[1]; f.v[6] = (bf16)hi[2]; f.v[7] = (bf16)hi[3];
+    return f;
+}
+SR_DEV bf16x4 cvt4(const f32x4& v) {
+    bf16x4 r;
+    r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];
+    return r;
+}
+SR_DEV void st_half(Frag<bf16>* cell, int half, const bf16x4& v) { *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + half * 8) = v; }
+
+// first MFMA of an accumulation chain: C is the inline constant 0 (no v_mov initialisation of the accumulator)
+SR_DEV void mma0(const Frag<bf16>& x, const Frag<bf16>& y, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, (f32x4)(0.0f), 0, 0, 0);
+}
+
+#ifdef SR_EXP_W0
+#define WSLOT(s) 0
+#else
+#define WSLOT(s) (s)
+#endif
+#ifdef SR_EXP_NOBAR
+#define BLOCK_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BLOCK_SYNC() __syncthreads()
+#endif
+
+SR_DEV float bcast_row3(float x) {  // value of lane (l & 15) + 48 in every lane
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float c = b, d = b;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return d;
+}
+// v[g] summed over the four 16-lane rows, the sum of index g delivered to row g
+SR_DEV float rows_reduce_scatter4(float v0, float v1, float v2, float v3) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v0), "+v"(v2));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v1), "+v"(v3));
+    float u02 = v0 + v2, u13 = v1 + v3;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u02), "+v"(u13));
+    return u02 + u13;
+}
+SR_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of 3 slots in registers.
+struct WStream {
+    Frag<bf16> r[3][3];
+    const Frag<bf16>* base;  // wstream + 3 w * 64 (wave-uniform)
+    SR_DEV void load(int s, int lane) {  // s is a compile-time constant at every call site (unrolled)
+        const Frag<bf16>* f = base + (size_t)WSLOT(s) * (12 * 64);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) r[s % 3][n] = f[n * 64 + lane];
+    }
+    // NST uniform steps starting at slot s0: loada(c, h, a) reads the two activation fragments (m-tiles 2h, 2h+1) of the stage's K-chunk c,
+    // compute(c, h, b, a) issues their 6 MFMAs.  Half 1 of chunk c and half 0 of chunk c + 1 are read under the MFMAs before them.
+    template <int NST, typename LoadA, typename Compute>
+    SR_DEV void run(int s0, int lane, LoadA&& loada, Compute&& compute) {
+        Frag<bf16> a0[2], a1[2];
+        loada(0, 0, a0);
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int s = s0 + c;
+            if (s + 2 < NSLOT) load(s + 2, lane);
+            loada(c, 1, a1);
+            compute(c, 0, r[s % 3], a0);
+            if (c + 1 < NST) loada(c + 1, 0, a0);
+            compute(c, 1, r[s % 3], a1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+// Specialised for C = 180 (Cp = 192), heads = 6, hd = 30 (32), ws = 8, hidden 360 (384): SwinIR / SwinFIR default geometry.
+__global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv) {
+    const SrSwinBlock& a = dv.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<bf16>* Aimg = reinterpret_cast<Frag<bf16>*>(smem);
+    Frag<bf16>* Qimg = Aimg + 24 * 64;
+    Frag<bf16>* Kimg = Qimg + 2 * 4 * 64;
+    Frag<bf16>* Vimg = Kimg + 2 * 4 * 64;
+    float* red = reinterpret_cast<float*>(Vimg + 2 * 2 * 4 * 32);
+    Frag<bf16>* Himg = Qimg;  // [24][64] hidden half (MLP stage: Q / K / V are dead)
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    int lane = lane0, ar = lane & 15, ag = lane >> 4;
+    // hipcc would hoist every per-lane LDS / global offset to kernel entry and keep ~40 address registers alive (and spilled);
+    // relane() makes the lane id opaque again so that offsets are recomputed where they are used.
+    auto relane = [&]() {
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        ar = lane & 15;
+        ag = lane >> 4;
+    };
+
+    // ---- window geometry (one window per workgroup)
+    uint32_t bimg, win, wy, wx;
+    dv.div_nw.divmod((uint32_t)blockIdx.x, bimg, win);
+    dv.div_nwx.divmod(win, wy, wx);
+    const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;  // strips arrive already rolled in y (halo exchange)
+    auto pixel_row = [&](int t) {  // image-order row of window token t (roll + partition as one gather)
+        int y = wy * WS + (t >> 3) + shift_y;
+        int x = wx * WS + (t & 7) + a.shift;
+        if (y >= a.H) y -= a.H;
+        if (x >= a.W) x -= a.W;
+        return ((int)bimg * a.H + y) * a.W + x;
+    };
+    const int hh = w >> 1, half = w & 1;  // GEMM role: d-half `half` of head 2p + hh; attention atom: queries [32 half, +32) of that head
+
+    STAMP(0);
+    // ---- x (window gather) straight into the residual registers, then the first two weight slots
+    f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float* xm = a.x + (size_t)pixel_row(m * 16 + ar) * a.ldx + w * 48 + ag * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) x1[m][n] = load4(xm + n * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WStream ws;
+    ws.base = reinterpret_cast<const Frag<bf16>*>(a.wstream) + 3 * w * 64;
+    ws.load(0, lane);
+    ws.load(1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // LayerNorm of the 64 tokens held in x1 (each wave owns 48 of the 192 channels) -> bf16 image; gamma / beta live in the weights.
+    // Pad channels 180, 181 of the image are the constant one that the bias rows of the stream multiply.
+    const bool one_lane = (w == ONE_C / 48) && (ag == (ONE_C % 16) / 4);  // channels 180.. = wave 3, n = 2, ag = 1, r = 0, 1
+    static_assert(ONE_C % 48 / 16 == 2 && ONE_C % 4 == 0, "position of the constant-one channels");
+    auto layernorm_to_image = [&]() {
+        {
+            float q1[4], q2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];  // pad channels of the stream are exactly 0
+                f32x4 t2 = x1[m][0] * x1[m][0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2[r] = __builtin_fmaf(x1[m][2][r], x1[m][2][r], __builtin_fmaf(x1[m][1][r], x1[m][1][r], t2[r]));
+                q1[m] = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+                q2[m] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+            }
+            const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);  // lane row ag: token tile m = ag
+            const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
+            *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);
+        }
+        BLOCK_SYNC();
+        const float inv = 1.0f / (float)a.C;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
+            const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf(x1[m][n][r], rstd, nmr);
+                if (n == 2) {
+                    nv[0] = one_lane ? 1.0f : nv[0];
+                    nv[1] = one_lane ? 1.0f : nv[1];
+                }
+                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, cvt4(nv));
+            }
+        }
+    };
+    layernorm_to_image();
+    STAMP(1);
+    BLOCK_SYNC();
+    STAMP(2);
+
+    // ---- shift mask terms that do not depend on the pass (common.py:250-274 from window coordinates), in log2 units
+    const bool last_row = a.y_mode != SR_Y_STRIP && (int)wy == a.H / WS - 1, last_col = (int)wx == a.W / WS - 1;
+    const bool masked = a.shift > 0 && (last_row || last_col);
+    constexpr float NEG = -100.0f * 1.4426950408889634f;
+
+    auto loada_img = [&](const Frag<bf16>* img) {
+        return [&, img](int c, int h, Frag<bf16> (&av)[2]) {
+            const Frag<bf16>* arow = img + (c * 4 + ag) * NTOK + h * 32 + ar;
+            av[0] = arow[0];
+            av[1] = arow[16];
+        };
+    };
+
+    // ---- three passes of two heads
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        relane();
+        f32x4 s[2][4];  // S^T tiles of the atom, initialised with the bias fragments
+        {
+            // -- QKV: q, k, v of (head 2p + hh, d-half) for all 64 tokens
+            f32x4 acc[4][3];
+            ws.run<6>(8 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&av)[2]) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (c == 0) {
+                        mma0(b[0], av[m], acc[2 * h + m][0]);  // q: lane = token, registers = 4 features
+                        mma0(b[1], av[m], acc[2 * h + m][1]);  // k: likewise
+                        mma0(av[m], b[2], acc[2 * h + m][2]);  // v: lane = feature, registers = 4 tokens
+                    } else {
+                        mma(b[0], av[m], acc[2 * h + m][0]);
+                        mma(b[1], av[m], acc[2 * h + m][1]);
+                        mma(av[m], b[2], acc[2 * h + m][2]);
+                    }
+                }
+            });
+            STAMP(3 + 8 * p);
+            {
+                const f32x4* bias = reinterpret_cast<const f32x4*>(a.bias) + ((size_t)(2 * p + hh) * 16 + 2 * half * 4) * 64;  // [h][qt][kt][lane]
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) s[qt][kt] = bias[(qt * 4 + kt) * 64 + lane];
+            }
+            if (p > 0) BLOCK_SYNC();  // every wave is done with the previous pass's Q / K / V (attention) and O (proj)
+            Frag<bf16>* qb = Qimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;  // cell [d-group][token]: d = 16 half + 4 ag + r
+            Frag<bf16>* kb = Kimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;
+            Frag<bf16>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + 16 * half + ar;      // cell [step][key group ag][d]: keys {32 s + 4 ag + r} then {32 s + 16 + 4 ag + r}
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                st_half(qb + m * 16, ag & 1, cvt4(acc[m][0]));
+                st_half(kb + m * 16, ag & 1, cvt4(acc[m][1]));
+                st_half(vb + (m >> 1) * 4 * 32, m & 1, cvt4(acc[m][2]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(4 + 8 * p);
+        BLOCK_SYNC();  // Q / K / V of both heads are in LDS
+        STAMP(5 + 8 * p);
+        relane();
+
+        // -- attention for the atom: S^T = K Q^T (+bias as the C operand), mask, softmax over keys (exp2), O^T = V^T P^T
+        {
+            const Frag<bf16>* qrow = Qimg + (hh * 4 + ag) * NTOK + half * 32 + ar;
+            const Frag<bf16>* kb = Kimg + (hh * 4 + ag) * NTOK + ar;
+            Frag<bf16> qf[2], kf[4];
+            qf[0] = qrow[0];
+            qf[1] = qrow[16];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) kf[kt] = kb[kt * 16];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) mma(kf[kt], qf[qt], s[qt][kt]);
+        }
+        const Frag<bf16>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + ar;
+        Frag<bf16> vf[2][2];  // [d tile][key step]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) vf[dt][st] = vb[st * 4 * 32 + dt * 16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (masked) {
+                f32x4 colneg;  // -100 where the key's column half differs from the query's
+                const bool qcol = last_col && (ar & 7) >= WS - a.shift;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) colneg[r] = (last_col && 4 * (ag & 1) + r >= WS - a.shift) != qcol ? NEG : 0.0f;
+                // label(q) != label(k)  <=>  the row halves differ (last window row only) or the column halves differ (last window
+                // column only); key row = 2 kt + (ag >> 1), key column = 4 (ag & 1) + r, query row = 4 half + 2 qt + (ar >> 3)
+                const bool qrow = last_row && 4 * half + 2 * qt + (ar >> 3) >= WS - a.shift;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const float rowneg = (last_row && 2 * kt + (ag >> 1) >= WS - a.shift) != qrow ? NEG : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qt][kt][r] += fminf(rowneg, colneg[r]);
+                }
+            }
+#ifndef SR_EXP_NOVALU
+            float mx = max3(s[qt][0][0], s[qt][0][1], s[qt][0][2]), my = max3(s[qt][2][0], s[qt][2][1], s[qt][2][2]);
+            mx = max3(mx, s[qt][0][3], s[qt][1][0]);
+            my = max3(my, s[qt][2][3], s[qt][3][0]);
+            mx = max3(mx, s[qt][1][1], s[qt][1][2]);
+            my = max3(my, s[qt][3][1], s[qt][3][2]);
+            mx = max3(mx, s[qt][1][3], s[qt][3][3]);
+            mx = fmaxf(mx, my);
+            mx = wave_max_xor(mx, 16);
+            mx = wave_max_xor(mx, 32);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#ifdef SR_EXP_NOTRANS
+                    s[qt][kt][r] = s[qt][kt][r] - mx;
+#else
+                    s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r] - mx);  // exp(logit - max): the logits are in log2 units
+#endif
+                }
+#endif
+            const Frag<bf16> p0 = pack2(s[qt][0], s[qt][1]), p1 = pack2(s[qt][2], s[qt][3]);
+            f32x4 o0, o1;
+            mma0(vf[0][0], p0, o0);
+            mma(vf[0][1], p1, o0);
+            mma0(vf[1][0], p0, o1);
+            mma(vf[1][1], p1, o1);
+            // row d = 30 of O^T (lanes 48..63, register 2 of the second d tile) is sum_k P[q][k]: the softmax denominator of query ar
+            const float inv_sum = __builtin_amdgcn_rcpf(bcast_row3(o1[PAD_D & 3]));
+            o0 *= inv_sum;
+            o1 *= inv_sum;  // feature 30 becomes 1: it multiplies the proj bias rows; feature 31 is 0
+            Frag<bf16>* ob = Qimg + (hh * 4 + (ag >> 1)) * NTOK + half * 32 + qt * 16 + ar;  // over this atom's own q cells
+            st_half(ob, ag & 1, cvt4(o0));
+            st_half(ob + 2 * NTOK, ag & 1, cvt4(o1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(6 + 8 * p);
+        BLOCK_SYNC();  // the O chunk (64 tokens x 64 channels) is complete
+        STAMP(7 + 8 * p);
+
+        // -- proj partial: x1 columns [48 w, 48 w + 48) += O_chunk @ Wproj[:, 64 p .. 64 p + 64)
+        ws.run<2>(8 * p + 6, lane, loada_img(Qimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&ov)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma(b[n], ov[m], x1[2 * h + m][n]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(8 + 8 * p);
+    }
+
+    // ---- MLP: LayerNorm2, then fc1 / GELU / fc2 in two hidden halves of 192 columns
+    relane();
+    layernorm_to_image();  // (its barrier also orders the last proj reads of O before the hidden image overwrites the region)
+    STAMP(27);
+    BLOCK_SYNC();
+    STAMP(28);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        relane();
+        f32x4 acc[4][3];
+        ws.run<6>(24 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&av)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    if (c == 0)
+                        mma0(b[n], av[m], acc[2 * h + m][n]);
+                    else
+                        mma(b[n], av[m], acc[2 * h + m][n]);
+                }
+        });
+        STAMP(30 + 5 * hf);
+        if (hf == 1) BLOCK_SYNC();  // fc2 of the first half has read the hidden image everywhere
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 g;
+#pragma unroll
+#if defined(SR_EXP_NOVALU)
+                for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r];
+#elif defined(SR_EXP_NOTRANS)
+                for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r] * 0.5f;
+#else
+                for (int r = 0; r < 4; ++r) g[r] = gelu_bf16(acc[m][n][r]);
+#endif
+                st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, cvt4(g));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(31 + 5 * hf);
+        BLOCK_SYNC();
+        STAMP(32 + 5 * hf);
+        // fc2 partial on top of x1: K = the 192 hidden columns of this half
+        ws.run<6>(30 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&hv)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma(b[n], hv[m], x1[2 * h + m][n]);
+        });
+        STAMP(33 + 5 * hf);
+    }
+
+    STAMP(40);
+    // ---- store (window_reverse + roll back folded into the address)
+    relane();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float* dst = a.out + (size_t)pixel_row(m * 16 + ar) * a.ldx + w * 48 + ag * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) store4(dst + n * 16, x1[m][n]);
+    }
+    STAMP(41);
+}
+
+}  // namespace
+
+extern "C" int sr_debug_sw3_stamps(unsigned long long* host64) {
+    return hipMemcpyFromSymbol(host64, HIP_SYMBOL(sr_dbg_sw3), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
+    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8 && Hp == 384) ? 1 : 0;
+}
+
+extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->out && p->wstream && p->bias, "sr_swin_block: null pointer");
+    const SrSwinBlock& a = *p;
+    SR_REQUIRE(sr_swin_block_supported(a.C, a.Cp, a.heads, a.hd_p, a.ws, a.Hp, SR_BF16), "sr_swin_block: unsupported geometry (use sr_swin_attn_fused / sr_gemm)");
+    SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
+                   a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
+               "sr_swin_block: bad geometry");
+    SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_block: more than 2^31 tokens");
+    SwinBlock3Dev dv;
+    dv.a = a;
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+    dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
+    dv.div_nwx = make_fastdiv((uint32_t)nwx);
+    static SrDeviceOnce attr_once;
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_block3_kernel, LDS_TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_block: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(sr_swin_block3_kernel, dim3(a.B * nwx * nwy), dim3(256), LDS_TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
+    SR_CHECK_LAUNCH("sr_swin_block");
+    return SR_OK;
+}

@@ -144,11 +144,34 @@ def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[
     return dict(fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b)
 
 
+def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
+    """The single weight stream of sr_swin_block (ABI v5) for one SwinTransformerBlock, when the kernel covers the geometry."""
+    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws == 8 and geo.hidden == 360):
+        return {}
+    attn, mlp = blk.attn, blk.mlp
+    qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, blk.norm1.weight, blk.norm1.bias)
+    w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, blk.norm2.weight, blk.norm2.bias)
+    stream = packing.pack_swin_block_stream(qw, qb, attn.proj.weight, attn.proj.bias, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden)
+    bias = packing.gather_bias(attn.relative_position_bias_table, attn.relative_position_index, geo.ntok, geo.ntok)
+    return dict(stream=stream, bias_frag_l2=packing.bias_fragments(bias * packing.LOG2E))
+
+
+def swin_block_kernel_choice() -> str:
+    """SR_SWIN_BLOCK = v3 (default: sr_swin_block, one weight stream) | v2 (round-2 one-window kernel) | v1 (round-1 kernel); read per call."""
+    return os.environ.get("SR_SWIN_BLOCK", "v3")
+
+
 def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_, cdt: torch.dtype, shift: int, y_mode: int = L.Y_ROLL) -> None:
-    """t_out = SwinTransformerBlock(t_in) (swinir.py:146-174): ONE launch when the fused kernel covers the geometry
+    """t_out = SwinTransformerBlock(t_in) (swinir.py:146-174): ONE launch when a fused kernel covers the geometry
     (attention half + MLP half on the same window), otherwise attention and MLP as separate launches."""
     B, H, W, Cp = t_in.shape
     sdt = sr_dtype(cdt)
+    if "stream" in p and swin_block_kernel_choice() == "v3" and ops.swin_block_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, sdt):
+        ops.swin_block(
+            x=t_in.data_ptr(), out=t_out.data_ptr(), wstream=p["stream"].data_ptr(), bias=p["bias_frag_l2"].data_ptr(), B=B, H=H, W=W, C=geo.C,
+            Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
+        )
+        return
     if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):
         ops.swin_attn_fused(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
@@ -319,6 +342,7 @@ class SwinIR(Model):
                 e = dict(shift=blk.shift_size, ln1=pack_ln(blk.norm1, Cp), ln2=pack_ln(blk.norm2, Cp))
                 e.update(pack_attention(blk.attn, geo, dt, norm=blk.norm1))
                 e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
+                e.update(pack_block_stream(blk, geo, dt))
                 blocks.append(e)
             P["layers"].append(dict(blocks=blocks, conv=self._pack_resi(layer.conv, C, Cp, dt), geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)

@@ -73,6 +73,18 @@ def swin_attn_fused(**kw) -> None:
     L.check(L.lib().sr_swin_attn_fused(C.byref(a), _stream()), "sr_swin_attn_fused")
 
 
+def swin_block_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, Hp: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_swin_block_supported(C_, Cp, heads, hd_p, ws, Hp, compute_dtype))
+
+
+def swin_block(**kw) -> None:
+    """The whole SwinTransformerBlock in one launch from one packed weight stream (ABI v5; swinir.py:146-174)."""
+    a = L.SrSwinBlock()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_swin_block(C.byref(a), _stream()), "sr_swin_block")
+
+
 def mlp_fused_supported(Cp: int, Hp: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_mlp_fused_supported(Cp, Hp, compute_dtype))
 

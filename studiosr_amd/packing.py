@@ -140,3 +140,103 @@ def bias_fragments(bias: Tensor) -> Tensor:
     heads, nq, nk = bias.shape
     b = bias.reshape(heads, nq // 16, 16, nk // 16, 4, 4)  # [h, qt, q16, kt, g, r]
     return b.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)  # [h, qt, kt, g, q16, r] -> lane = g*16 + q16
+
+
+# --------------------------------------------------------------------------- Swin block weight stream (C ABI v5, sr_swin_block)
+LOG2E = 1.4426950408889634
+SWIN_STREAM_SLOTS = 48
+
+
+def _bf16_hi_lo(v: Tensor):
+    """v (fp32) as a pair of bf16 numbers hi + lo (returned in fp32): 16 mantissa bits when both ride on constant-one channels."""
+    hi = v.to(torch.bfloat16).to(torch.float32)
+    lo = (v - hi).to(torch.bfloat16).to(torch.float32)
+    return hi, lo
+
+
+def gelu_bf16_value(x: float) -> float:
+    """sr_common.h gelu_bf16 (x * sigmoid form of tanh-GELU) evaluated in fp32, rounded to bf16: what the kernel stores for a
+    hidden pad column whose pre-activation is x.  Asserts that the value is far from a bf16 rounding boundary."""
+    t = torch.tensor(float(x), dtype=torch.float32)
+    sq = t * t
+    pp = sq * torch.tensor(-0.1029432, dtype=torch.float32) + torch.tensor(-2.3022082, dtype=torch.float32)
+    e = torch.exp2(t * pp)
+    g = t / (1.0 + e)
+    gb = g.to(torch.bfloat16).to(torch.float32)
+    ulp = abs(float(gb)) * 2.0 ** -8
+    assert abs(abs(float(g - gb)) - ulp / 2) > 1e-4 * max(abs(float(gb)), 1e-3), "gelu pad value sits on a bf16 rounding boundary"
+    return float(gb)
+
+
+def _tile_fragment(t: Tensor) -> Tensor:
+    """[16 rows, 32 k] -> [64 lanes, 8]: lane l holds row l & 15, k = 8 (l >> 4) + j."""
+    return t.reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)
+
+
+def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tensor, proj_b: Optional[Tensor], fc1_w: Tensor, fc1_b: Optional[Tensor],
+                           fc2_w: Tensor, fc2_b: Optional[Tensor], C: int, heads: int, hidden: int) -> Tensor:
+    """The ONE weight stream of a SwinTransformerBlock for sr_swin_block (include/studiosr_hip.h SrSwinBlock; swinir.py:78-105,146-174,
+    common.py:173-195): 48 slots x 12 fragments x [64 lanes][8] bf16 in the order the kernel consumes them --
+    per pass p (heads 2p, 2p+1): 6 QKV slots (K-chunks), 2 proj slots; then 6 fc1 + 6 fc2 slots per hidden half.
+    Wave w of the 4-wave workgroup reads fragments 3w .. 3w+2 of every slot.  All weights are the LayerNorm-folded fp32 matrices
+    (packing.fold_layernorm).  Folded in here: attention scale and log2(e) into the q rows; every bias as a hi + lo bf16 pair in the
+    columns of the constant-one channels (LayerNorm image channels C, C+1; O feature hd of heads 0 / 1; hidden columns `hidden`, +1);
+    v's pad feature hd := 1 (softmax denominator); the v bias into the proj bias (softmax rows sum to one); the k bias is dropped
+    (it shifts every logit of a row equally)."""
+    assert C == 180 and heads == 6 and hidden == 360, "sr_swin_block geometry"
+    hd, hdp, Cp, Hp = C // heads, 32, 192, 384
+    dev = qkv_w.device
+    f32 = torch.float32
+    qkv_w, proj_w, fc1_w, fc2_w = (t.detach().to(f32) for t in (qkv_w, proj_w, fc1_w, fc2_w))
+    zeros = lambda n: torch.zeros(n, dtype=f32, device=dev)
+    qkv_b = zeros(3 * C) if qkv_b is None else qkv_b.detach().to(f32)
+    proj_b = zeros(C) if proj_b is None else proj_b.detach().to(f32)
+    fc1_b = zeros(hidden) if fc1_b is None else fc1_b.detach().to(f32)
+    fc2_b = zeros(C) if fc2_b is None else fc2_b.detach().to(f32)
+
+    # ---- padded matrices
+    qs = hd ** -0.5 * LOG2E
+    M_qkv = torch.zeros(3, heads, hdp, Cp, dtype=f32, device=dev)
+    M_qkv[:, :, :hd, :C] = qkv_w.reshape(3, heads, hd, C)
+    M_qkv[0] *= qs
+    bq_hi, bq_lo = _bf16_hi_lo(qkv_b[:C].reshape(heads, hd) * qs)
+    M_qkv[0, :, :hd, C] = bq_hi
+    M_qkv[0, :, :hd, C + 1] = bq_lo
+    M_qkv[2, :, hd, C] = 1.0  # v[:, hd] = 1: row hd of O^T is the softmax denominator
+
+    bpf = proj_b + proj_w @ qkv_b[2 * C:]  # proj(o + b_v) = proj(o) + W_proj b_v
+    M_proj = torch.zeros(Cp, heads, hdp, dtype=f32, device=dev)
+    M_proj[:C, :, :hd] = proj_w.reshape(C, heads, hd)
+    bp_hi, bp_lo = _bf16_hi_lo(bpf)
+    M_proj[:C, 0, hd] = bp_hi  # O[:, head, hd] = 1 after the softmax normalisation
+    M_proj[:C, 1, hd] = bp_lo
+
+    M_fc1 = torch.zeros(Hp, Cp, dtype=f32, device=dev)
+    M_fc1[:hidden, :C] = fc1_w
+    b1_hi, b1_lo = _bf16_hi_lo(fc1_b)
+    M_fc1[:hidden, C] = b1_hi
+    M_fc1[:hidden, C + 1] = b1_lo
+    v0 = 1.0
+    c0 = gelu_bf16_value(v0)  # hidden columns `hidden`, `hidden`+1 hold the constant c0 = gelu(v0)
+    M_fc1[hidden, C] = v0
+    M_fc1[hidden + 1, C] = v0
+
+    M_fc2 = torch.zeros(Cp, Hp, dtype=f32, device=dev)
+    M_fc2[:C, :hidden] = fc2_w
+    b2_hi, b2_lo = _bf16_hi_lo(fc2_b / c0)
+    M_fc2[:C, hidden] = b2_hi
+    M_fc2[:C, hidden + 1] = b2_lo
+
+    # ---- slots: [slot][fragment 3 w + t][lane = 16 g + i][j] with element (row 16 tile + i, k = 32 chunk + 8 g + j)
+    out = torch.empty(SWIN_STREAM_SLOTS, 12, 64, 8, dtype=f32, device=dev)
+    att = out[:24].reshape(3, 8, 12, 64, 8)
+    # QKV: M_qkv[t, head = 2p + hh, d = 16 half + i, k = 32 c + 8 g + j] -> att[p, c, 3 (2 hh + half) + t, 16 g + i, j]
+    att[:, :6] = M_qkv.reshape(3, 3, 2, 2, 16, 6, 4, 8).permute(1, 5, 2, 3, 0, 6, 4, 7).reshape(3, 6, 12, 64, 8)
+    # proj: M_proj[ch = 48 w + 16 n + i, head = 2p + c2, d = 8 g + j] -> att[p, 6 + c2, 3 w + n, 16 g + i, j]
+    att[:, 6:] = M_proj.reshape(4, 3, 16, 3, 2, 4, 8).permute(3, 4, 0, 1, 5, 2, 6).reshape(3, 2, 12, 64, 8)
+    mlp = out[24:].reshape(2, 12, 12, 64, 8)
+    # fc1: M_fc1[row = 192 hf + 48 w + 16 n + i, k = 32 c + 8 g + j] -> mlp[hf, c, 3 w + n, 16 g + i, j]
+    mlp[:, :6] = M_fc1.reshape(2, 4, 3, 16, 6, 4, 8).permute(0, 4, 1, 2, 5, 3, 6).reshape(2, 6, 12, 64, 8)
+    # fc2: M_fc2[ch = 48 w + 16 n + i, k = 192 hf + 32 c + 8 g + j] -> mlp[hf, 6 + c, 3 w + n, 16 g + i, j]
+    mlp[:, 6:] = M_fc2.reshape(4, 3, 16, 2, 6, 4, 8).permute(3, 4, 0, 1, 5, 2, 6).reshape(2, 6, 12, 64, 8)
+    return out.to(torch.bfloat16).reshape(-1).contiguous()

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""sr_swin_block (round-3 stream kernel) against the round-2 kernel and the oracle on one RSTB-sized problem; then timings of both."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import studiosr_amd as S  # noqa: E402
+from studiosr_amd.models import swinir as SW  # noqa: E402
+
+
+def randomise(m, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif "relative_position_bias_table" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    m = S.SwinIR(scale=4, depths=[2], num_heads=[6]).eval()
+    randomise(m)
+    m = m.to(dev).set_precision("bf16")
+    cdt = torch.bfloat16
+    P = m._get_packed(cdt)
+    lp = P["layers"][0]
+    geo = lp["geo"]
+    ws_ = S.runtime.Workspace(dev)
+    for (B, H, W) in [(1, 24, 16), (2, 72, 72)]:
+        t = torch.randn(B, H, W, geo.Cp, device=dev)
+        t[..., geo.C:] = 0
+        for bi, bp in enumerate(lp["blocks"]):
+            outs = {}
+            for k in ("v2", "v3"):
+                os.environ["SR_SWIN_BLOCK"] = k
+                o = torch.empty_like(t)
+                SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"])
+                torch.cuda.synchronize()
+                outs[k] = o
+            d = (outs["v3"] - outs["v2"]).abs()
+            ref = (outs["v2"] - t).abs().max().item()
+            print(f"B={B} {H}x{W} block {bi} shift {bp['shift']}: max|v3-v2| {d.max().item():.3e}  mean {d.mean().item():.3e}  (max|v2-x| {ref:.3e})  pad max {outs['v3'][..., geo.C:].abs().max().item():.1e}", flush=True)
+    # oracle check of the whole reduced model (fp32 reference)
+    try:
+        from oracle import models as OM
+        x = torch.rand(1, 3, 24, 24)
+        sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+        cfg = m.get_model_config()
+        ref = OM.swinir_forward(sd, x, cfg, training=False) if hasattr(OM, "swinir_forward") else None
+        if ref is not None:
+            for k in ("v2", "v3"):
+                os.environ["SR_SWIN_BLOCK"] = k
+                y = m(x.to(dev)).cpu()
+                print(f"model vs oracle ({k}): max |d| {(y - ref).abs().max().item():.3e}", flush=True)
+    except Exception as e:  # the oracle API differs: the pytest suite covers it
+        print("oracle check skipped:", repr(e)[:200])
+    bp = lp["blocks"][1]
+    for B in (1, 4, 8, 16):
+        t = torch.randn(B, 72, 72, geo.Cp, device=dev)
+        t[..., geo.C:] = 0
+        res = {}
+        for k in ("v2", "v3"):
+            os.environ["SR_SWIN_BLOCK"] = k
+            res[k] = timeit(lambda: SW.run_swin_block(bp, geo, t, t, ws_, cdt, bp["shift"]))
+        print(f"B={B:2d} windows={B * 81:5d}  v2={res['v2']:7.1f}us  v3={res['v3']:7.1f}us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
