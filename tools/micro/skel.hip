@@ -152,6 +152,66 @@ __global__ __launch_bounds__(256, 3) void k_curv(const Frag* W, const Frag* Ain,
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3] + vs;
 }
 
+// CUR with every weight load reading slot 0 (W0 = true: L1-resident, no L2 -> L1 stream) -- how much of CUR's time is the weight stream?
+// and T12: ONE 768-thread workgroup = three 4-wave window teams kept in phase by a barrier every SYNC steps, so that a weight
+// line fetched by one team is an L1 hit for the other two (L2 -> L1 traffic / 3).
+template <bool W0, int NTEAM, int SYNC>
+__global__ __launch_bounds__(256 * NTEAM, NTEAM == 1 ? 3 : 3) void k_team(const Frag* W, const Frag* Ain, float* out, int nslot) {
+    constexpr int DIST = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int team = wv >> 2, w = wv & 3;
+    Frag* Aimg = reinterpret_cast<Frag*>(smem) + team * (50 * 1024 / 16);
+    const int ar = lane & 15, ag = lane >> 4;
+    for (int i = threadIdx.x & 255; i < 24 * 64; i += 256) Aimg[i] = Ain[i];
+    __syncthreads();
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4)(0.f);
+    Frag ring[DIST + 1][3];
+    auto loadb = [&](int s, Frag (&b)[3]) {
+        const Frag* f = W + ((size_t)(W0 ? 0 : s) * 12 + 3 * w) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) b[n] = f[n * 64];
+    };
+    auto loada = [&](int s, int h, Frag (&a)[2]) {
+        const Frag* p = Aimg + ((s % KC) * 4 + ag) * 64 + h * 32 + ar;
+        a[0] = p[0];
+        a[1] = p[16];
+    };
+#pragma unroll
+    for (int s = 0; s < DIST; ++s) loadb(s, ring[s]);
+    Frag a0[2], a1[2];
+    loada(0, 0, a0);
+    for (int s0 = 0; s0 < nslot; s0 += 12) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int s = s0 + u;
+            if (s + DIST < nslot) loadb(s + DIST, ring[(u + DIST) % (DIST + 1)]);
+            loada(s, 1, a1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma(ring[u % (DIST + 1)][n], a0[m], acc[m][n]);
+            loada(s + 1, 0, a0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma(ring[u % (DIST + 1)][n], a1[m], acc[2 + m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTEAM > 1 && SYNC > 0 && (u + 1) % SYNC == 0) __builtin_amdgcn_s_barrier();
+        }
+    }
+    f32x4 t = (f32x4)(0.f);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) t += acc[m][n];
+    out[(size_t)blockIdx.x * 256 * NTEAM + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+}
+
 // ------------------------------------------------------------------------------------------------ G
 // 4 waves, two windows: per step and wave 8 m-tiles x 3 n-tiles = 24 MFMAs per 3 weight fragments.
 template <int DIST>
@@ -338,7 +398,7 @@ int main(int argc, char** argv) {
         char nm[64]; snprintf(nm, 64, "v%d b%d %s", V, B, R ? "bar" : "-"); \
         rows.push_back({nm, [=](int nw) { hipLaunchKernelGGL(kf, dim3(nw), dim3(256), lds_cur, 0, W, A, out, NSLOT); }}); } while (0)
     std::vector<std::pair<std::string, std::function<void(int)>>> rows;
-    const int wins[] = {81, 256, 486, 512, 648, 768, 1296};
+    const int wins[] = {81, 486, 648, 768, 1296, 1944};
     printf("# us per launch; TF/s counts 2304 MFMAs x 16384 FLOP per window\n");
     printf("%-10s", "windows");
     for (int nw : wins) printf("%9d", nw);
@@ -357,17 +417,15 @@ int main(int argc, char** argv) {
         printf("\n");
         fflush(stdout);
     };
-    row("cur d2", [&](int nw) { hipLaunchKernelGGL(k_cur<2>, dim3(nw), dim3(256), lds_cur, 0, W, A, out, NSLOT); });
     row("cur d3", [&](int nw) { hipLaunchKernelGGL(k_cur<3>, dim3(nw), dim3(256), lds_cur, 0, W, A, out, NSLOT); });
-    row("G d2", [&](int nw) { hipLaunchKernelGGL(k_g<2>, dim3(nw / 2), dim3(256), lds_g, 0, W, A, out, NSLOT); });
     row("G d3", [&](int nw) { hipLaunchKernelGGL(k_g<3>, dim3(nw / 2), dim3(256), lds_g, 0, W, A, out, NSLOT); });
     row("A m0", [&](int nw) { hipLaunchKernelGGL(k_a<0>, dim3(nw / 2), dim3(512), lds_a, 0, W, A, out, NSLOT); });
-    row("A m1", [&](int nw) { hipLaunchKernelGGL(k_a<1>, dim3(nw / 2), dim3(512), lds_a, 0, W, A, out, NSLOT); });
+#define TEAM(W0, NT, SY) do { auto kf = k_team<W0, NT, SY>; const int lds = NT * 50 * 1024; CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        char nm[64]; snprintf(nm, 64, "t%d %s s%d", NT, W0 ? "w0" : "ws", SY); \
+        rows.push_back({nm, [=](int nw) { hipLaunchKernelGGL(kf, dim3(nw / NT), dim3(256 * NT), lds, 0, W, A, out, NSLOT); }}); } while (0)
+    TEAM(false, 1, 0); TEAM(true, 1, 0); TEAM(false, 3, 0); TEAM(false, 3, 1); TEAM(false, 3, 2); TEAM(false, 3, 6); TEAM(true, 3, 6); TEAM(false, 2, 1); TEAM(false, 2, 2);
     CURV(0, 1, false); CURV(0, 6, true);
-    CURV(10, 1, false); CURV(20, 1, false); CURV(40, 1, false); CURV(60, 1, false);
-    CURV(20, 6, false); CURV(40, 6, false); CURV(60, 6, false);
-    CURV(20, 6, true); CURV(40, 6, true); CURV(60, 6, true);
-    CURV(40, 2, true); CURV(40, 3, true);
+    CURV(40, 6, true);
     for (auto& r : rows) row(r.first.c_str(), r.second);
     CK(hipDeviceSynchronize());
     return 0;
