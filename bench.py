@@ -10,10 +10,10 @@ one rank per GPU) every rank processes its own batch of 8 tiles -- tiles are ind
 data-path collective ("weak" scaling); the barrier + max-over-ranks timing uses RCCL.
 
 The JSON line also carries
-  roofline      dominant kernel (the one-launch Swin block kernel `sr_swin_block_kernel<MLP>`) vs the bf16 MFMA peak,
-                timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
-  cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this
-                host's cores on a bounded sample of the same workload.
+  roofline      dominant kernel (the one-launch Swin block kernel `sr_swin_block3_kernel`, C ABI sr_swin_block) vs the bf16 MFMA
+                peak: median of 200 launches timed live with HIP events on the launch stream; `forward` = whole-forward fraction.
+  cpu_baseline  the CPU oracle (oracle/, a PyTorch-fp32 restatement pinned to the reference) timed on this host: all the
+                cores this process may use (count and CPU model stated) on one full step, plus a 1-thread leg on one tile.
   parity        PSNR of the HIP output against the oracle output on the sample, and the metric's
                 "PSNR delta" against a fixed synthetic target.
 """
@@ -50,13 +50,15 @@ def build_model(device):
     return model.to(device).set_precision("bf16")
 
 
-def time_dominant_kernel(model, x, iters: int = 50):
-    """Average duration of ONE launch of the dominant kernel, `sr_swin_block_kernel<MLP=true>` -- one whole Swin block
+def time_dominant_kernel(model, x, groups: int = 40, per_group: int = 5):
+    """Duration of ONE launch of the dominant kernel, `sr_swin_block3_kernel` (C ABI sr_swin_block) -- one whole Swin block
     (LayerNorm1 + QKV + shifted-window attention + proj + residual, LayerNorm2 + fc1 + GELU + fc2 + residual) at the
     bench shape: 648 windows = 41,472 tokens, 36 launches per forward -- timed with HIP events on the launch stream
-    (torch's current stream is the stream the C-ABI call enqueues on), and its ALGORITHMIC FLOPs per token:
+    (torch's current stream is the stream the C-ABI call enqueues on): `groups` event pairs around `per_group` back-to-back
+    launches each (200 launches), MEDIAN of the group averages.  Its ALGORITHMIC FLOPs per token:
     2*MAC of qkv (180->540) 194,400 + QK^T and AV (6 heads x 64 keys x 30) 46,080 + proj (180->180) 64,800
-    + fc1 (180->360) 129,600 + fc2 (360->180) 129,600 = 564,480 FLOP."""
+    + fc1 (180->360) 129,600 + fc2 (360->180) 129,600 = 564,480 FLOP.
+    Returns (median ms, min ms, algorithmic FLOPs per launch, launches timed)."""
     from studiosr_amd.models import swinir as SW
 
     cdt = torch.bfloat16
@@ -71,18 +73,38 @@ def time_dominant_kernel(model, x, iters: int = 50):
     def launch():
         SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"])
 
-    for _ in range(5):
+    for _ in range(10):
         launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
+    for e0, e1 in ev:
+        e0.record()
+        for _ in range(per_group):
+            launch()
+        e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = sorted(e0.elapsed_time(e1) / per_group for e0, e1 in ev)
     flops = float(B * PADDED * PADDED) * 564_480.0
-    return ms, flops
+    return ms[len(ms) // 2], ms[0], flops, groups * per_group
+
+
+# MFMAs the block kernel executes per 64-token window (padded shapes: 180 -> 192 channels, 30 -> 32 per head, 360 -> 384 hidden):
+# QKV 864 + QK^T 96 + PV 96 + proj 288 + fc1 576 + fc2 576, each v_mfma_f32_16x16x32_bf16 = 16,384 FLOP
+EXECUTED_FLOP_PER_WINDOW = 2496 * 16384.0
+
+
+def profiled_clock_ghz():
+    """Shader clock the chip holds under the dominant kernel, from the committed diagnostic run (profiles/*_block_kernel_clock.txt,
+    tools/wgtrace_blk3.py on a -DSR_WGTRACE build: s_memtime cycles / s_memrealtime time of every workgroup, median).  None if absent."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_block_kernel_clock.txt")))
+    for line in (open(files[-1]) if files else []):
+        m = re.search(r"clock_ghz_median\s*=\s*([0-9.]+)", line)
+        if m:
+            return float(m.group(1))
+    return None
 
 
 def profiled_hbm_traffic():
@@ -99,7 +121,7 @@ def profiled_hbm_traffic():
     vals, key = {}, None
     for line in open(files[-1]):
         if line.startswith("("):
-            key = "swin_block_kernel<true>" in line and ", 648)" in line
+            key = ("swin_block3_kernel" in line or "swin_block_kernel<true>" in line) and ", 648)" in line
         elif key:
             m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
             if m:
@@ -108,6 +130,36 @@ def profiled_hbm_traffic():
         return None
     return dict(bytes=int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), source=os.path.relpath(files[-1], ROOT),
                 fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"])
+
+
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores(avail: int) -> int:
+    """Physical cores among the CPUs this process may run on (distinct (physical id, core id) pairs of /proc/cpuinfo); SMT siblings
+    add little to an fp32 GEMM-bound forward, and a thread count above the core count is what made round 2's baseline swing 2.6x."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, phys = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id") and cpu in allowed:
+                cores.add((phys, line.split(":")[1].strip()))
+        if cores:
+            return len(cores)
+    except (OSError, ValueError, AttributeError):
+        pass
+    return avail
 
 
 def cpu_baseline_and_parity(model, device):
@@ -119,20 +171,29 @@ def cpu_baseline_and_parity(model, device):
     cfg = model.get_model_config()
     g = torch.Generator().manual_seed(0)
     x = torch.rand(CPU_SAMPLE_TILES, 3, TILE, TILE, generator=g)
-    cores = max(1, min(int(os.environ.get("SR_CPU_THREADS", "16")), os.cpu_count() or 1))  # the GPU box gives one GPU ~16 host cores
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(int(os.environ.get("SR_CPU_THREADS", "0")) or physical_cores(avail), avail))  # all the physical cores this process may run on
     torch.set_num_threads(cores)
     with torch.inference_mode():
         OM.swinir_forward(sd, x[:1], cfg)  # warm-up
         times = []
-        for _ in range(CPU_SAMPLE_FORWARDS):  # ~10-15 s of CPU work on 16 cores
+        for _ in range(CPU_SAMPLE_FORWARDS):  # ~10-20 s of CPU work
             t0 = time.perf_counter()
             ref = OM.swinir_forward(sd, x, cfg)
             times.append(time.perf_counter() - t0)
         dt = sorted(times)[len(times) // 2]
+        torch.set_num_threads(1)  # 1-thread leg: one tile, best of 2
+        t1 = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            OM.swinir_forward(sd, x[:1], cfg)
+            t1.append(time.perf_counter() - t0)
+        torch.set_num_threads(cores)
     mpix = CPU_SAMPLE_TILES * (TILE * SCALE) ** 2 / 1e6
-    cpu = dict(value=round(mpix / dt, 5), unit="HR-Mpix/s", cores=cores, kind="port",
-               sample=f"one step of the same workload ({CPU_SAMPLE_TILES} tiles, SwinIR x4 eval, 64x64 LR, fp32, torch CPU): median of "
-                      f"{CPU_SAMPLE_FORWARDS} forwards after 1 warm-up, {round(sum(times), 1)} s of CPU work")
+    cpu = dict(value=round(mpix / dt, 5), unit="HR-Mpix/s", cores=cores, kind="port", cpu_model=cpu_model_string(), logical_cpus_available=avail,
+               one_thread=dict(value=round((TILE * SCALE) ** 2 / 1e6 / min(t1), 5), unit="HR-Mpix/s", sample="one tile, best of 2 forwards"),
+               sample=f"one step of the same workload ({CPU_SAMPLE_TILES} tiles, SwinIR x4 eval, 64x64 LR, fp32, torch CPU, {cores} threads): median of "
+                      f"{CPU_SAMPLE_FORWARDS} forwards after 1 warm-up, {round(sum(times), 1)} s of CPU work; spread {round(min(times), 2)}-{round(max(times), 2)} s per forward")
 
     tgt = torch.rand(CPU_SAMPLE_TILES, 3, TILE * SCALE, TILE * SCALE, generator=g)
 
@@ -425,18 +486,22 @@ def main() -> None:
         elapsed1 = float(t.item())
 
     if rank == 0:
-        k_ms, k_flops = time_dominant_kernel(model, x)
+        k_ms, k_ms_min, k_flops, k_n = time_dominant_kernel(model, x)
         achieved = k_flops / (k_ms * 1e-3) / 1e12
+        executed = BATCH * (PADDED // 8) ** 2 * EXECUTED_FLOP_PER_WINDOW
+        clock = profiled_clock_ghz()
         fwd_flops = BATCH * PADDED * PADDED * FLOP_PER_LR_PIXEL  # per GPU per step, reference semantics (padded tile)
         fwd_tflops = fwd_flops / (ms_per_step * 1e-3) / 1e12
         traffic = profiled_hbm_traffic()
         # fp32 residual stream in + out (Cp = 192 channels) + the block's packed bf16 weights and biases, per launch
         algo_bytes = 2 * BATCH * PADDED * PADDED * 192 * 4 + 2 * (192 * 576 + 192 * 192 + 2 * 192 * 384) + 4 * 6 * 64 * 64
         roof = dict(
-            bound="mfma", kernel="sr_swin_block_kernel<MLP> (one whole Swin block per launch: LN1 + QKV + shifted-window attention + proj + residual + LN2 + MLP + residual; "
-                                 "one 64-token window per 4-wave workgroup, 648 workgroups, 36 launches per forward)",
+            bound="mfma", kernel="sr_swin_block3_kernel / C ABI sr_swin_block (one whole Swin block per launch: LN1 + QKV + shifted-window attention + proj + residual + LN2 + MLP + "
+                                 "residual; one 64-token window per 4-wave workgroup, 648 workgroups, 36 launches per forward)",
             achieved=round(achieved, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
             traffic=(traffic or {}).get("bytes"), traffic_detail=traffic, algorithmic_hbm_bytes=algo_bytes, kernel_ms=round(k_ms, 5),
+            kernel_ms_min=round(k_ms_min, 5), launches_timed=k_n, executed_over_algorithmic_flops=round(executed / k_flops, 4),
+            clock_ghz_held=clock, frac_of_peak_at_held_clock=(round(achieved / (MFMA_BF16_PEAK_TFLOPS * clock / 2.4), 4) if clock else None),
             forward=dict(achieved=round(fwd_tflops, 2), frac=round(fwd_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                          frac_unpadded=round(fwd_tflops * (TILE * TILE) / (PADDED * PADDED) / MFMA_BF16_PEAK_TFLOPS, 4),
                          gflop_per_step=round(fwd_flops / 1e9, 2)),

@@ -42,6 +42,23 @@ __device__ unsigned long long sr_dbg_sw3[64];
 #define STAMP(i) do { } while (0)
 #endif
 
+#ifdef SR_WGTRACE
+// diagnostic build only: per workgroup [start realtime, end realtime, (XCC id << 32) | HW_ID, start s_memtime, end s_memtime, -]
+__device__ unsigned long long sr_dbg_wgtrace[4096 * 6];
+#define WGTRACE(k)                                                                                                        \
+    do {                                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                                      \
+            sr_dbg_wgtrace[blockIdx.x * 6 + (k)] = __builtin_amdgcn_s_memrealtime();                                      \
+            sr_dbg_wgtrace[blockIdx.x * 6 + 3 + (k)] = __builtin_amdgcn_s_memtime();                                      \
+            if ((k) == 0)                                                                                                 \
+                sr_dbg_wgtrace[blockIdx.x * 6 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | \
+                                                      __builtin_amdgcn_s_getreg(4 | (31 << 11));                         \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define WGTRACE(k) do { } while (0)
+#endif
+
 struct SwinBlock3Dev {
     SrSwinBlock a;
     FastDiv div_nw, div_nwx;  // windows per image, windows per row
@@ -55,7 +72,15 @@ constexpr int LDS_Q = 2 * 4 * 64 * 16;      // Q image [2 heads][4 d-groups][64 
 constexpr int LDS_K = 2 * 4 * 64 * 16;      // K image [2 heads][4 d-groups][64 keys]
 constexpr int LDS_V = 2 * 2 * 4 * 32 * 16;  // V^T image [2 heads][2 key steps][4 key groups][32 d]
 constexpr int LDS_RED = 64 * 4 * 2 * 4;     // LayerNorm partial sums [64 tokens][4 waves][2]
-constexpr int LDS_TOTAL = LDS_A + LDS_Q + LDS_K + LDS_V + LDS_RED;
+// The fp32 window tile (x at kernel entry, the result at its end) passes through LDS as 64 token rows of 768 B at a stride of
+// XS = 784 B, laid over the image regions (all free at both moments): full rows travel between HBM and LDS with ADJACENT lanes on
+// ADJACENT addresses (the accumulator layout has adjacent lanes on different token rows: every such load / store cost the
+// vector-memory path four cache-line accesses per quad, 36 % of the kernel's TA busy time in profiles/r03_block_kernel_counters.txt),
+// and the 784-B stride makes the accumulator-layout ds_read_b128 / ds_write_b128 side conflict-free.
+constexpr int XS = 784;
+constexpr int LDS_X = 64 * XS;
+static_assert(LDS_X >= LDS_A + LDS_Q + LDS_K + LDS_V, "the x tile covers the image regions; the LayerNorm partials sit behind it");
+constexpr int LDS_TOTAL = LDS_X + LDS_RED;
 static_assert(LDS_Q + LDS_K + LDS_V == LDS_A, "the hidden-half image reuses the Q / K / V region");
 static_assert(3 * LDS_TOTAL <= 160 * 1024, "three workgroups per CU");
 
@@ -77,6 +102,20 @@ SR_DEV void mma0(const Frag<bf16>& x, const Frag<bf16>& y, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, (f32x4)(0.0f), 0, 0, 0);
 }
 
+// Wave priority by phase: a workgroup in its attention passes outranks one in its MLP, so the three workgroups of a CU (which start
+// together) stay closer in progress and the last one does not finish alone (-2..3 % at B = 8 / 16; SR_EXP_PHPRIO=0 switches it off).
+#ifndef SR_EXP_PHPRIO
+#define SR_EXP_PHPRIO 1
+#endif
+#if defined(SR_EXP_PHPRIO) && SR_EXP_PHPRIO == 1
+#define PHASE_PRIO(ph) __builtin_amdgcn_s_setprio(2 - (ph))
+#elif defined(SR_EXP_PHPRIO) && SR_EXP_PHPRIO == 2
+#define PHASE_PRIO(ph) __builtin_amdgcn_s_setprio(ph)
+#elif defined(SR_EXP_PHPRIO) && SR_EXP_PHPRIO == 3
+#define PHASE_PRIO(ph) __builtin_amdgcn_s_setprio((ph) == 0 ? 3 : 2 - (ph))
+#else
+#define PHASE_PRIO(ph) do { } while (0)
+#endif
 #ifdef SR_EXP_W0
 #define WSLOT(s) 0
 #else
@@ -103,16 +142,48 @@ SR_DEV float rows_reduce_scatter4(float v0, float v1, float v2, float v3) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u02), "+v"(u13));
     return u02 + u13;
 }
+// experiment (SR_EXP_GELUPOLY): x * clamp(0.5 + x Q(x^2), 0, 1) with a degree-4 Q: 7 plain VALU, |error| <= 1.4e-3 against erf-GELU
+SR_DEV float gelu_poly(float x) {
+    const float s = x * x;
+    float q = __builtin_fmaf(s, 1.30341647e-05f, -4.82968101e-04f);
+    q = __builtin_fmaf(q, s, 7.36121539e-03f);
+    q = __builtin_fmaf(q, s, -6.23224052e-02f);
+    q = __builtin_fmaf(q, s, 3.97474261e-01f);
+    const float phi = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, q, 0.5f), 0.0f, 1.0f);
+    return x * phi;
+}
 SR_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-// The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of 3 slots in registers.
+// one token row of the fp32 tile: global (wave-uniform row pointer + 16 B per lane, lanes 0..47) -> LDS at `lds_dst` + 16 B per lane, no VGPR staging
+SR_DEV void dma_row48(const float* row, unsigned lds_dst, int lane) {
+    if (lane < 48) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane * 16), "s"(row), "s"(lds_dst)
+                     : "memory");
+    }
+}
+
+// The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of RING slots in registers.
+// Buffer loads: the fragment's byte offset is a scalar (soffset), the lane part one shared VGPR -- no per-load 64-bit address arithmetic.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+SR_DEV Frag<bf16> buf_load_frag(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    return f;
+}
+#ifndef SR_RING_DIST
+#define SR_RING_DIST 2
+#endif
 struct WStream {
-    Frag<bf16> r[3][3];
-    const Frag<bf16>* base;  // wstream + 3 w * 64 (wave-uniform)
+    static constexpr int DIST = SR_RING_DIST, RING = DIST + 1;
+    Frag<bf16> r[RING][3];
+    __amdgpu_buffer_rsrc_t rsrc;
+    int wave_off;  // 3 w KiB (scalar)
     SR_DEV void load(int s, int lane) {  // s is a compile-time constant at every call site (unrolled)
-        const Frag<bf16>* f = base + (size_t)WSLOT(s) * (12 * 64);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) r[s % 3][n] = f[n * 64 + lane];
+        for (int n = 0; n < 3; ++n) r[s % RING][n] = buf_load_frag(rsrc, lane * 16, wave_off + (WSLOT(s) * 12 + n) * 1024);
     }
     // NST uniform steps starting at slot s0: loada(c, h, a) reads the two activation fragments (m-tiles 2h, 2h+1) of the stage's K-chunk c,
     // compute(c, h, b, a) issues their 6 MFMAs.  Half 1 of chunk c and half 0 of chunk c + 1 are read under the MFMAs before them.
@@ -120,16 +191,24 @@ struct WStream {
     SR_DEV void run(int s0, int lane, LoadA&& loada, Compute&& compute) {
         Frag<bf16> a0[2], a1[2];
         loada(0, 0, a0);
+#ifdef SR_EXP_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int c = 0; c < NST; ++c) {
             const int s = s0 + c;
-            if (s + 2 < NSLOT) load(s + 2, lane);
+            if (s + DIST < NSLOT) load(s + DIST, lane);
             loada(c, 1, a1);
-            compute(c, 0, r[s % 3], a0);
+            compute(c, 0, r[s % RING], a0);
             if (c + 1 < NST) loada(c + 1, 0, a0);
-            compute(c, 1, r[s % 3], a1);
+            compute(c, 1, r[s % RING], a1);
+#ifndef SR_EXP_NOSB
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#ifdef SR_EXP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 };
 
@@ -141,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
     Frag<bf16>* Qimg = Aimg + 24 * 64;
     Frag<bf16>* Kimg = Qimg + 2 * 4 * 64;
     Frag<bf16>* Vimg = Kimg + 2 * 4 * 64;
-    float* red = reinterpret_cast<float*>(Vimg + 2 * 2 * 4 * 32);
+    float* red = reinterpret_cast<float*>(smem + LDS_X);
     Frag<bf16>* Himg = Qimg;  // [24][64] hidden half (MLP stage: Q / K / V are dead)
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -171,20 +250,33 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
     const int hh = w >> 1, half = w & 1;  // GEMM role: d-half `half` of head 2p + hh; attention atom: queries [32 half, +32) of that head
 
     STAMP(0);
-    // ---- x (window gather) straight into the residual registers, then the first two weight slots
-    f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
+    WGTRACE(0);
+    // ---- x: 16 full token rows per wave by LDS-DMA (window gather = one scalar row address per piece), then the first weight slots
+    {
+        const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const float* xm = a.x + (size_t)pixel_row(m * 16 + ar) * a.ldx + w * 48 + ag * 4;
-#pragma unroll
-        for (int n = 0; n < 3; ++n) x1[m][n] = load4(xm + n * 16);
+        for (int i = 0; i < 16; ++i) {
+            const int t = 16 * w + i;
+            dma_row48(a.x + (size_t)pixel_row(t) * a.ldx, __builtin_amdgcn_readfirstlane(tile_lds + t * XS), lane);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     WStream ws;
-    ws.base = reinterpret_cast<const Frag<bf16>*>(a.wstream) + 3 * w * 64;
-    ws.load(0, lane);
-    ws.load(1, lane);
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, NSLOT * 12 * 1024, 0x00020000);
+    ws.wave_off = w * 3 * 1024;
+#pragma unroll
+    for (int s0 = 0; s0 < WStream::DIST; ++s0) ws.load(s0, lane);
+    const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, 6 * 16 * 64 * 16, 0x00020000);
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * WStream::DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
+    BLOCK_SYNC();
+    f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) x1[m][n] = *reinterpret_cast<const f32x4*>(xm + n * 64);
+    }
 
     // LayerNorm of the 64 tokens held in x1 (each wave owns 48 of the 192 channels) -> bf16 image; gamma / beta live in the weights.
     // Pad channels 180, 181 of the image are the constant one that the bias rows of the stream multiply.
@@ -249,7 +341,10 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         relane();
-        f32x4 s[2][4];  // S^T tiles of the atom, initialised with the bias fragments
+        if (p == 0) PHASE_PRIO(0);
+        if (p == 2) PHASE_PRIO(1);
+        f32x4 s[2][4];   // S^T tiles of the atom
+        f32x4 bt[5];     // bias tiles: tile (qt, kt) of a head depends on kt - qt only (tokens are row-major 8 x 8: a 16-token tile = two window rows)
         {
             // -- QKV: q, k, v of (head 2p + hh, d-half) for all 64 tokens
             f32x4 acc[4][3];
@@ -269,11 +364,14 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
             });
             STAMP(3 + 8 * p);
             {
-                const f32x4* bias = reinterpret_cast<const f32x4*>(a.bias) + ((size_t)(2 * p + hh) * 16 + 2 * half * 4) * 64;  // [h][qt][kt][lane]
+                // bt[j] = tile with kt - qt = j - 2 half - 1; s[q2][kt] (qt = 2 half + q2) takes bt[kt - q2 + 1].  Fetched from the
+                // representative tile (qt', kt') = (max(0, -d), max(0, d)) of the [h][qt][kt][lane] table.
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) s[qt][kt] = bias[(qt * 4 + kt) * 64 + lane];
+                for (int j = 0; j < 5; ++j) {
+                    const int d = j - 2 * half - 1;
+                    const int rep = (d < 0 ? -d * 4 : d);
+                    bt[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, lane * 16, ((2 * p + hh) * 16 + rep) * 1024, 0));
+                }
             }
             if (p > 0) BLOCK_SYNC();  // every wave is done with the previous pass's Q / K / V (attention) and O (proj)
             Frag<bf16>* qb = Qimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;  // cell [d-group][token]: d = 16 half + 4 ag + r
@@ -304,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) mma(kf[kt], qf[qt], s[qt][kt]);
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt].v, qf[qt].v, bt[kt - qt + 1], 0, 0, 0);
         }
         const Frag<bf16>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + ar;
         Frag<bf16> vf[2][2];  // [d tile][key step]
@@ -383,6 +481,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 
     // ---- MLP: LayerNorm2, then fc1 / GELU / fc2 in two hidden halves of 192 columns
     relane();
+    PHASE_PRIO(2);
     layernorm_to_image();  // (its barrier also orders the last proj reads of O before the hidden image overwrites the region)
     STAMP(27);
     BLOCK_SYNC();
@@ -414,6 +513,8 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
                 for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r];
 #elif defined(SR_EXP_NOTRANS)
                 for (int r = 0; r < 4; ++r) g[r] = acc[m][n][r] * 0.5f;
+#elif defined(SR_EXP_GELUPOLY)
+                for (int r = 0; r < 4; ++r) g[r] = gelu_poly(acc[m][n][r]);
 #else
                 for (int r = 0; r < 4; ++r) g[r] = gelu_bf16(acc[m][n][r]);
 #endif
@@ -434,15 +535,29 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
     }
 
     STAMP(40);
-    // ---- store (window_reverse + roll back folded into the address)
+    // ---- store (window_reverse + roll back folded into the row address): accumulator layout -> LDS tile -> 16 full rows per wave
     relane();
+    BLOCK_SYNC();  // every wave has read its last hidden fragments: the tile region is free
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        float* dst = a.out + (size_t)pixel_row(m * 16 + ar) * a.ldx + w * 48 + ag * 4;
+        char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) store4(dst + n * 16, x1[m][n]);
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xm + n * 64) = x1[m][n];
+    }
+    BLOCK_SYNC();
+    {
+        f32x4 rowv[16];
+        const int l48 = lane < 48 ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float* dst = a.out + (size_t)pixel_row(16 * w + i) * a.ldx;
+            if (lane < 48) store4(dst + lane * 4, rowv[i]);
+        }
     }
     STAMP(41);
+    WGTRACE(1);
 }
 
 }  // namespace
@@ -450,6 +565,12 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 extern "C" int sr_debug_sw3_stamps(unsigned long long* host64) {
     return hipMemcpyFromSymbol(host64, HIP_SYMBOL(sr_dbg_sw3), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
+
+#ifdef SR_WGTRACE
+extern "C" int sr_debug_sw3_wgtrace(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(sr_dbg_wgtrace), (size_t)n * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
     return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8 && Hp == 384) ? 1 : 0;
