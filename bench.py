@@ -162,6 +162,25 @@ def physical_cores(avail: int) -> int:
     return avail
 
 
+def cgroup_cpu_limit():
+    """CPU quota of this container in cores (cgroup v2 cpu.max or v1 cfs quota), or None when unlimited / unreadable.  The GPU boxes
+    expose every host CPU in the affinity mask but schedule the container on a fraction of them: threads beyond the quota only contend."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline_and_parity(model, device):
     """Oracle (CPU, fp32) on CPU_SAMPLE_TILES tiles of the same synthetic workload: throughput + parity."""
     from oracle import metrics as OMT
@@ -172,7 +191,10 @@ def cpu_baseline_and_parity(model, device):
     g = torch.Generator().manual_seed(0)
     x = torch.rand(CPU_SAMPLE_TILES, 3, TILE, TILE, generator=g)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(int(os.environ.get("SR_CPU_THREADS", "0")) or physical_cores(avail), avail))  # all the physical cores this process may run on
+    quota = cgroup_cpu_limit()
+    # all the physical cores this process may run on; with no readable CPU quota, at most 32 threads (the default run has to stay within minutes)
+    cores = int(os.environ.get("SR_CPU_THREADS", "0")) or min(physical_cores(avail), quota if quota else 32)
+    cores = max(1, min(cores, avail))
     torch.set_num_threads(cores)
     with torch.inference_mode():
         OM.swinir_forward(sd, x[:1], cfg)  # warm-up
@@ -190,7 +212,7 @@ def cpu_baseline_and_parity(model, device):
             t1.append(time.perf_counter() - t0)
         torch.set_num_threads(cores)
     mpix = CPU_SAMPLE_TILES * (TILE * SCALE) ** 2 / 1e6
-    cpu = dict(value=round(mpix / dt, 5), unit="HR-Mpix/s", cores=cores, kind="port", cpu_model=cpu_model_string(), logical_cpus_available=avail,
+    cpu = dict(value=round(mpix / dt, 5), unit="HR-Mpix/s", cores=cores, kind="port", cpu_model=cpu_model_string(), logical_cpus_available=avail, cgroup_cpu_quota=quota,
                one_thread=dict(value=round((TILE * SCALE) ** 2 / 1e6 / min(t1), 5), unit="HR-Mpix/s", sample="one tile, best of 2 forwards"),
                sample=f"one step of the same workload ({CPU_SAMPLE_TILES} tiles, SwinIR x4 eval, 64x64 LR, fp32, torch CPU, {cores} threads): median of "
                       f"{CPU_SAMPLE_FORWARDS} forwards after 1 warm-up, {round(sum(times), 1)} s of CPU work; spread {round(min(times), 2)}-{round(max(times), 2)} s per forward")

@@ -155,10 +155,28 @@ SR_DEV float gelu_poly(float x) {
 SR_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 // one token row of the fp32 tile: global (wave-uniform row pointer + 16 B per lane, lanes 0..47) -> LDS at `lds_dst` + 16 B per lane, no VGPR staging
+// cache policy of the once-read x rows and the once-written result rows (experiment knobs: 0 default, 1 sc1, 2 nt, 3 sc0 sc1)
+#ifndef SR_X_LOAD_POLICY_ID
+#define SR_X_LOAD_POLICY_ID 0
+#endif
+#ifndef SR_X_STORE_POLICY_ID
+#define SR_X_STORE_POLICY_ID 2  // nt: the 32 MB result leaves L2 as it is written instead of at the kernel boundary (-6.5 % at B = 8; nt on the loads: +2 %)
+#endif
+#define SR_POLICY_STR_0 ""
+#define SR_POLICY_STR_1 " sc1"
+#define SR_POLICY_STR_2 " nt"
+#define SR_POLICY_STR_3 " sc0 sc1"
+#define SR_POLICY_CAT(a, b) a##b
+#define SR_POLICY_STR(id) SR_POLICY_CAT(SR_POLICY_STR_, id)
+#define SR_X_LOAD_POLICY SR_POLICY_STR(SR_X_LOAD_POLICY_ID)
+#define SR_X_STORE_POLICY SR_POLICY_STR(SR_X_STORE_POLICY_ID)
+SR_DEV void store_row48(float* row, const f32x4& v, int lane) {  // lanes 0..47: 16 B each at row + 16 lane
+    if (lane < 48) asm volatile("global_store_dwordx4 %0, %1, %2" SR_X_STORE_POLICY "\n\ts_nop 1" ::"v"(lane * 16), "v"(v), "s"(row) : "memory");
+}
 SR_DEV void dma_row48(const float* row, unsigned lds_dst, int lane) {
     if (lane < 48) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" SR_X_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(lane * 16), "s"(row), "s"(lds_dst)
                      : "memory");
@@ -552,8 +570,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
         for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float* dst = a.out + (size_t)pixel_row(16 * w + i) * a.ldx;
-            if (lane < 48) store4(dst + lane * 4, rowv[i]);
+            store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
         }
     }
     STAMP(41);
