@@ -160,7 +160,8 @@ SR_DEV float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_
 #define SR_X_LOAD_POLICY_ID 0
 #endif
 #ifndef SR_X_STORE_POLICY_ID
-#define SR_X_STORE_POLICY_ID 2  // nt: the 32 MB result leaves L2 as it is written instead of at the kernel boundary (-6.5 % at B = 8; nt on the loads: +2 %)
+#define SR_X_STORE_POLICY_ID 1  // sc1 (write-through): the 32 MB result leaves L2 as it is written instead of at the kernel boundary: -6 % per launch at
+                                // B = 8; `nt` does the same for one batch in flight but costs 4 % with two; nt on the loads: +2 % (profiles/r03_block_kernel_ablation.txt)
 #endif
 #define SR_POLICY_STR_0 ""
 #define SR_POLICY_STR_1 " sc1"
