@@ -42,6 +42,15 @@ def bgemm(A: Tensor, B: Tensor, Cc: Tensor, M: int, N: int, K: int, sa: Tuple[in
     Under torch.autocast(bfloat16) (the reference Trainer's context) large contractions round their operands to bf16 and run on the
     bf16 matrix cores with fp32 accumulation, exactly the reference's autocast contract; `bf16_ok=False` pins a call to exact fp32
     (the DFT matrices of SwinFIR: torch.fft is not autocast to bf16 either)."""
+    # the fp32 kernels carry (batch x ksplit) on grid.z (<= 65535): chunk the first batch level beyond that (SwinIR at batch 64 of
+    # 128 x 128 patches is nb = (16,384, 6); a grad-enabled eval forward of an 830 x 830 image likewise)
+    if nb[0] * nb[1] * ksplit > 65535 and nb[0] > 1:
+        step = max(1, 65535 // (nb[1] * ksplit))
+        for b0 in range(0, nb[0], step):
+            n1 = min(step, nb[0] - b0)
+            bgemm(A, B, Cc, M, N, K, sa, sb, sc, a_off=a_off + b0 * sab[0], b_off=b_off + b0 * sbb[0], c_off=c_off + b0 * scb[0], bias=bias, alpha=alpha,
+                  accumulate=accumulate, ksplit=ksplit, nb=(n1, nb[1]), sab=sab, sbb=sbb, scb=scb, bf16_ok=bf16_ok)
+        return
     g = L.SrBgemm()
     g.A, g.B, g.C = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cc.data_ptr() + 4 * c_off
     g.bias = None if bias is None else bias.data_ptr()
@@ -141,15 +150,20 @@ class _ZeroArena:
     def __init__(self) -> None:
         self.buf: Optional[Tensor] = None
         self.off = 0
+        self.stream = None
 
     def take(self, shape, device) -> Tensor:
         n = 1
         for d in shape:
             n *= int(d)
-        if n == 0 or n > self.CHUNK // 8:
+        if n == 0 or n > self.CHUNK // 8 or torch.cuda.is_current_stream_capturing():
+            # under HIP-graph capture the chunk's fill would not be part of the graph: every replay would accumulate onto the last result
             return torch.zeros(tuple(shape), device=device, dtype=torch.float32)
-        if self.buf is None or self.buf.device != torch.device(device) or self.off + n > self.CHUNK:
-            self.buf, self.off = torch.zeros(self.CHUNK, device=device, dtype=torch.float32), 0
+        dev = torch.device(device)
+        stream = torch.cuda.current_stream(dev)
+        if self.buf is None or self.buf.device != dev or self.stream != stream or self.off + n > self.CHUNK:
+            # one chunk per (device, stream): the fill and every kernel that adds into a slice are ordered on that stream
+            self.buf, self.off, self.stream = torch.zeros(self.CHUNK, device=dev, dtype=torch.float32), 0, stream
         v = self.buf[self.off:self.off + n].view(tuple(shape))
         self.off += (n + 63) // 64 * 64  # 256-byte granules
         return v
@@ -627,7 +641,33 @@ def nhwc_out(y: Tensor, scale: Tensor, shift: Tensor, Ho: int, Wo: int) -> Tenso
 
 
 # --------------------------------------------------------------------------- host-side index logic
-_MASKS = {}
+class _LruCache(dict):
+    """Small LRU keyed on geometry (H, W, ...): a grad-enabled evaluation over a dataset of many image sizes must not keep one
+    [nW, N, N] mask (268 MB at 1024 x 1024, ws 8) or DFT matrix set per size alive."""
+
+    def __init__(self, max_items: int, max_bytes: int) -> None:
+        super().__init__()
+        self.max_items, self.max_bytes = max_items, max_bytes
+
+    @staticmethod
+    def _nbytes(v) -> int:
+        ts = v if isinstance(v, (tuple, list)) else (v,)
+        return sum(t.numel() * t.element_size() for t in ts)
+
+    def get(self, key, default=None):
+        if key in self:
+            v = self.pop(key)
+            self[key] = v  # most recently used last
+            return v
+        return default
+
+    def put(self, key, v) -> None:
+        self[key] = v
+        while len(self) > 1 and (len(self) > self.max_items or sum(self._nbytes(x) for x in self.values()) > self.max_bytes):
+            self.pop(next(iter(self)))
+
+
+_MASKS = _LruCache(8, 512 << 20)
 
 
 def shift_mask(H: int, W: int, ws: int, shift: int, device) -> Tensor:
@@ -644,7 +684,7 @@ def shift_mask(H: int, W: int, ws: int, shift: int, device) -> Tensor:
         win = img.reshape(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
         diff = win[:, None, :] - win[:, :, None]
         m = torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff)).contiguous().to(device)
-        _MASKS[key] = m
+        _MASKS.put(key, m)
     return m
 
 
@@ -823,7 +863,7 @@ def conv3d_27(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 # ---- 2-D real FFT as matrix products on the fp32 matrix cores (SwinFIR's FourierUnit, swinfir.py:19-35: rfftn / irfftn, norm="ortho")
-_DFT = {}
+_DFT = _LruCache(8, 256 << 20)
 
 
 def _dft_mats(H: int, W: int, device):
@@ -844,7 +884,7 @@ def _dft_mats(H: int, W: int, device):
         angh = 2 * torch.pi * hh[:, None] * hh[None, :] / H
         gr, gi = torch.cos(angh) / H ** 0.5, -torch.sin(angh) / H ** 0.5
         m = tuple(t.to(torch.float32).contiguous().to(device) for t in (fw, finv, gr, gi))
-        _DFT[key] = m
+        _DFT.put(key, m)
     return m
 
 
@@ -852,7 +892,7 @@ def _dft_h(Y: Tensor, Gr: Tensor, Gi: Tensor, sgn: float, B: int, H: int, Wf: in
     """Z = (Gr + i sgn Gi) Y along H for Y [B, H, Wf, (re | im) x C]: four real GEMMs batched over (b, k)."""
     Z = torch.empty_like(Y)
     ld = Wf * 2 * Cn
-    kw = dict(nb=(B, Wf), sab=(0, 0), sbb=(H * ld, 2 * Cn), scb=(H * ld, 2 * Cn))
+    kw = dict(nb=(B, Wf), sab=(0, 0), sbb=(H * ld, 2 * Cn), scb=(H * ld, 2 * Cn), bf16_ok=False)  # the reference never runs its FFT in bf16
     bgemm(Gr, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=0, c_off=0, **kw)                               # Zr  = Gr Yr
     bgemm(Gi, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=Cn, c_off=0, alpha=-sgn, accumulate=True, **kw)  # Zr -= sgn Gi Yi
     bgemm(Gi, Y, Z, H, Cn, H, (H, 1), (ld, 1), (ld, 1), b_off=0, c_off=Cn, alpha=sgn, **kw)                    # Zi  = sgn Gi Yr
@@ -870,7 +910,7 @@ class _Rfft2(Fn):
         Wf = W // 2 + 1
         fw, finv, gr, gi = _dft_mats(H, W, x.device)
         Y = torch.empty(B, H, Wf, 2 * Cn, device=x.device, dtype=torch.float32)
-        bgemm(fw, x, Y, 2 * Wf, Cn, W, (W, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0))
+        bgemm(fw, x, Y, 2 * Wf, Cn, W, (W, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0), bf16_ok=False)
         ctx.shape = (B, H, W, Cn)
         return _dft_h(Y, gr, gi, 1.0, B, H, Wf, Cn)
 
@@ -882,7 +922,7 @@ class _Rfft2(Fn):
         fw, finv, gr, gi = _dft_mats(H, W, dZ.device)
         dY = _dft_h(dZ, gr, gi, -1.0, B, H, Wf, Cn)  # the DFT matrix is symmetric: adjoint = conjugate
         dx = torch.empty(B, H, W, Cn, device=dZ.device, dtype=torch.float32)
-        bgemm(fw, dY, dx, W, Cn, 2 * Wf, (1, W), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0))
+        bgemm(fw, dY, dx, W, Cn, 2 * Wf, (1, W), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0), bf16_ok=False)
         return dx
 
 
@@ -899,7 +939,7 @@ class _Irfft2(Fn):
         fw, finv, gr, gi = _dft_mats(H, W, Z.device)
         Y = _dft_h(Z, gr, gi, -1.0, B, H, Wf, Cn)
         x = torch.empty(B, H, W, Cn, device=Z.device, dtype=torch.float32)
-        bgemm(finv, Y, x, W, Cn, 2 * Wf, (2 * Wf, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0))
+        bgemm(finv, Y, x, W, Cn, 2 * Wf, (2 * Wf, 1), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(2 * Wf * Cn, 0), scb=(W * Cn, 0), bf16_ok=False)
         ctx.shape = (B, H, W, Cn)
         return x
 
@@ -910,7 +950,7 @@ class _Irfft2(Fn):
         dx = _chk(dx)
         fw, finv, gr, gi = _dft_mats(H, W, dx.device)
         dY = torch.empty(B, H, Wf, 2 * Cn, device=dx.device, dtype=torch.float32)
-        bgemm(finv, dx, dY, 2 * Wf, Cn, W, (1, 2 * Wf), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0))
+        bgemm(finv, dx, dY, 2 * Wf, Cn, W, (1, 2 * Wf), (Cn, 1), (Cn, 1), nb=(B * H, 1), sbb=(W * Cn, 0), scb=(2 * Wf * Cn, 0), bf16_ok=False)
         return _dft_h(dY, gr, gi, 1.0, B, H, Wf, Cn), None
 
 

@@ -1099,7 +1099,7 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     SrBgemm g = *p;
     SR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nb1 > 0 && g.nb2 > 0 && g.ksplit > 0, "sr_bgemm: bad sizes M=%d N=%d K=%d nb=%dx%d ksplit=%d", g.M, g.N, g.K, g.nb1, g.nb2, g.ksplit);
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
-    SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large (batches x ksplit = %lld)", nz);
+    SR_REQUIRE(nz < (1ll << 31), "sr_bgemm: too many batches x ksplit (%lld)", nz);
     static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
     if (g.M < 96 && g.N >= 96 && !g.bias) {
         // short-and-wide (weight gradients of convs with few output channels: M = 3 or 60, N = 9 Cin): run the transposed problem
@@ -1140,6 +1140,9 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
         SR_CHECK_LAUNCH("sr_bgemm");
         return SR_OK;
     }
+    // the fp32 kernels below put (batch x ksplit) on grid.z (the bf16 kernels above use a flat x grid and have no such limit:
+    // batch 64 of 128 x 128 patches at ws 8 / 6 heads is nb = 16,384 x 6); autograd.bgemm chunks the first batch level beyond it
+    SR_REQUIRE(nz <= 65535 && (g.M + 63) / 64 <= 65535, "sr_bgemm: grid too large for the fp32 kernels (batches x ksplit = %lld > 65535)", nz);
     if (g.M >= 96 && g.N >= 24 && g.K >= 16 && !no_tiled && (g.M + BT - 1) / BT <= 65535) {
         // 128 x 128 LDS-tiled kernel; the staging mode of each operand follows which of its axes is contiguous
         const int ma = g.sa_k == 1 ? 0 : (g.sa_m == 1 ? 1 : 2), mb = g.sb_k == 1 ? 0 : (g.sb_n == 1 ? 1 : 2);

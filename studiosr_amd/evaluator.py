@@ -71,8 +71,6 @@ class Evaluator:
         return psnr, ssim
 
     def run(self, func: Callable[[np.ndarray], np.ndarray], y_only: bool = True, visualize: bool = False, logging: bool = False) -> Tuple[float, float]:
-        if visualize:
-            raise NotImplementedError("visualisation needs cv2 / a display; not part of the MI355X build")
         crop_border = self.scale
         psnrs, ssims = [], []
         for i, (lq, gt) in enumerate(self.testset):
@@ -81,7 +79,23 @@ class Evaluator:
             ssims.append(compute_ssim(sr, gt, crop_border=crop_border, y_only=y_only))
             if logging:
                 print(f" {self.dataset:>8} - {i + 1:>3}/{len(self.testset):>3} PSNR: {psnrs[-1]:6.3f}, SSIM: {ssims[-1]:6.4f}", end="\r")
+            if visualize:
+                self._save_comparison(i, lq, sr, gt)
         return float(np.mean(psnrs)), float(np.mean(ssims))
+
+    def _save_comparison(self, i: int, lq: np.ndarray, sr: np.ndarray, gt: np.ndarray) -> str:
+        """The reference shows nearest | bicubic | SR | GT side by side in a window (evaluator.py:69-72, cv2 + helpers.compare); there is
+        no display (or cv2) on an MI355X node, so the same strip is written to `<root>/<dataset>/visualize_x<scale>/<index>.png` (PIL resizes)."""
+        from PIL import Image
+
+        h, w = gt.shape[:2]
+        lq_img = Image.fromarray(lq)
+        tiles = [np.asarray(lq_img.resize((w, h), Image.NEAREST)), np.asarray(lq_img.resize((w, h), Image.BICUBIC)), sr[:h, :w], gt]
+        out_dir = os.path.join(self.root, self.dataset, f"visualize_x{self.scale}")
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, f"{i:04d}.png")
+        Image.fromarray(np.concatenate([np.ascontiguousarray(t[..., :3]) for t in tiles], axis=1)).save(path)
+        return path
 
     @staticmethod
     def benchmark(func: Callable[[np.ndarray], np.ndarray], scale: int = 4, y_only: bool = True,

@@ -31,11 +31,22 @@ def _ingest(x: Tensor, Hp: int, Wp: int, pad_mode: int, scale: Tensor, bias: Ten
     return xin
 
 
+_AFFINE_CACHE = {}
+
+
 def _affines(img_range: float, n_colors: int, device):
-    mean = torch.tensor(RGB_MEAN[:n_colors], dtype=torch.float32, device=device)
-    ing = (torch.full((n_colors,), 1.0 / float(img_range), dtype=torch.float32, device=device), (-mean).contiguous())  # x / range - mean
-    fin = (torch.full((n_colors,), float(img_range), dtype=torch.float32, device=device), (mean * img_range).contiguous())  # (x + mean) * range
-    return ing, fin
+    """Normalizer affines (common.py:222-233) as device vectors, built once per (range, colours, device): four pageable H2D copies per
+    forward would each synchronise the host against the launch queue."""
+    key = (float(img_range), int(n_colors), str(device))
+    hit = _AFFINE_CACHE.get(key)
+    if hit is None:
+        mean = torch.tensor(RGB_MEAN[:n_colors], dtype=torch.float32, device=device)
+        ing = (torch.full((n_colors,), 1.0 / float(img_range), dtype=torch.float32, device=device), (-mean).contiguous())  # x / range - mean
+        fin = (torch.full((n_colors,), float(img_range), dtype=torch.float32, device=device), (mean * img_range).contiguous())  # (x + mean) * range
+        if len(_AFFINE_CACHE) > 64:
+            _AFFINE_CACHE.clear()
+        hit = _AFFINE_CACHE[key] = (ing, fin)
+    return hit
 
 
 def _conv(x: Tensor, m: torch.nn.Conv2d, cin=None) -> Tensor:
@@ -182,8 +193,15 @@ def hat_forward(model, x: Tensor) -> Tensor:
 
 # --------------------------------------------------------------------------- EDSR / RCAN
 def _mean_shift(ms):
-    w = ms.weight.detach().reshape(3, 3)
-    return torch.diagonal(w).to(torch.float32).contiguous(), ms.bias.detach().to(torch.float32).contiguous()
+    """MeanShift (common.py:108-121) as a per-channel affine; its parameters are frozen, so the two small vectors are cached on the
+    module and rebuilt only when the weight tensor changes identity / device (`.to()`, load_state_dict)."""
+    w, b = ms.weight, ms.bias
+    key = (w.data_ptr(), b.data_ptr(), w._version, b._version, str(w.device))
+    hit = getattr(ms, "_sr_affine", None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.diagonal(w.detach().reshape(3, 3)).to(torch.float32).contiguous(), b.detach().to(torch.float32).contiguous())
+        ms._sr_affine = hit
+    return hit[1], hit[2]
 
 
 def edsr_forward(model, x: Tensor) -> Tensor:

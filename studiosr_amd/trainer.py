@@ -103,7 +103,9 @@ class Trainer:
         self._wrapped: Optional[nn.Module] = None
 
     # ------------------------------------------------------------------ one optimisation step (trainer.py:97-109)
-    def step(self, x: Tensor, y: Tensor) -> float:
+    def step(self, x: Tensor, y: Tensor) -> Tensor:
+        """One optimisation step; returns the DETACHED loss tensor (no host sync: the reference loop reads the loss only inside its
+        `eval_interval` branch, trainer.py:111-116, and a per-step `.item()` would serialise the host against ~1.4 k launches)."""
         model = self._wrapped if self._wrapped is not None else self.model
         with torch.autocast(device_type="cuda", dtype=self.dtype):
             out = model(x)
@@ -112,7 +114,7 @@ class Trainer:
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         self.scheduler.step()
-        return float(loss.detach())
+        return loss.detach()
 
     def prepare(self) -> torch.device:
         """Everything run() does before its loop: data handler, seeds, device placement, checkpoint resume, DDP wrap."""
@@ -136,7 +138,7 @@ class Trainer:
             it = dh.iterations
             if it % self.eval_interval == 0 and dh.is_main_process:
                 psnr, ssim = self.evaluate()
-                line = f" Iterations = {it:<8}  loss: {loss:8.5f}  PSNR: {psnr:6.3f} SSIM: {ssim:6.4f}"
+                line = f" Iterations = {it:<8}  loss: {float(loss):8.5f}  PSNR: {psnr:6.3f} SSIM: {ssim:6.4f}"
                 print(line)
                 log.write(line + "\n")
                 log.flush()

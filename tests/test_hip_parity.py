@@ -645,3 +645,71 @@ def test_device_weight_packing_is_bit_identical_to_the_host_packing(dt):
             want = packing.bias_fragments(packing.gather_bias(table, rpi.to(DEV), nq, nk))
             got = ops.pack_bias_fragments(table, rpi.to(DEV).contiguous(), nq, nk)
             assert torch.equal(got, want), ws
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+def test_swin_block_stream_kernel_against_the_reference_block(shift):
+    """sr_swin_block (ABI v5: one launch, one packed weight stream, biases on constant-one channels, exp2 softmax) on the reference's own
+    SwinTransformerBlock vectors (fixture f07: dim 180, 6 heads, 24 x 24 tokens, shift 0 and 4 -> masked windows), next to the round-2
+    kernel on the same input; the bf16 path keeps the stream, the LayerNorm statistics and the softmax in fp32."""
+    import os
+
+    from studiosr_amd.models import swinir as SW
+
+    g = load_golden("f07_swin_block")
+    sd = golden_sd(g, f"sd{shift}/")
+    blk = SW.SwinTransformerBlock(180, 6, 8, shift, 2.0)
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    geo = SW.SwinGeometry(180, 6, 8, 360)
+    cdt = torch.bfloat16
+    p = dict(shift=shift)
+    p.update(SW.pack_attention(blk.attn, geo, cdt, norm=blk.norm1))
+    p.update(SW.pack_mlp(blk.mlp, geo, cdt, norm=blk.norm2))
+    p.update(SW.pack_block_stream(blk, geo, cdt))
+    assert "stream" in p and p["stream"].numel() == 48 * 12 * 64 * 8
+    x = torch.from_numpy(g["x"]).to(DEV)
+    xin = torch.zeros(1, 24, 24, geo.Cp, device=DEV)
+    xin[..., :180] = x
+    want = torch.from_numpy(g[f"y_shift{shift}"])
+    ws_ = S.runtime.Workspace(torch.device(DEV))
+    outs = {}
+    prev = os.environ.get("SR_SWIN_BLOCK")
+    try:
+        for kern in ("v3", "v2"):
+            os.environ["SR_SWIN_BLOCK"] = kern
+            out = torch.full_like(xin, float("nan"))
+            SW.run_swin_block(p, geo, xin, out, ws_, cdt, shift)
+            torch.cuda.synchronize()
+            outs[kern] = out.cpu()
+    finally:
+        if prev is None:
+            os.environ.pop("SR_SWIN_BLOCK", None)
+        else:
+            os.environ["SR_SWIN_BLOCK"] = prev
+    rng = float((want - g["x"]).abs().max())  # size of what the block adds to its input
+    for kern, out in outs.items():
+        assert bool((out[..., 180:] == 0).all()), kern  # pad channels of the stream stay exactly zero
+        err = float((out[..., :180] - want).abs().max())
+        assert err <= 1e-2 * rng, (kern, err, rng)
+    # the two kernels differ only in rounding order (bias path, exp2): well inside the tolerance against the reference
+    assert float((outs["v3"] - outs["v2"]).abs().max()) <= 5e-3 * rng
+
+
+def test_swinfir_bf16_keeps_the_fft_in_fp32_at_dft_sized_images():
+    """SwinFIR precision='bf16' on an image large enough (H >= 96, W >= 190) for sr_bgemm's bf16 path: the DFT-as-GEMM rFFT / irFFT of
+    the SFB blocks must stay exact fp32 (the reference never runs torch.fft under bf16 autocast); checked against the oracle."""
+    torch.manual_seed(0)
+    m = S.SwinFIR(scale=2, embed_dim=60, depths=[2], num_heads=[6]).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    x = torch.rand(1, 3, 120, 248, generator=torch.Generator().manual_seed(2))  # eval pad -> 128 x 256
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = OM.swinir_forward(sd, x, m.get_model_config())
+        y = m.to(DEV).set_precision("bf16")(x.to(DEV)).cpu()
+    mse = float(((y - ref) ** 2).mean())
+    psnr = 10 * np.log10(max(float(ref.abs().max()), 1.0) ** 2 / max(mse, 1e-20))
+    assert float((y - ref).abs().max()) <= BF16_TOL * max(1.0, float(ref.abs().max())) and psnr >= BF16_PSNR_DB, (float((y - ref).abs().max()), psnr)

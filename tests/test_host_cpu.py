@@ -35,14 +35,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/studiosr_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in studiosr_amd/_lib.py"
     assert sorted(L.SYMBOLS) == names
-    assert lib.sr_abi_version() == L.ABI_VERSION == 4
+    assert lib.sr_abi_version() == L.ABI_VERSION == 5
 
 
 def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() of every argument struct."""
     import subprocess
 
-    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn", "SrRcab", "SrBgemm"]
+    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn", "SrSwinBlock", "SrRcab", "SrBgemm"]
     c = tmp_path / "sz.c"
     c.write_text('#include <stdio.h>\n#include "studiosr_hip.h"\nint main(){' + "".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}\n")
     exe = tmp_path / "sz"
@@ -153,3 +153,71 @@ def test_graft_entry_build_runs():
 
     g.build()
 
+
+
+def test_swin_block_stream_packing_places_every_fragment():
+    """packing.pack_swin_block_stream (vectorised) against a fragment-by-fragment restatement of the layout the kernel reads
+    (sr_swin_block3.hip: slot s, fragment 3 w + t, lane 16 g + i, element j  <->  row 16 tile + i, k = 32 chunk + 8 g + j), including the
+    bias rows on the constant-one channels and the folded scales."""
+    import torch
+
+    from studiosr_amd import packing as P
+
+    g = torch.Generator().manual_seed(3)
+    C, heads, hidden, hd = 180, 6, 360, 30
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * 0.05, torch.randn(3 * C, generator=g) * 0.1
+    proj_w, proj_b = torch.randn(C, C, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    fc1_w, fc1_b = torch.randn(hidden, C, generator=g) * 0.05, torch.randn(hidden, generator=g) * 0.1
+    fc2_w, fc2_b = torch.randn(C, hidden, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    st = P.pack_swin_block_stream(qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden).to(torch.float32).reshape(48, 12, 64, 8)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    qs = hd ** -0.5 * P.LOG2E
+    c0 = P.gelu_bf16_value(1.0)
+    assert 0.83 < c0 < 0.85
+
+    def frag(slot, f, i, k):  # element (row i of the tile, k of the 32-wide chunk)
+        return float(st[slot, f, 16 * (k // 8) + i, k % 8])
+
+    rng = torch.Generator().manual_seed(4)
+    for _ in range(300):
+        p, c, w, i, k = (int(torch.randint(0, n, (1,), generator=rng)) for n in (3, 6, 4, 16, 32))
+        hh, half = w >> 1, w & 1
+        head, d, ch = 2 * p + hh, 16 * half + i, 32 * c + k
+        for t in range(3):  # q, k, v tiles of the QKV slot
+            if d < hd and ch < C:
+                want = float(bf(qkv_w[t * C + head * hd + d, ch] * (qs if t == 0 else 1.0)))
+            elif t == 0 and d < hd and ch in (C, C + 1):
+                b = qkv_b[head * hd + d] * qs
+                want = float(bf(b)) if ch == C else float(bf(b - bf(b)))
+            elif t == 2 and d == hd and ch == C:
+                want = 1.0
+            else:
+                want = 0.0
+            assert frag(8 * p + c, 3 * w + t, i, k) == want, (p, c, w, t, i, k)
+        # fc1 / fc2 slots of hidden half hf = p % 2
+        hf, n = p % 2, c % 3
+        row = 192 * hf + 48 * w + 16 * n + i
+        if row < hidden:
+            want = float(bf(fc1_w[row, ch])) if ch < C else (float(bf(fc1_b[row])) if ch == C else (float(bf(fc1_b[row] - bf(fc1_b[row]))) if ch == C + 1 else 0.0))
+        else:
+            want = 1.0 if (row in (hidden, hidden + 1) and ch == C) else 0.0
+        assert frag(24 + 12 * hf + c, 3 * w + n, i, k) == want, ("fc1", hf, c, w, n, i, k)
+        och, hcol = 48 * w + 16 * n + i, 192 * hf + 32 * c + k
+        if och < C and hcol < hidden:
+            want = float(bf(fc2_w[och, hcol]))
+        elif och < C and hcol in (hidden, hidden + 1):
+            q = fc2_b[och] / c0
+            want = float(bf(q)) if hcol == hidden else float(bf(q - bf(q)))
+        else:
+            want = 0.0
+        assert frag(30 + 12 * hf + c, 3 * w + n, i, k) == want, ("fc2", hf, c, w, n, i, k)
+        # proj slot c2 = c % 2 of pass p: rows = output channels, k = feature d of head 2p + c2
+        c2 = c % 2
+        if och < C and k < hd:
+            want = float(bf(proj_w[och, (2 * p + c2) * hd + k]))
+        elif och < C and k == hd and 2 * p + c2 in (0, 1):
+            bpf = proj_b + proj_w @ qkv_b[2 * C:]
+            want = float(bf(bpf[och])) if 2 * p + c2 == 0 else float(bf(bpf[och] - bf(bpf[och])))
+        else:
+            want = 0.0
+        assert frag(8 * p + 6 + c2, 3 * w + n, i, k) == want, ("proj", p, c2, w, n, i, k)

@@ -95,5 +95,12 @@ def test_evaluator_over_a_directory_of_pairs(tmp_path, capsys):
     assert "Average PSNR" in capsys.readouterr().out
     ps, ss = Evaluator.benchmark(func, scale=4, datasets=["Toy"], root=str(root))
     assert ps == [pytest.approx(want_p)] and ss == [pytest.approx(want_s)]
+    # visualize=True (evaluator.py:69-72): the nearest | bicubic | SR | GT strip is written next to the dataset instead of shown in a window
+    p2, s2 = ev.run(func, visualize=True)
+    assert p2 == pytest.approx(want_p) and s2 == pytest.approx(want_s)
+    strip = imread(str(root / "Toy" / "visualize_x4" / "0000.png"))
+    lq0, gt0 = pairs["a.png"]
+    assert strip.shape == (gt0.shape[0], 4 * gt0.shape[1], 3)
+    assert np.array_equal(strip[:, :gt0.shape[1]], func(lq0)) and np.array_equal(strip[:, 2 * gt0.shape[1]:3 * gt0.shape[1]], func(lq0)) and np.array_equal(strip[:, 3 * gt0.shape[1]:], gt0)
     with pytest.raises(FileNotFoundError):
         Evaluator("Set5", scale=4, root=str(root))
