@@ -27,6 +27,7 @@ template <typename TIn, int TH, int NW, int KC, int PH>
 __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     constexpr int HH = TH + 2;                       // halo height
     constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
+    constexpr int BRS = BROWS | 1;                   // row stride of the image in cells (odd: the staging writes of one pixel's 8 K-groups hit 8 bank groups)
     constexpr int HALF = TH / 2;                     // row tiles per activation-fragment buffer
     static_assert(TH % 2 == 0, "two half chunks");
     constexpr int KCP = KC / PH;                   // 32-channel chunks per phase
@@ -51,28 +52,19 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
     const TIn* xin = reinterpret_cast<const TIn*>(c.x);
 
-    // plain residual convs: the skip tile is the initial accumulator
-    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC;
     f32x4 acc[TH][NW];
 #pragma unroll
-    for (int m = 0; m < TH; ++m) {
-        const int yy = y0 + m, xx = x0 + ar;
-        const bool inb0 = (yy < c.H) && (xx < c.W);
+    for (int m = 0; m < TH; ++m)
 #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            acc[m][n] = (f32x4)(0.0f);
-            if (acc_from_skip && inb0) {
-                const size_t off = ((size_t)(b * c.H + yy) * c.W + xx) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
-                acc[m][n] = c.skip_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(c.skip) + off) : load4(reinterpret_cast<const float*>(c.skip) + off);
-            }
-        }
-    }
+        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4)(0.0f);
 
     for (int ph = 0; ph < PH; ++ph) {
         if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
         // ---- stage channels [ph * KGP * 8, +KGP * 8) of the halo tile: 8 pixels x 8 K-groups per wave instruction
         {
-            const int r8 = lane & 7, kq = lane >> 3;
+            // K-group on the fast lane axis: the 8 lanes of a pixel read 128 / 256 contiguous bytes (pixel-fastest lanes cost the vector
+            // memory path four cache-line accesses per quad of lanes, see sr_conv_impl.h)
+            const int kq = lane & 7, r8 = lane >> 3;
             constexpr int KI = KGP / 8;
             constexpr int NPASS = 4;  // row passes whose loads are all in flight before the first LDS write
             for (int pb = wave * 8; pb < BROWS; pb += 32 * NPASS) {
@@ -93,7 +85,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                     const int p = pb + u * 32 + r8;
                     if (p < BROWS) {
 #pragma unroll
-                        for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * BROWS + p] = frag_keep_if(valid[u], f[u][i]);
+                        for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * BRS + p] = frag_keep_if(valid[u], f[u][i]);
                     }
                 }
             }
@@ -101,7 +93,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         __syncthreads();
 
         // ---- 9 taps x KCP chunks of this phase; weight chunk index in the packed order = tap * KC + ph * KCP + kc
-        const Frag<bf16>* abase0 = As + ar + ag * BROWS;
+        const Frag<bf16>* abase0 = As + ar + ag * BRS;
         Frag<bf16> br[RING][NW];
         auto wload = [&](int slot, int tap, int kc) {  // slot is compile-time at every call site
             int chunk = tap * KC + ph * KCP + kc;
@@ -126,7 +118,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 wload((kc + RING - 1) % RING, tap, kc + RING - 1);
                 // half chunk 0: the upper rows are in af[0]; fetch the lower rows of this chunk
 #pragma unroll
-                for (int m = 0; m < HALF; ++m) af[1][m] = abase[(HALF + m) * BH + kc * 4 * BROWS];
+                for (int m = 0; m < HALF; ++m) af[1][m] = abase[(HALF + m) * BH + kc * 4 * BRS];
 #pragma unroll
                 for (int m = 0; m < HALF; ++m)
 #pragma unroll
@@ -134,7 +126,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 __builtin_amdgcn_sched_barrier(0);
                 // half chunk 1: fetch the upper rows of the next chunk (next tap's first chunk after the last one)
                 {
-                    const Frag<bf16>* nb = (kc + 1 < KCP) ? abase + (kc + 1) * 4 * BROWS : abase_next;
+                    const Frag<bf16>* nb = (kc + 1 < KCP) ? abase + (kc + 1) * 4 * BRS : abase_next;
 #pragma unroll
                     for (int m = 0; m < HALF; ++m) af[0][m] = nb[m * BH];
                 }
@@ -147,62 +139,85 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         }
     }
 
-    // ---- epilogue: lane = pixel (x0 + ar), registers = 4 consecutive output channels
-    const int x = x0 + ar;
+    // ---- epilogue (the coalesced form of sr_conv_impl.h, same op order: (acc + bias) -> activation -> scale -> + skip -> round):
+    //      each wave transposes two row tiles at a time through a private fp32 LDS tile [pixel][its NW * 16 channels] and stores / reads
+    //      the residual in 16-byte pieces with adjacent lanes on adjacent addresses of one pixel
     f32x4 bias_r[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) bias_r[n] = c.bias ? load4(c.bias + (ntile0 + n) * 16 + ag * 4) : (f32x4)(0.0f);
-    int nch[NW], ps_i[NW], ps_j[NW];  // channel inside the (shuffled) pixel, sub-pixel: the run-time divisions once per column tile
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const int col = (ntile0 + n) * 16 + ag * 4;
-        nch[n] = col;
-        ps_i[n] = ps_j[n] = 0;
-        if (c.out_mode == SR_OUT_PIXEL_SHUFFLE) {  // packed channel = (i*r + j)*cps_p + ch: 4 consecutive channels of ONE shuffled pixel
-            const int sub = col / c.cps_p;
-            nch[n] = col - sub * c.cps_p;
-            ps_i[n] = sub / c.ps_r;
-            ps_j[n] = sub - ps_i[n] * c.ps_r;
-        }
-    }
     const bool scaled = c.out_scale != 1.0f;
     const float lrelu_slope = c.act_slope != 0.0f ? c.act_slope : 0.01f;
+    __syncthreads();  // every wave has issued its last fragment read of the halo image: the private tiles overlay it
+    constexpr int S = NW * 64 + 16;
+    char* priv = smem + wave * (2 * 16 * S);
+    const bool ps = c.out_mode == SR_OUT_PIXEL_SHUFFLE;
+    const int sub = ps ? (ntile0 * 16) / c.cps_p : 0, cb = ps ? ntile0 * 16 - sub * c.cps_p : ntile0 * 16;
+    const int pi = ps ? sub / c.ps_r : 0, pj = ps ? sub - pi * c.ps_r : 0;
+    const int r = ps ? c.ps_r : 1, ldo = ps ? c.cps_p : c.Cout_p;
+    const int Wo = c.W * r;
     act_dispatch(c.act, [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
+        auto run = [&](auto obf_tag) {
+            constexpr bool OBF = decltype(obf_tag)::value != 0;  // bf16 output: 8 channels per 16-byte piece; fp32: 4
+            constexpr int NV = OBF ? 8 : 4, PP = NW * 16 / NV;
+            constexpr int G = (16 * PP) % 64 == 0 ? 1 : 2, NI = G * 16 * PP / 64;
+            static_assert(TH % G == 0, "row-tile groups");
 #pragma unroll
-        for (int m = 0; m < TH; ++m) {
-            const int y = y0 + m;
-            const bool inb = (y < c.H) && (x < c.W);
-            if (!inb) continue;  // one exec-mask branch per row tile
-            const size_t pix_nhwc = ((size_t)(b * c.H + y) * c.W + x) * c.Cout_p;
-            const size_t ps_row = (size_t)(b * c.H + y) * c.ps_r, ps_col = (size_t)x * c.ps_r;
+            for (int mg = 0; mg < TH / G; ++mg) {
 #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                f32x4 v = acc[m][n] + bias_r[n];
+                for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT>(v[r], lrelu_slope);
-                if (scaled) v *= c.out_scale;
-                const size_t off = c.out_mode == SR_OUT_PIXEL_SHUFFLE ? ((ps_row + ps_i[n]) * ((size_t)c.W * c.ps_r) + ps_col + ps_j[n]) * c.cps_p + nch[n]
-                                                                     : pix_nhwc + nch[n];
-                if (c.skip && !acc_from_skip) {
-                    if (c.skip_dtype == SR_BF16)
-                        v += load4(reinterpret_cast<const bf16*>(c.skip) + off);
-                    else
-                        v += load4(reinterpret_cast<const float*>(c.skip) + off);
+                    for (int n = 0; n < NW; ++n) {
+                        f32x4 v = acc[mg * G + g][n] + bias_r[n];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = act_ct<ACT>(v[q], lrelu_slope);
+                        if (scaled) v *= c.out_scale;
+                        *reinterpret_cast<f32x4*>(priv + (g * 16 + ar) * S + (n * 16 + ag * 4) * 4) = v;
+                    }
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int idx = k * 64 + lane, px = idx / PP, pc = idx - px * PP;
+                    const int y = y0 + mg * G + (px >> 4), xq = x0 + (px & 15);
+                    const float* src = reinterpret_cast<const float*>(priv + px * S) + pc * NV;
+                    f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = (f32x4)(0.0f);
+                    if constexpr (OBF) hi = *reinterpret_cast<const f32x4*>(src + 4);
+                    if (y < c.H && xq < c.W) {
+                        const size_t off = ((size_t)((size_t)(b * c.H + y) * r + pi) * Wo + (size_t)xq * r + pj) * ldo + cb + pc * NV;
+                        if (c.skip) {
+                            if (c.skip_dtype == SR_BF16) {
+                                if constexpr (OBF) {
+                                    const bf16x8 sk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(c.skip) + off);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) lo[q] += (float)sk[q], hi[q] += (float)sk[4 + q];
+                                } else
+                                    lo += load4(reinterpret_cast<const bf16*>(c.skip) + off);
+                            } else {
+                                lo += load4(reinterpret_cast<const float*>(c.skip) + off);
+                                if constexpr (OBF) hi += load4(reinterpret_cast<const float*>(c.skip) + off + 4);
+                            }
+                        }
+                        if constexpr (OBF) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o[q] = (bf16)lo[q], o[4 + q] = (bf16)hi[q];
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(c.out) + off) = o;
+                        } else
+                            store4(reinterpret_cast<float*>(c.out) + off, lo);
+                    }
                 }
-                if (c.out_dtype == SR_BF16)
-                    store4(reinterpret_cast<bf16*>(c.out) + off, v);
-                else
-                    store4(reinterpret_cast<float*>(c.out) + off, v);
             }
-        }
+        };
+        if (c.out_dtype == SR_BF16)
+            run(IntC<1>{});
+        else
+            run(IntC<0>{});
     });
 }
 
 template <typename TIn, int TH, int NW, int KC, int PH>
 int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
-    constexpr int lds = (KC / PH) * 4 * BROWS * (int)sizeof(Frag<bf16>);
+    constexpr int lds = (KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<bf16>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
     static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
@@ -240,6 +255,7 @@ bool sr_conv3x3_big_supported(const SrConv3x3& c) {
     static const int min_tiles = getenv("SR_CONV_BIG_MIN") ? atoi(getenv("SR_CONV_BIG_MIN")) : 224;
     if (c.compute_dtype != SR_BF16 || (c.out_mode != SR_OUT_NHWC && c.out_mode != SR_OUT_PIXEL_SHUFFLE) || c.pool_partial) return false;
     if (!((c.Cin_p == 192 && c.Cout_p % 192 == 0 && c.Cout_p % 256 != 0) || (c.Cin_p == 256 && c.Cout_p % 256 == 0))) return false;
+    if (c.out_mode == SR_OUT_PIXEL_SHUFFLE && c.cps_p % (big_nw(c) * 16) != 0) return false;  // the coalesced epilogue needs a wave's channels inside one sub-pixel
     return big_tiles(c, big_tile_rows(c)) >= min_tiles;  // small launches keep the 8 x 16 tiles (more workgroups)
 }
 

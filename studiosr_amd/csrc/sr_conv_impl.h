@@ -36,12 +36,27 @@ template <int TH, int ESZ = 4>
 struct ConvGeo {
     static constexpr int HH = TH + 2;
     static constexpr int ROWS = ESZ == 2 ? ((HH * HALO_W + 63) / 64) * 64 : ((HH * HALO_W + 15) / 16) * 16;
+    static constexpr int RS = ROWS + 1;
+};
+
+// Coalesced epilogue (bf16-compute kernels): a wave's accumulator tiles have the PIXEL on the lane axis, so storing them directly puts
+// adjacent lanes on different pixels = different cache lines (8 or 16 useful bytes per line access).  Instead a wave transposes one
+// group of row tiles through a private fp32 LDS tile [pixel][its NW * 16 channels] (row stride S: conflict-free b128 writes) and
+// stores 16-byte pieces with adjacent lanes on adjacent addresses of ONE pixel; the residual is read the same way.
+template <int NW>
+struct EpiGeo {
+    static constexpr int S = NW * 64 + 16;       // bytes per pixel row of the private tile
+    static constexpr int GMAX = 2;               // row tiles per group (so that 16 * pieces * G is a multiple of 64)
+    static constexpr int PRIV = GMAX * 16 * S;   // bytes per wave
 };
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
     constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
+    // row stride of the K-group-major image in cells: ROWS + 1, so that the staging writes of ONE pixel's 8 K-groups (8 adjacent lanes,
+    // see below) fall into different banks; the fragment reads (16 consecutive rows of one K-group) do not care
+    constexpr int RS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::RS;
     constexpr int HH = ConvGeo<TH>::HH;
     constexpr int MTW = TH / WM;  // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,9 +75,11 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     const int KG = c.Cin_p >> 3, KC = c.Cin_p >> 5;
     STAMP(0);
 
-    // ---- stage the halo tile (8 pixels x 8 K-groups per wave instruction: full 128-B lines)
+    // ---- stage the halo tile: 8 pixels x 8 K-groups per wave instruction with the K-GROUP on the fast lane axis -- the 8 lanes of a pixel
+    //      read 128 (bf16) / 256 (fp32) CONTIGUOUS bytes.  (Pixel-fastest lanes made every quad of adjacent lanes touch four cache
+    //      lines: the vector-memory path then spends four tag cycles per quad -- profiles/r03_conv_ta_counters.txt.)
     {
-        const int r8 = lane & 7, kq = lane >> 3;
+        const int kq = lane & 7, r8 = lane >> 3;
         const TIn* xin = reinterpret_cast<const TIn*>(c.x);
         if constexpr (KCS > 0 && (KCS * 4) % 8 == 0) {
             // compile-time channel count (multiple of 64): two row passes per step, all of their loads issued before the first LDS write
@@ -86,7 +103,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
                 for (int u = 0; u < 2; ++u) {
                     const int p = pb + u * 32 + r8;
 #pragma unroll
-                    for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * ROWS + p] = frag_keep_if(valid[u], f[u][i]);
+                    for (int i = 0; i < KI; ++i) As[(kq + 8 * i) * RS + p] = frag_keep_if(valid[u], f[u][i]);
                 }
             }
         } else {
@@ -102,7 +119,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
                         f = load_group<TC, TIn>(src + kg * 8);
                     else
                         frag_zero(f);
-                    As[kg * ROWS + p] = f;
+                    As[kg * RS + p] = f;
                 }
             }
         }
@@ -119,7 +136,11 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     const Frag<TC>* Bp = reinterpret_cast<const Frag<TC>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
 
     // plain residual convs (no activation / scale, NHWC out): the skip tile is the initial accumulator, fetched now
-    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
+    // coalesced epilogue (see EpiGeo): NHWC, or PixelShuffle when every wave's NW * 16 channels are one sub-pixel's contiguous channels
+    bool coal = false;
+    if constexpr (sizeof(TC) == 2 && MTW % 2 == 0)
+        coal = c.out_mode == SR_OUT_NHWC || (c.out_mode == SR_OUT_PIXEL_SHUFFLE && c.cps_p % (NW * 16) == 0);
+    const bool acc_from_skip = !coal && c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
     f32x4 acc[MTW][NW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         for (int t = 0; t < RING - 1; ++t)
 #pragma unroll
             for (int n = 0; n < NW; ++n) br[t][n] = Bp[((size_t)n * KCTS + chunk_of(t)) * 64];
-        const Frag<TC>* abase0 = As + (wm * MTW) * HALO_W + ar + ag * ROWS;
+        const Frag<TC>* abase0 = As + (wm * MTW) * HALO_W + ar + ag * RS;
         if constexpr (KCS >= 2) {
             // activation fragments are double buffered across chunks: the LDS reads of chunk t+1 are issued before the MFMAs of
             // chunk t, so their latency (the only thing a one-wave-per-SIMD workgroup cannot hide otherwise) is off the critical path
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
                 }
                 if (t + 1 < KCTS) {
                     const int tn = t + 1, tap = tap_of(tn), kc = kc_of(tn);
-                    const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * ROWS;
+                    const Frag<TC>* arow = abase0 + (tap / 3) * HALO_W + (tap % 3) + kc * 4 * RS;
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) af[tn & 1][m] = arow[m * HALO_W];
                 }
@@ -207,12 +228,12 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         int chunk = 0;
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const Frag<TC>* abase = As + (wm * MTW + ky) * HALO_W + kx + ar + ag * ROWS;
+            const Frag<TC>* abase = As + (wm * MTW + ky) * HALO_W + kx + ar + ag * RS;
             for (int kc = 0; kc < KC; ++kc, ++chunk) {
                 const int cn = chunk + 1 < KCT ? chunk + 1 : chunk;
 #pragma unroll
                 for (int n = 0; n < NW; ++n) bn[n] = Bp[((size_t)n * KCT + cn) * 64];
-                const Frag<TC>* arow = abase + kc * 4 * ROWS;
+                const Frag<TC>* arow = abase + kc * 4 * RS;
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
                     const Frag<TC> a = arow[m * HALO_W];
@@ -249,6 +270,77 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     }
     const bool scaled = c.out_scale != 1.0f;
     const float lrelu_slope = c.act_slope != 0.0f ? c.act_slope : 0.01f;
+    if (coal) {
+        if constexpr (sizeof(TC) == 2 && MTW % 2 == 0) {
+            __syncthreads();  // every wave has issued its last fragment read of the halo image: the private tiles overlay it
+            char* priv = smem + wave * EpiGeo<NW>::PRIV;
+            constexpr int S = EpiGeo<NW>::S;
+            const bool ps = c.out_mode == SR_OUT_PIXEL_SHUFFLE;
+            // PixelShuffle: this wave's channels [ntile0 * 16, +NW * 16) are channels [cb, +NW * 16) of sub-pixel (pi, pj)
+            const int sub = ps ? (ntile0 * 16) / c.cps_p : 0, cb = ps ? ntile0 * 16 - sub * c.cps_p : ntile0 * 16;
+            const int pi = ps ? sub / c.ps_r : 0, pj = ps ? sub - pi * c.ps_r : 0;
+            const int r = ps ? c.ps_r : 1, ldo = ps ? c.cps_p : c.Cout_p;
+            const int Wo = c.W * r;
+            act_dispatch(c.act, [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+                auto run = [&](auto obf_tag) {
+                    constexpr bool OBF = decltype(obf_tag)::value != 0;  // bf16 output: 8 channels per 16-byte piece; fp32: 4
+                    constexpr int NV = OBF ? 8 : 4, PP = NW * 16 / NV;
+                    constexpr int G = (16 * PP) % 64 == 0 ? 1 : 2, NI = G * 16 * PP / 64;
+                    static_assert(MTW % G == 0 && G <= EpiGeo<NW>::GMAX, "row-tile groups");
+#pragma unroll
+                    for (int mg = 0; mg < MTW / G; ++mg) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int n = 0; n < NW; ++n) {
+                                f32x4 v = acc[mg * G + g][n] + bias_r[n];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = act_ct<ACT>(v[q], lrelu_slope);
+                                if (c.pool_partial) pool[n] += v;
+                                if (scaled) v *= c.out_scale;
+                                *reinterpret_cast<f32x4*>(priv + (g * 16 + ar) * S + (n * 16 + ag * 4) * 4) = v;
+                            }
+#pragma unroll
+                        for (int k = 0; k < NI; ++k) {
+                            const int idx = k * 64 + lane, px = idx / PP, pc = idx - px * PP;
+                            const int y = y0 + wm * MTW + mg * G + (px >> 4), xq = x0 + (px & 15);
+                            const float* src = reinterpret_cast<const float*>(priv + px * S) + pc * NV;
+                            f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = (f32x4)(0.0f);
+                            if constexpr (OBF) hi = *reinterpret_cast<const f32x4*>(src + 4);
+                            if (y < c.H && xq < c.W) {
+                                const size_t off = ((size_t)((size_t)(b * c.H + y) * r + pi) * Wo + (size_t)xq * r + pj) * ldo + cb + pc * NV;
+                                if (c.skip) {
+                                    if (c.skip_dtype == SR_BF16) {
+                                        if constexpr (OBF) {
+                                            const bf16x8 sk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(c.skip) + off);
+#pragma unroll
+                                            for (int q = 0; q < 4; ++q) lo[q] += (float)sk[q], hi[q] += (float)sk[4 + q];
+                                        } else
+                                            lo += load4(reinterpret_cast<const bf16*>(c.skip) + off);
+                                    } else {
+                                        lo += load4(reinterpret_cast<const float*>(c.skip) + off);
+                                        if constexpr (OBF) hi += load4(reinterpret_cast<const float*>(c.skip) + off + 4);
+                                    }
+                                }
+                                if constexpr (OBF) {
+                                    bf16x8 o;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) o[q] = (bf16)lo[q], o[4 + q] = (bf16)hi[q];
+                                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(c.out) + off) = o;
+                                } else
+                                    store4(reinterpret_cast<float*>(c.out) + off, lo);
+                            }
+                        }
+                    }
+                };
+                if (c.out_dtype == SR_BF16)
+                    run(IntC<1>{});
+                else
+                    run(IntC<0>{});
+            });
+        }
+    } else {
     act_dispatch(c.act, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -294,6 +386,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     }
     });
 
+    }
     STAMP(4);
     if (c.pool_partial) {
         const int n_tiles = tiles_x * tiles_y * WM;
@@ -317,8 +410,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
-    constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
-    const int lds = c.Cin_p * ROWS * (int)sizeof(TC);
+    constexpr int RS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::RS;
+    // halo image, or the four wave-private transpose tiles of the coalesced epilogue if they need more
+    const int lds_img = c.Cin_p * RS * (int)sizeof(TC);
+    const int lds = lds_img > 4 * EpiGeo<NW>::PRIV ? lds_img : 4 * EpiGeo<NW>::PRIV;
     SR_REQUIRE(lds <= 160 * 1024, "sr_conv3x3: Cin_p=%d needs %d B of LDS", c.Cin_p, lds);
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
