@@ -52,11 +52,23 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
     const TIn* xin = reinterpret_cast<const TIn*>(c.x);
 
+    // plain residual convs: the skip tile is the initial accumulator (fetched now, in the accumulator layout: its latency hides under
+    // the staging; in the epilogue a residual read sits on the critical path of every row-tile group: 37 -> 47 us on the RSTB conv)
+    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC;
     f32x4 acc[TH][NW];
 #pragma unroll
-    for (int m = 0; m < TH; ++m)
+    for (int m = 0; m < TH; ++m) {
+        const int yy = y0 + m, xx = x0 + ar;
+        const bool inb0 = (yy < c.H) && (xx < c.W);
 #pragma unroll
-        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4)(0.0f);
+        for (int n = 0; n < NW; ++n) {
+            acc[m][n] = (f32x4)(0.0f);
+            if (acc_from_skip && inb0) {
+                const size_t off = ((size_t)(b * c.H + yy) * c.W + xx) * c.Cout_p + (ntile0 + n) * 16 + ag * 4;
+                acc[m][n] = c.skip_dtype == SR_BF16 ? load4(reinterpret_cast<const bf16*>(c.skip) + off) : load4(reinterpret_cast<const float*>(c.skip) + off);
+            }
+        }
+    }
 
     for (int ph = 0; ph < PH; ++ph) {
         if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                     if constexpr (OBF) hi = *reinterpret_cast<const f32x4*>(src + 4);
                     if (y < c.H && xq < c.W) {
                         const size_t off = ((size_t)((size_t)(b * c.H + y) * r + pi) * Wo + (size_t)xq * r + pj) * ldo + cb + pc * NV;
-                        if (c.skip) {
+                        if (c.skip && !acc_from_skip) {
                             if (c.skip_dtype == SR_BF16) {
                                 if constexpr (OBF) {
                                     const bf16x8 sk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(c.skip) + off);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     bool coal = false;
     if constexpr (sizeof(TC) == 2 && MTW % 2 == 0)
         coal = c.out_mode == SR_OUT_NHWC || (c.out_mode == SR_OUT_PIXEL_SHUFFLE && c.cps_p % (NW * 16) == 0);
-    const bool acc_from_skip = !coal && c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
+    const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
     f32x4 acc[MTW][NW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
                             if constexpr (OBF) hi = *reinterpret_cast<const f32x4*>(src + 4);
                             if (y < c.H && xq < c.W) {
                                 const size_t off = ((size_t)((size_t)(b * c.H + y) * r + pi) * Wo + (size_t)xq * r + pj) * ldo + cb + pc * NV;
-                                if (c.skip) {
+                                if (c.skip && !acc_from_skip) {
                                     if (c.skip_dtype == SR_BF16) {
                                         if constexpr (OBF) {
                                             const bf16x8 sk = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(c.skip) + off);
