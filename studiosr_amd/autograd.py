@@ -22,13 +22,25 @@ Tensor = torch.Tensor
 Fn = torch.autograd.Function
 
 
+_LAUNCH_TLS = threading.local()  # device of the tensors of the op being launched on this thread
+
+
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    """Stream handle for a C-ABI launch: the current stream OF THE DEVICE THE OPERANDS LIVE ON (recorded by _chk), not of whatever device
+    the calling thread happens to have current."""
+    dev = getattr(_LAUNCH_TLS, "dev", None)
+    return (torch.cuda.current_stream(dev) if dev is not None else torch.cuda.current_stream()).cuda_stream
 
 
 def _chk(t: Tensor) -> Tensor:
     if not t.is_cuda:
         raise L.HipLibraryError("studiosr_amd training ops need ROCm device tensors (there is no CPU path)")
+    # kernels launch on the current HIP device: make it the operands' device (autograd's worker thread of device i normally has it
+    # current already, Model.__call__ pins it in forward; a model on cuda:3 driven from a thread whose current device is 0 would
+    # otherwise launch on the wrong device's stream)
+    if t.device.index != torch.cuda.current_device():
+        torch.cuda.set_device(t.device)
+    _LAUNCH_TLS.dev = t.device
     if t.dtype != torch.float32:
         raise TypeError(f"training ops are fp32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()

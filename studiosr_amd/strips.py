@@ -18,6 +18,8 @@ single GPU.  The orchestration (`swinir_forward_strips`) is written once, over a
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -164,6 +166,18 @@ class DistStripComm(StripComm):
         return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0).movedim(0, dim).to(out_dev)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """One halo-exchange stream per device (created on first use; streams are cheap but not free to create per forward)."""
+    key = torch.device(device).index
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 # --------------------------------------------------------------------------- strip buffers
 class _Strip:
     """Rows [r0, r1) of a [1, H, W, C] NHWC image, stored with `top` margin rows above and `bot` below so that halo rows
@@ -241,23 +255,71 @@ def swinir_forward_strips(model, x: Tensor, comm: StripComm) -> Tensor:
         conv_call(xin[:, row0[i] : row0[i] + n + 2], *P["first"], first[i].view(-1, n + 1), cdt)
         ops.layernorm(first[i].own, ta[i].own, *P["pe_norm"], C)
 
+    # Halo exchanges of the SW-MSA blocks run on a SIDE stream beside the windows that do not need them: the rolled
+    # strip's interior window rows are launched first, the last window row (the only one that reads the rows received from the strip
+    # below) after the exchange has landed; the roll-back exchange of its result overlaps with the interior window rows of the NEXT block,
+    # whose first window row waits for it.  Same windows, same kernels, same operands: results stay bit-identical to the unsharded forward.
+    overlap = os.environ.get("SR_STRIPS_OVERLAP", "1") != "0" and x.is_cuda
+    main = torch.cuda.current_stream(x.device) if x.is_cuda else None
+    side = _side_stream(x.device) if overlap else None
+    pending = [None]  # event of a roll-back exchange whose rows [0, shift) of `tb` the next consumer must wait for
+
+    def on_side(fn):
+        """Run the exchange `fn` on the side stream, ordered after everything enqueued on the compute stream so far; returns its completion event."""
+        if not overlap:
+            fn()
+            return None
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        return done
+
+    def wait(ev) -> None:
+        if ev is not None:
+            main.wait_event(ev)
+
+    def settle() -> None:  # before any consumer that reads whole strips (convs, LayerNorm)
+        wait(pending[0])
+        pending[0] = None
+
     for lp in P["layers"]:
         geo = lp["geo"]
         cur = ta
         for bp in lp["blocks"]:
             sh = bp["shift"]
             if sh == 0:
-                for i in range(len(ranks)):
-                    SW.run_swin_block(bp, geo, cur[i].own, tb[i].own, ws_, cdt, 0)
+                if pending[0] is None:
+                    for i in range(len(ranks)):
+                        SW.run_swin_block(bp, geo, cur[i].own, tb[i].own, ws_, cdt, 0)
+                else:  # rows [0, shift) of `cur` are still in flight: every window row but the first goes ahead
+                    for i in range(len(ranks)):
+                        if cur[i].rows > w8:
+                            SW.run_swin_block(bp, geo, cur[i].view(w8, cur[i].rows), tb[i].view(w8, tb[i].rows), ws_, cdt, 0)
+                    settle()
+                    for i in range(len(ranks)):
+                        SW.run_swin_block(bp, geo, cur[i].view(0, w8), tb[i].view(0, w8), ws_, cdt, 0)
             else:
+                settle()
                 # rows [sh, rows+sh) of the buffer = this strip of roll(x, -sh): own rows sh.. + the first sh rows of the strip below
-                comm.shift_up([c.view(0, sh) for c in cur], [c.view(c.rows, c.rows + sh) for c in cur], cyclic=True)
+                got = on_side(lambda: comm.shift_up([c.view(0, sh) for c in cur], [c.view(c.rows, c.rows + sh) for c in cur], cyclic=True))
+                for i, r in enumerate(ranks):  # interior window rows: own rows only, never the wrapped window row
+                    n = cur[i].rows
+                    if overlap and n > w8:
+                        SW.run_swin_block(bp, geo, cur[i].view(sh, n + sh - w8), tb[i].view(sh, n + sh - w8), ws_, cdt, sh, y_mode=L.Y_STRIP)
+                wait(got)
                 for i, r in enumerate(ranks):
                     y_mode = L.Y_STRIP_LAST if r == comm.world - 1 else L.Y_STRIP
-                    SW.run_swin_block(bp, geo, cur[i].view(sh, cur[i].rows + sh), tb[i].view(sh, tb[i].rows + sh), ws_, cdt, sh, y_mode=y_mode)
+                    n = cur[i].rows
+                    a0 = n + sh - w8 if overlap else sh  # without overlap: the whole rolled strip in one launch
+                    SW.run_swin_block(bp, geo, cur[i].view(a0, n + sh), tb[i].view(a0, n + sh), ws_, cdt, sh, y_mode=y_mode)
                 # roll back: the last sh rows of the rolled strip are the first sh rows of the strip below
-                comm.shift_down([t.view(t.rows, t.rows + sh) for t in tb], [t.view(0, sh) for t in tb], cyclic=True)
+                pending[0] = on_side(lambda: comm.shift_down([t.view(t.rows, t.rows + sh) for t in tb], [t.view(0, sh) for t in tb], cyclic=True))
             cur = tb
+        settle()
         if cur is ta:  # zero-depth RSTB: convolve a copy, `ta` stays the skip
             tc = strips("tc", Cp, torch.float32, bot_=bot)
             for i in range(len(ranks)):

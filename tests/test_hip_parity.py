@@ -715,3 +715,21 @@ def test_swinfir_bf16_keeps_the_fft_in_fp32_at_dft_sized_images():
     mse = float(((y - ref) ** 2).mean())
     psnr = 10 * np.log10(max(float(ref.abs().max()), 1.0) ** 2 / max(mse, 1e-20))
     assert float((y - ref).abs().max()) <= BF16_TOL * max(1.0, float(ref.abs().max())) and psnr >= BF16_PSNR_DB, (float((y - ref).abs().max()), psnr)
+
+
+def test_strips_full_size_2048_local_8_equal_the_unsharded_forward():
+    """BASELINE config 4 at its real size: default SwinIR x4 on ONE 2048 x 2048 LR image in 8 window-aligned row strips with per-layer halo
+    exchange (LocalStripComm: all strips in this process, the orchestration a DistStripComm rank runs; halo exchanges on the side
+    stream) must equal the unsharded forward bit for bit (bf16 path, the one-launch block kernel with y_mode strips)."""
+    from studiosr_amd.strips import LocalStripComm
+
+    torch.manual_seed(0)
+    m = S.SwinIR(scale=4).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(1, 3, 2048, 2048, device=DEV)
+    with torch.no_grad():
+        ref = m(x)
+        out = m.forward_strips(x, LocalStripComm(8))
+    assert out.shape == ref.shape == (1, 3, 8192, 8192)
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    del out, ref
+    torch.cuda.empty_cache()
