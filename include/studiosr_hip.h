@@ -131,11 +131,13 @@ typedef struct SrSwinBlock {
      * two constant-one pad channels (hi + lo bf16 split).  bf16 operands, fp32 stream / statistics / softmax; out may alias x. */
     const float* x;        /* [B,H,W,ldx] fp32 stream */
     float* out;
-    const void* wstream;   /* 48 * 12 * 64 * 8 bf16 */
+    const void* wstream;   /* 48 slots x 12 fragments x 64 lanes x 8 (bf16) or 16 (bf16x3) bf16 */
     const float* bias;     /* relative-position bias * log2(e) in fragment order [heads][qt][kt][lane][4] */
     int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift, Hp;
     float eps;
     int y_mode;            /* SR_Y_* */
+    int compute_dtype;     /* SR_BF16: bf16 operands (wstream 48 * 12 * 64 * 8 bf16); SR_BF16X3: split operands hi + lo (precision "fp32x3": fp32-class
+                            * accuracy, wstream 48 * 12 * 64 * 16 bf16 = per lane 8 hi | 8 lo, erf GELU, bias pre-scaled by log2(e) as for bf16) */
 } SrSwinBlock;
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);

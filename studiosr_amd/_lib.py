@@ -56,7 +56,7 @@ class SrSwinBlock(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("wstream", _vp), ("bias", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("Hp", _i),
-        ("eps", _f), ("y_mode", _i),
+        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
     ]
 
 

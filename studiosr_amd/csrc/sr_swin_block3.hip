@@ -67,11 +67,13 @@ struct SwinBlock3Dev {
 constexpr int NTOK = 64, WS = 8, NSLOT = 48;
 constexpr int PAD_D = 30;  // first pad feature of a head: v[:, 30] = 1 -> row 30 of O^T = softmax denominator
 constexpr int ONE_C = 180; // first pad channel of the stream: the LayerNorm images carry 1.0 in channels 180, 181
-constexpr int LDS_A = 24 * 64 * 16;         // LayerNorm image [24 k-groups][64 tokens] of 16-B cells
-constexpr int LDS_Q = 2 * 4 * 64 * 16;      // Q image [2 heads][4 d-groups][64 tokens]; the attention output O overwrites it atom by atom
-constexpr int LDS_K = 2 * 4 * 64 * 16;      // K image [2 heads][4 d-groups][64 keys]
-constexpr int LDS_V = 2 * 2 * 4 * 32 * 16;  // V^T image [2 heads][2 key steps][4 key groups][32 d]
-constexpr int LDS_RED = 64 * 4 * 2 * 4;     // LayerNorm partial sums [64 tokens][4 waves][2]
+// LDS image sizes in 16-B (bf16) / 32-B (bf3 = hi | lo split operands, compute type SR_BF16X3) cells
+constexpr int CELLS_A = 24 * 64;          // LayerNorm image [24 k-groups][64 tokens]
+constexpr int CELLS_Q = 2 * 4 * 64;       // Q image [2 heads][4 d-groups][64 tokens]; the attention output O overwrites it atom by atom
+constexpr int CELLS_K = 2 * 4 * 64;       // K image [2 heads][4 d-groups][64 keys]
+constexpr int CELLS_V = 2 * 2 * 4 * 32;   // V^T image [2 heads][2 key steps][4 key groups][32 d]
+static_assert(CELLS_Q + CELLS_K + CELLS_V == CELLS_A, "the hidden-half image reuses the Q / K / V region");
+constexpr int LDS_RED = 64 * 4 * 2 * 4;   // LayerNorm partial sums [64 tokens][4 waves][2]
 // The fp32 window tile (x at kernel entry, the result at its end) passes through LDS as 64 token rows of 768 B at a stride of
 // XS = 784 B, laid over the image regions (all free at both moments): full rows travel between HBM and LDS with ADJACENT lanes on
 // ADJACENT addresses (the accumulator layout has adjacent lanes on different token rows: every such load / store cost the
@@ -79,28 +81,70 @@ constexpr int LDS_RED = 64 * 4 * 2 * 4;     // LayerNorm partial sums [64 tokens
 // and the 784-B stride makes the accumulator-layout ds_read_b128 / ds_write_b128 side conflict-free.
 constexpr int XS = 784;
 constexpr int LDS_X = 64 * XS;
-static_assert(LDS_X >= LDS_A + LDS_Q + LDS_K + LDS_V, "the x tile covers the image regions; the LayerNorm partials sit behind it");
-constexpr int LDS_TOTAL = LDS_X + LDS_RED;
-static_assert(LDS_Q + LDS_K + LDS_V == LDS_A, "the hidden-half image reuses the Q / K / V region");
-static_assert(3 * LDS_TOTAL <= 160 * 1024, "three workgroups per CU");
+template <typename T>
+struct Lds {
+    static constexpr int IMG = 2 * CELLS_A * (int)sizeof(Frag<T>);
+    static constexpr int RED_OFF = IMG > LDS_X ? IMG : LDS_X;  // the LayerNorm partials sit behind the images AND the x tile
+    static constexpr int TOTAL = RED_OFF + LDS_RED;
+};
+static_assert(3 * Lds<bf16>::TOTAL <= 160 * 1024, "bf16: three workgroups per CU");
+static_assert(Lds<bf3>::TOTAL <= 160 * 1024, "bf16x3: one workgroup per CU");
 
-SR_DEV Frag<bf16> pack2(const f32x4& lo, const f32x4& hi) {
-    Frag<bf16> f;
-    f.v[0] = (bf16)lo[0]; f.v[1] = (bf16)lo[1]; f.v[2] = (bf16)lo[2]; f.v[3] = (bf16)lo[3];
-    f.v[4] = (bf16)hi[0]; f.v[5] = (bf16)hi[1]; f.v[6] = (bf16)hi[2]; f.v[7] = (bf16)hi[3];
-    return f;
-}
 SR_DEV bf16x4 cvt4(const f32x4& v) {
     bf16x4 r;
     r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];
     return r;
 }
-SR_DEV void st_half(Frag<bf16>* cell, int half, const bf16x4& v) { *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + half * 8) = v; }
-
-// first MFMA of an accumulation chain: C is the inline constant 0 (no v_mov initialisation of the accumulator)
-SR_DEV void mma0(const Frag<bf16>& x, const Frag<bf16>& y, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, (f32x4)(0.0f), 0, 0, 0);
+SR_DEV f32x4 widen4(const bf16x4& v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+// 8 fp32 values (two accumulator quads) as one operand fragment
+template <typename T>
+SR_DEV Frag<T> pack2(const f32x4& lo, const f32x4& hi);
+template <>
+SR_DEV Frag<bf16> pack2<bf16>(const f32x4& lo, const f32x4& hi) {
+    Frag<bf16> f;
+    f.v[0] = (bf16)lo[0]; f.v[1] = (bf16)lo[1]; f.v[2] = (bf16)lo[2]; f.v[3] = (bf16)lo[3];
+    f.v[4] = (bf16)hi[0]; f.v[5] = (bf16)hi[1]; f.v[6] = (bf16)hi[2]; f.v[7] = (bf16)hi[3];
+    return f;
 }
+template <>
+SR_DEV Frag<bf3> pack2<bf3>(const f32x4& lo, const f32x4& hi) {  // x = h + l with h = bf16(x), l = bf16(x - h): 16 mantissa bits
+    Frag<bf3> f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16 h0 = (bf16)lo[j], h1 = (bf16)hi[j];
+        f.hi[j] = h0;
+        f.hi[4 + j] = h1;
+        f.lo[j] = (bf16)(lo[j] - (float)h0);
+        f.lo[4 + j] = (bf16)(hi[j] - (float)h1);
+    }
+    return f;
+}
+// 4 fp32 values into the 8-byte half `half` of an image cell
+SR_DEV void st_half(Frag<bf16>* cell, int half, const f32x4& v) { *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + half * 8) = cvt4(v); }
+SR_DEV void st_half(Frag<bf3>* cell, int half, const f32x4& v) {
+    const bf16x4 h = cvt4(v);
+    const bf16x4 l = cvt4(v - widen4(h));
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + half * 8) = h;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + 16 + half * 8) = l;
+}
+
+// D = X Y^T + C with C a separate register set (the first MFMA of a chain: C = 0 or a bias tile); sr_common.h mma() accumulates in place
+SR_DEV f32x4 mma_c(const Frag<bf16>& x, const Frag<bf16>& y, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, c, 0, 0, 0); }
+SR_DEV f32x4 mma_c(const Frag<bf3>& x, const Frag<bf3>& y, const f32x4& c) {  // small terms first, as mma(bf3)
+    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.lo, y.hi, c, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, y.lo, d, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, y.hi, d, 0, 0, 0);
+}
+// first MFMA of an accumulation chain: C is the inline constant 0 (no v_mov initialisation of the accumulator)
+template <typename T>
+SR_DEV void mma0(const Frag<T>& x, const Frag<T>& y, f32x4& c) { c = mma_c(x, y, (f32x4)(0.0f)); }
+
+template <typename T>
+SR_DEV float gelu_op(float x);
+template <>
+SR_DEV float gelu_op<bf16>(float x) { return gelu_bf16(x); }  // x * sigmoid form: 4.8e-4 below the bf16 rounding of its own output
+template <>
+SR_DEV float gelu_op<bf3>(float x) { return gelu_fast(x); }   // erf to 1.5e-7: the fp32-class path
 
 // Wave priority by phase: a workgroup in its attention passes outranks one in its MLP, so the three workgroups of a CU (which start
 // together) stay closer in progress and the last one does not finish alone (-2..3 % at B = 8 / 16; SR_EXP_PHPRIO=0 switches it off).
@@ -187,28 +231,32 @@ SR_DEV void dma_row48(const float* row, unsigned lds_dst, int lane) {
 // The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of RING slots in registers.
 // Buffer loads: the fragment's byte offset is a scalar (soffset), the lane part one shared VGPR -- no per-load 64-bit address arithmetic.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-SR_DEV Frag<bf16> buf_load_frag(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-    Frag<bf16> f;
-    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-    return f;
+SR_DEV void buf_load_frag(Frag<bf16>& f, __amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index) {
+    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, 0));
+}
+SR_DEV void buf_load_frag(Frag<bf3>& f, __amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index) {  // per lane 8 hi | 8 lo (32 B)
+    f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, frag_index * 2048, 0));
+    f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, frag_index * 2048 + 16, 0));
 }
 #ifndef SR_RING_DIST
 #define SR_RING_DIST 2
 #endif
+template <typename T>
 struct WStream {
     static constexpr int DIST = SR_RING_DIST, RING = DIST + 1;
-    Frag<bf16> r[RING][3];
+    static constexpr int LOADS_PER_SLOT = 3 * (int)sizeof(Frag<T>) / 16;  // buffer_load instructions per slot (vmcnt bookkeeping)
+    Frag<T> r[RING][3];
     __amdgpu_buffer_rsrc_t rsrc;
-    int wave_off;  // 3 w KiB (scalar)
+    int wave_frag;  // 3 w (scalar)
     SR_DEV void load(int s, int lane) {  // s is a compile-time constant at every call site (unrolled)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) r[s % RING][n] = buf_load_frag(rsrc, lane * 16, wave_off + (WSLOT(s) * 12 + n) * 1024);
+        for (int n = 0; n < 3; ++n) buf_load_frag(r[s % RING][n], rsrc, lane, wave_frag + WSLOT(s) * 12 + n);
     }
     // NST uniform steps starting at slot s0: loada(c, h, a) reads the two activation fragments (m-tiles 2h, 2h+1) of the stage's K-chunk c,
     // compute(c, h, b, a) issues their 6 MFMAs.  Half 1 of chunk c and half 0 of chunk c + 1 are read under the MFMAs before them.
     template <int NST, typename LoadA, typename Compute>
     SR_DEV void run(int s0, int lane, LoadA&& loada, Compute&& compute) {
-        Frag<bf16> a0[2], a1[2];
+        Frag<T> a0[2], a1[2];
         loada(0, 0, a0);
 #ifdef SR_EXP_PRIO
         __builtin_amdgcn_s_setprio(1);
@@ -232,15 +280,19 @@ struct WStream {
 };
 
 // Specialised for C = 180 (Cp = 192), heads = 6, hd = 30 (32), ws = 8, hidden 360 (384): SwinIR / SwinFIR default geometry.
-__global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv) {
+// T = bf16: bf16 operands (three workgroups per CU).  T = bf3 (compute type SR_BF16X3, precision "fp32x3"): every operand is a hi + lo
+// bf16 pair and every product hi*hi + hi*lo + lo*hi -- fp32-class accuracy on the bf16 matrix cores; images are 32-B cells (98 KiB:
+// one workgroup per CU), GELU is the erf form.
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_block3_kernel(SwinBlock3Dev dv) {
     const SrSwinBlock& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<bf16>* Aimg = reinterpret_cast<Frag<bf16>*>(smem);
-    Frag<bf16>* Qimg = Aimg + 24 * 64;
-    Frag<bf16>* Kimg = Qimg + 2 * 4 * 64;
-    Frag<bf16>* Vimg = Kimg + 2 * 4 * 64;
-    float* red = reinterpret_cast<float*>(smem + LDS_X);
-    Frag<bf16>* Himg = Qimg;  // [24][64] hidden half (MLP stage: Q / K / V are dead)
+    Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);
+    Frag<T>* Qimg = Aimg + CELLS_A;
+    Frag<T>* Kimg = Qimg + CELLS_Q;
+    Frag<T>* Vimg = Kimg + CELLS_K;
+    float* red = reinterpret_cast<float*>(smem + Lds<T>::RED_OFF);
+    Frag<T>* Himg = Qimg;  // [24][64] hidden half (MLP stage: Q / K / V are dead)
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane0 = threadIdx.x & 63;
@@ -280,14 +332,14 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    WStream ws;
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, NSLOT * 12 * 1024, 0x00020000);
-    ws.wave_off = w * 3 * 1024;
+    WStream<T> ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, NSLOT * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
+    ws.wave_frag = w * 3;
 #pragma unroll
-    for (int s0 = 0; s0 < WStream::DIST; ++s0) ws.load(s0, lane);
+    for (int s0 = 0; s0 < WStream<T>::DIST; ++s0) ws.load(s0, lane);
     const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, 6 * 16 * 64 * 16, 0x00020000);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * WStream::DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WStream<T>::LOADS_PER_SLOT * WStream<T>::DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
     BLOCK_SYNC();
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
 #pragma unroll
@@ -334,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
                     nv[0] = one_lane ? 1.0f : nv[0];
                     nv[1] = one_lane ? 1.0f : nv[1];
                 }
-                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, cvt4(nv));
+                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, nv);
             }
         }
     };
@@ -348,9 +400,9 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
     const bool masked = a.shift > 0 && (last_row || last_col);
     constexpr float NEG = -100.0f * 1.4426950408889634f;
 
-    auto loada_img = [&](const Frag<bf16>* img) {
-        return [&, img](int c, int h, Frag<bf16> (&av)[2]) {
-            const Frag<bf16>* arow = img + (c * 4 + ag) * NTOK + h * 32 + ar;
+    auto loada_img = [&](const Frag<T>* img) {
+        return [&, img](int c, int h, Frag<T> (&av)[2]) {
+            const Frag<T>* arow = img + (c * 4 + ag) * NTOK + h * 32 + ar;
             av[0] = arow[0];
             av[1] = arow[16];
         };
@@ -367,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
         {
             // -- QKV: q, k, v of (head 2p + hh, d-half) for all 64 tokens
             f32x4 acc[4][3];
-            ws.run<6>(8 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&av)[2]) {
+            ws.template run<6>(8 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     if (c == 0) {
@@ -393,14 +445,14 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
                 }
             }
             if (p > 0) BLOCK_SYNC();  // every wave is done with the previous pass's Q / K / V (attention) and O (proj)
-            Frag<bf16>* qb = Qimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;  // cell [d-group][token]: d = 16 half + 4 ag + r
-            Frag<bf16>* kb = Kimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;
-            Frag<bf16>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + 16 * half + ar;      // cell [step][key group ag][d]: keys {32 s + 4 ag + r} then {32 s + 16 + 4 ag + r}
+            Frag<T>* qb = Qimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;  // cell [d-group][token]: d = 16 half + 4 ag + r
+            Frag<T>* kb = Kimg + (hh * 4 + 2 * half + (ag >> 1)) * NTOK + ar;
+            Frag<T>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + 16 * half + ar;      // cell [step][key group ag][d]: keys {32 s + 4 ag + r} then {32 s + 16 + 4 ag + r}
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                st_half(qb + m * 16, ag & 1, cvt4(acc[m][0]));
-                st_half(kb + m * 16, ag & 1, cvt4(acc[m][1]));
-                st_half(vb + (m >> 1) * 4 * 32, m & 1, cvt4(acc[m][2]));
+                st_half(qb + m * 16, ag & 1, acc[m][0]);
+                st_half(kb + m * 16, ag & 1, acc[m][1]);
+                st_half(vb + (m >> 1) * 4 * 32, m & 1, acc[m][2]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -411,9 +463,9 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 
         // -- attention for the atom: S^T = K Q^T (+bias as the C operand), mask, softmax over keys (exp2), O^T = V^T P^T
         {
-            const Frag<bf16>* qrow = Qimg + (hh * 4 + ag) * NTOK + half * 32 + ar;
-            const Frag<bf16>* kb = Kimg + (hh * 4 + ag) * NTOK + ar;
-            Frag<bf16> qf[2], kf[4];
+            const Frag<T>* qrow = Qimg + (hh * 4 + ag) * NTOK + half * 32 + ar;
+            const Frag<T>* kb = Kimg + (hh * 4 + ag) * NTOK + ar;
+            Frag<T> qf[2], kf[4];
             qf[0] = qrow[0];
             qf[1] = qrow[16];
 #pragma unroll
@@ -421,10 +473,10 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt].v, qf[qt].v, bt[kt - qt + 1], 0, 0, 0);
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = mma_c(kf[kt], qf[qt], bt[kt - qt + 1]);
         }
-        const Frag<bf16>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + ar;
-        Frag<bf16> vf[2][2];  // [d tile][key step]
+        const Frag<T>* vb = Vimg + (hh * 2 * 4 + ag) * 32 + ar;
+        Frag<T> vf[2][2];  // [d tile][key step]
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -468,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 #endif
                 }
 #endif
-            const Frag<bf16> p0 = pack2(s[qt][0], s[qt][1]), p1 = pack2(s[qt][2], s[qt][3]);
+            const Frag<T> p0 = pack2<T>(s[qt][0], s[qt][1]), p1 = pack2<T>(s[qt][2], s[qt][3]);
             f32x4 o0, o1;
             mma0(vf[0][0], p0, o0);
             mma(vf[0][1], p1, o0);
@@ -478,9 +530,9 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
             const float inv_sum = __builtin_amdgcn_rcpf(bcast_row3(o1[PAD_D & 3]));
             o0 *= inv_sum;
             o1 *= inv_sum;  // feature 30 becomes 1: it multiplies the proj bias rows; feature 31 is 0
-            Frag<bf16>* ob = Qimg + (hh * 4 + (ag >> 1)) * NTOK + half * 32 + qt * 16 + ar;  // over this atom's own q cells
-            st_half(ob, ag & 1, cvt4(o0));
-            st_half(ob + 2 * NTOK, ag & 1, cvt4(o1));
+            Frag<T>* ob = Qimg + (hh * 4 + (ag >> 1)) * NTOK + half * 32 + qt * 16 + ar;  // over this atom's own q cells
+            st_half(ob, ag & 1, o0);
+            st_half(ob + 2 * NTOK, ag & 1, o1);
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(6 + 8 * p);
@@ -488,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
         STAMP(7 + 8 * p);
 
         // -- proj partial: x1 columns [48 w, 48 w + 48) += O_chunk @ Wproj[:, 64 p .. 64 p + 64)
-        ws.run<2>(8 * p + 6, lane, loada_img(Qimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&ov)[2]) {
+        ws.template run<2>(8 * p + 6, lane, loada_img(Qimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -509,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
     for (int hf = 0; hf < 2; ++hf) {
         relane();
         f32x4 acc[4][3];
-        ws.run<6>(24 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&av)[2]) {
+        ws.template run<6>(24 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -535,16 +587,25 @@ __global__ __launch_bounds__(256, 3) void sr_swin_block3_kernel(SwinBlock3Dev dv
 #elif defined(SR_EXP_GELUPOLY)
                 for (int r = 0; r < 4; ++r) g[r] = gelu_poly(acc[m][n][r]);
 #else
-                for (int r = 0; r < 4; ++r) g[r] = gelu_bf16(acc[m][n][r]);
+                for (int r = 0; r < 4; ++r) g[r] = gelu_op<T>(acc[m][n][r]);
 #endif
-                st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, cvt4(g));
+                if constexpr (sizeof(Frag<T>) == 32) {
+                    // split-operand path: hidden pad columns 360, 361 (wave 3, n = 1, ag = 2, r = 0, 1 of the second half) are the constant one that
+                    // the fc2 bias rows multiply (the bf16 path wires gelu(1) there through the weights instead)
+                    if (hf == 1 && n == 1) {
+                        const bool one_h = (w == 3) && (ag == 2);
+                        g[0] = one_h ? 1.0f : g[0];
+                        g[1] = one_h ? 1.0f : g[1];
+                    }
+                }
+                st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, g);
             }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(31 + 5 * hf);
         BLOCK_SYNC();
         STAMP(32 + 5 * hf);
         // fc2 partial on top of x1: K = the 192 hidden columns of this half
-        ws.run<6>(30 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<bf16> (&b)[3], Frag<bf16> (&hv)[2]) {
+        ws.template run<6>(30 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&hv)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -591,13 +652,26 @@ extern "C" int sr_debug_sw3_wgtrace(unsigned long long* host, int n) {
 #endif
 
 extern "C" int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
-    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8 && Hp == 384) ? 1 : 0;
+    return ((compute_dtype == SR_BF16 || compute_dtype == SR_BF16X3) && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8 && Hp == 384) ? 1 : 0;
+}
+
+template <typename T>
+static int launch_swin_block3(const SwinBlock3Dev& dv, int nblocks, hipStream_t st) {
+    static SrDeviceOnce attr_once;  // one flag per instantiation, one bit per device
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_block3_kernel<T>, Lds<T>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_block: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(sr_swin_block3_kernel<T>, dim3(nblocks), dim3(256), Lds<T>::TOTAL, st, dv);
+    SR_CHECK_LAUNCH("sr_swin_block");
+    return SR_OK;
 }
 
 extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
     SR_REQUIRE(p && p->x && p->out && p->wstream && p->bias, "sr_swin_block: null pointer");
     const SrSwinBlock& a = *p;
-    SR_REQUIRE(sr_swin_block_supported(a.C, a.Cp, a.heads, a.hd_p, a.ws, a.Hp, SR_BF16), "sr_swin_block: unsupported geometry (use sr_swin_attn_fused / sr_gemm)");
+    const int cdt = a.compute_dtype;  // SR_BF16 or SR_BF16X3
+    SR_REQUIRE(sr_swin_block_supported(a.C, a.Cp, a.heads, a.hd_p, a.ws, a.Hp, cdt), "sr_swin_block: unsupported geometry / compute type (use sr_swin_attn_fused / sr_gemm)");
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_block: bad geometry");
@@ -607,12 +681,6 @@ extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
     dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
-    static SrDeviceOnce attr_once;
-    {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_block3_kernel, LDS_TOTAL); });
-        SR_REQUIRE(e == hipSuccess, "sr_swin_block: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(sr_swin_block3_kernel, dim3(a.B * nwx * nwy), dim3(256), LDS_TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
-    SR_CHECK_LAUNCH("sr_swin_block");
-    return SR_OK;
+    if (cdt == SR_BF16X3) return launch_swin_block3<bf3>(dv, a.B * nwx * nwy, reinterpret_cast<hipStream_t>(stream));
+    return launch_swin_block3<bf16>(dv, a.B * nwx * nwy, reinterpret_cast<hipStream_t>(stream));
 }

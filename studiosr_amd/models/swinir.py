@@ -145,15 +145,19 @@ def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[
 
 
 def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
-    """The single weight stream of sr_swin_block (ABI v5) for one SwinTransformerBlock, when the kernel covers the geometry."""
-    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws == 8 and geo.hidden == 360):
+    """The single weight stream of sr_swin_block (ABI v5) for one SwinTransformerBlock, when the kernel covers the geometry: bf16 operands
+    for the bf16 path, split operands (hi | lo) for precision "fp32x3"; the exact-fp32 parity path has no fused block kernel."""
+    from ..runtime import X3_KEY
+
+    x3 = dt == X3_KEY
+    if not ((x3 or fold_ln(dt)) and geo.C == 180 and geo.heads == 6 and geo.ws == 8 and geo.hidden == 360):
         return {}
     attn, mlp = blk.attn, blk.mlp
     qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, blk.norm1.weight, blk.norm1.bias)
     w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, blk.norm2.weight, blk.norm2.bias)
-    stream = packing.pack_swin_block_stream(qw, qb, attn.proj.weight, attn.proj.bias, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden)
+    stream = packing.pack_swin_block_stream(qw, qb, attn.proj.weight, attn.proj.bias, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden, x3=x3)
     bias = packing.gather_bias(attn.relative_position_bias_table, attn.relative_position_index, geo.ntok, geo.ntok)
-    return dict(stream=stream, bias_frag_l2=packing.bias_fragments(bias * packing.LOG2E))
+    return dict(stream=stream, bias_frag_l2=packing.bias_fragments(bias * packing.LOG2E), stream_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
 
 
 def swin_block_kernel_choice() -> str:
@@ -166,10 +170,14 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
     (attention half + MLP half on the same window), otherwise attention and MLP as separate launches."""
     B, H, W, Cp = t_in.shape
     sdt = sr_dtype(cdt)
-    if "stream" in p and swin_block_kernel_choice() == "v3" and ops.swin_block_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, sdt):
+    from ..runtime import x3_active
+
+    # the stream was packed for bf16 (cdt bf16) or for split operands (cdt fp32 inside a precision="fp32x3" forward)
+    want = L.SR_BF16 if cdt == torch.bfloat16 else (L.SR_BF16X3 if x3_active() else -1)
+    if p.get("stream_dtype", -2) == want and swin_block_kernel_choice() == "v3" and ops.swin_block_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, want):
         ops.swin_block(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wstream=p["stream"].data_ptr(), bias=p["bias_frag_l2"].data_ptr(), B=B, H=H, W=W, C=geo.C,
-            Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
+            Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode, compute_dtype=want,
         )
         return
     if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):

@@ -173,8 +173,15 @@ def _tile_fragment(t: Tensor) -> Tensor:
     return t.reshape(16, 4, 8).permute(1, 0, 2).reshape(64, 8)
 
 
+def _split16(v: Tensor):
+    """v (fp32) -> (h, v - h) with h the value's leading 16 mantissa bits (what a split-operand hi | lo fragment can hold)."""
+    hi = v.to(torch.bfloat16).to(torch.float32)
+    h = hi + (v - hi).to(torch.bfloat16).to(torch.float32)
+    return h, v - h
+
+
 def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tensor, proj_b: Optional[Tensor], fc1_w: Tensor, fc1_b: Optional[Tensor],
-                           fc2_w: Tensor, fc2_b: Optional[Tensor], C: int, heads: int, hidden: int) -> Tensor:
+                           fc2_w: Tensor, fc2_b: Optional[Tensor], C: int, heads: int, hidden: int, x3: bool = False) -> Tensor:
     """The ONE weight stream of a SwinTransformerBlock for sr_swin_block (include/studiosr_hip.h SrSwinBlock; swinir.py:78-105,146-174,
     common.py:173-195): 48 slots x 12 fragments x [64 lanes][8] bf16 in the order the kernel consumes them --
     per pass p (heads 2p, 2p+1): 6 QKV slots (K-chunks), 2 proj slots; then 6 fc1 + 6 fc2 slots per hidden half.
@@ -182,7 +189,9 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
     (packing.fold_layernorm).  Folded in here: attention scale and log2(e) into the q rows; every bias as a hi + lo bf16 pair in the
     columns of the constant-one channels (LayerNorm image channels C, C+1; O feature hd of heads 0 / 1; hidden columns `hidden`, +1);
     v's pad feature hd := 1 (softmax denominator); the v bias into the proj bias (softmax rows sum to one); the k bias is dropped
-    (it shifts every logit of a row equally)."""
+    (it shifts every logit of a row equally).
+    x3 = True: the split-operand stream of compute type SR_BF16X3 (precision "fp32x3"): every element as hi | lo (per lane 8 hi then 8 lo),
+    the two bias channels carry the bias's leading 16 bits and the rest, and the hidden pad columns are set to 1 by the kernel itself."""
     assert C == 180 and heads == 6 and hidden == 360, "sr_swin_block geometry"
     hd, hdp, Cp, Hp = C // heads, 32, 192, 384
     dev = qkv_w.device
@@ -199,7 +208,8 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
     M_qkv = torch.zeros(3, heads, hdp, Cp, dtype=f32, device=dev)
     M_qkv[:, :, :hd, :C] = qkv_w.reshape(3, heads, hd, C)
     M_qkv[0] *= qs
-    bq_hi, bq_lo = _bf16_hi_lo(qkv_b[:C].reshape(heads, hd) * qs)
+    split = _split16 if x3 else _bf16_hi_lo
+    bq_hi, bq_lo = split(qkv_b[:C].reshape(heads, hd) * qs)
     M_qkv[0, :, :hd, C] = bq_hi
     M_qkv[0, :, :hd, C + 1] = bq_lo
     M_qkv[2, :, hd, C] = 1.0  # v[:, hd] = 1: row hd of O^T is the softmax denominator
@@ -207,23 +217,26 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
     bpf = proj_b + proj_w @ qkv_b[2 * C:]  # proj(o + b_v) = proj(o) + W_proj b_v
     M_proj = torch.zeros(Cp, heads, hdp, dtype=f32, device=dev)
     M_proj[:C, :, :hd] = proj_w.reshape(C, heads, hd)
-    bp_hi, bp_lo = _bf16_hi_lo(bpf)
+    bp_hi, bp_lo = split(bpf)
     M_proj[:C, 0, hd] = bp_hi  # O[:, head, hd] = 1 after the softmax normalisation
     M_proj[:C, 1, hd] = bp_lo
 
     M_fc1 = torch.zeros(Hp, Cp, dtype=f32, device=dev)
     M_fc1[:hidden, :C] = fc1_w
-    b1_hi, b1_lo = _bf16_hi_lo(fc1_b)
+    b1_hi, b1_lo = split(fc1_b)
     M_fc1[:hidden, C] = b1_hi
     M_fc1[:hidden, C + 1] = b1_lo
-    v0 = 1.0
-    c0 = gelu_bf16_value(v0)  # hidden columns `hidden`, `hidden`+1 hold the constant c0 = gelu(v0)
-    M_fc1[hidden, C] = v0
-    M_fc1[hidden + 1, C] = v0
+    if x3:
+        c0 = 1.0  # the split-operand kernel writes 1.0 into hidden columns `hidden`, `hidden`+1 itself
+    else:
+        v0 = 1.0
+        c0 = gelu_bf16_value(v0)  # hidden columns `hidden`, `hidden`+1 hold the constant c0 = gelu(v0)
+        M_fc1[hidden, C] = v0
+        M_fc1[hidden + 1, C] = v0
 
     M_fc2 = torch.zeros(Cp, Hp, dtype=f32, device=dev)
     M_fc2[:C, :hidden] = fc2_w
-    b2_hi, b2_lo = _bf16_hi_lo(fc2_b / c0)
+    b2_hi, b2_lo = split(fc2_b / c0)
     M_fc2[:C, hidden] = b2_hi
     M_fc2[:C, hidden + 1] = b2_lo
 
@@ -239,4 +252,8 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
     mlp[:, :6] = M_fc1.reshape(2, 4, 3, 16, 6, 4, 8).permute(0, 4, 1, 2, 5, 3, 6).reshape(2, 6, 12, 64, 8)
     # fc2: M_fc2[ch = 48 w + 16 n + i, k = 192 hf + 32 c + 8 g + j] -> mlp[hf, 6 + c, 3 w + n, 16 g + i, j]
     mlp[:, 6:] = M_fc2.reshape(4, 3, 16, 2, 6, 4, 8).permute(3, 4, 0, 1, 5, 2, 6).reshape(2, 6, 12, 64, 8)
+    if x3:
+        hi = out.to(torch.bfloat16)
+        lo = (out - hi.to(f32)).to(torch.bfloat16)
+        return torch.cat([hi, lo], dim=-1).reshape(-1).contiguous()  # [slot][fragment][lane][8 hi | 8 lo]
     return out.to(torch.bfloat16).reshape(-1).contiguous()

@@ -733,3 +733,27 @@ def test_strips_full_size_2048_local_8_equal_the_unsharded_forward():
     assert torch.equal(out, ref), float((out - ref).abs().max())
     del out, ref
     torch.cuda.empty_cache()
+
+
+def test_inference_under_auto_runs_the_split_operand_path():
+    """Model.inference with precision 'auto' (outside autocast) = the reference-precision fast path 'fp32x3' -- for SwinIR the fused block
+    kernel in its split-operand instantiation -- and stays within one LSB of the exact-fp32 mode on a handful of pixels at most."""
+    torch.manual_seed(0)
+    m = S.SwinIR(scale=4, depths=[2, 2], num_heads=[6, 6]).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    img = np.random.default_rng(0).integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+    y_auto = m.set_precision("auto").inference(img)
+    assert m.precision == "auto"  # restored
+    y_x3 = m.set_precision("fp32x3").inference(img)
+    y_32 = m.set_precision("fp32").inference(img)
+    assert np.array_equal(y_auto, y_x3)
+    d = np.abs(y_auto.astype(int) - y_32.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
+    # and the float forward of the split-operand block kernel against the exact path
+    x = torch.rand(2, 3, 40, 56, device=DEV)
+    with torch.no_grad():
+        e = float((m.set_precision("fp32x3")(x) - m.set_precision("fp32")(x)).abs().max())
+    assert e <= 2e-5, e
