@@ -12,7 +12,7 @@ for f in files:
         name = r["Kernel_Name"]
         if "sr_" not in name:
             continue
-        key = (name.split("sr_")[1][:40], int(r["Grid_Size"]) // int(r["Workgroup_Size"]) if "Grid_Size" in r else 0)
+        key = (name.split("sr_")[-1 if "sr_conv_impl" in name else 1][:40], int(r["Grid_Size"]) // int(r["Workgroup_Size"]) if "Grid_Size" in r else 0)
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     print(k)

@@ -13,7 +13,7 @@ for f in files:
         name = r["Kernel_Name"]
         if "sr_" not in name:
             continue
-        short = name.split("sr_")[1][:44]
+        short = name.split("sr_")[-1 if "sr_conv_impl" in name else 1][:44]  # sr_conv_impl::sr_conv3x3_kernel<...> -> conv3x3_kernel<...>
         acc[(short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(acc):
     v = sorted(acc[k])
