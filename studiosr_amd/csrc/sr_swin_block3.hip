@@ -167,6 +167,10 @@ SR_DEV float gelu_op<bf3>(float x) { return gelu_fast(x); }   // erf to 1.5e-7: 
 #endif
 #ifdef SR_EXP_NOBAR
 #define BLOCK_SYNC() __builtin_amdgcn_sched_barrier(0)
+#elif defined(SR_EXP_RAWBAR)
+// experiment: barrier that waits for LDS operations only.  Measured +-0 against __syncthreads(): hipcc already emits a bare s_barrier here
+// (its fence only waits for vector-memory operations when an LDS-DMA it knows of is pending; the weight ring survives the barrier)
+#define BLOCK_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #else
 #define BLOCK_SYNC() __syncthreads()
 #endif
