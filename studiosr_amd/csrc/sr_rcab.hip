@@ -26,6 +26,7 @@ constexpr int TO = 14;             // output tile edge
 constexpr int TI = 16;             // intermediate tile edge (= one MFMA row tile)
 constexpr int TIN = 18;            // input halo edge
 constexpr int IN_ROWS = 328;       // 18 * 18 = 324 halo pixels, padded to a multiple of 8
+constexpr int IN_RS = IN_ROWS + 1;  // row stride of the input image in cells: odd, so that the staging writes of one pixel's 8 K-groups (8 adjacent lanes) hit 8 bank groups
 constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 1 margin cell, padded to a multiple of 8
 constexpr int RRING = 3;
 
@@ -35,7 +36,7 @@ template <typename TIn, typename TOut, bool GATED>
 __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [RKG][IN_ROWS]
-    Frag<bf16>* Amid = Ain + RKG * IN_ROWS;                   // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
+    Frag<bf16>* Amid = Ain + RKG * IN_RS;                     // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -58,9 +59,11 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
         for (int n = 0; n < 2; ++n) br[s][n] = W1[((size_t)n * RKCT + s) * 64];
 
     float gk[8];  // gated input: this lane's 8 channel gates
-    // ---- stage the input halo (8 pixels x 8 K-groups per wave instruction: full 256-byte pixel rows), all loads of 3 passes in flight
+    // ---- stage the input halo: 8 pixels x 8 K-groups per wave instruction with the K-GROUP on the fast lane axis (the 8 lanes of a pixel read
+    //      its 128 / 256 contiguous bytes; pixel-fastest lanes cost the vector-memory path four cache-line accesses per quad of lanes), all loads
+    //      of 3 passes in flight
     {
-        const int r8 = lane & 7, kq = lane >> 3;
+        const int kq = lane & 7, r8 = lane >> 3;
         constexpr int NPASS = 3;
         if constexpr (GATED) {
             // x_eff = x + gate * gate_y (fp32, one fma per element as in sr_channel_attention); the tile interior goes back to HBM as this
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
                         store4(c.x_out + off[u], f32x4{e[0], e[1], e[2], e[3]});
                         store4(c.x_out + off[u] + 4, f32x4{e[4], e[5], e[6], e[7]});
                     }
-                    if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], frag_from8(e));
+                    if (p < IN_ROWS) Ain[kq * IN_RS + p] = frag_keep_if(valid[u], frag_from8(e));
                 }
             };
             issue(wave * 8);
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
                 }
                 __syncthreads();
         #pragma unroll
-                for (int i = 0; i < 8; ++i) gk[i] = gate[(lane >> 3) * 8 + i];
+                for (int i = 0; i < 8; ++i) gk[i] = gate[(lane & 7) * 8 + i];
             }
             commit(wave * 8);
             issue(wave * 8 + 32 * GP);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 #pragma unroll
                 for (int u = 0; u < NPASS; ++u) {
                     const int p = pb + u * 32 + r8;
-                    if (p < IN_ROWS) Ain[kq * IN_ROWS + p] = frag_keep_if(valid[u], f[u]);
+                    if (p < IN_ROWS) Ain[kq * IN_RS + p] = frag_keep_if(valid[u], f[u]);
                 }
             }
         }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
             acc[m][0] = (f32x4)(0.0f);
             acc[m][1] = (f32x4)(0.0f);
         }
-        const Frag<bf16>* abase0 = Ain + (wm * 8) * TIN + ar + ag * IN_ROWS;
+        const Frag<bf16>* abase0 = Ain + (wm * 8) * TIN + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < RKCT; ++tt) {
             const int tap = tt / RKC, kc = tt - tap * RKC;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W2[((size_t)n * RKCT + tt + RRING - 1 - RKCT) * 64];
             }
-            const Frag<bf16>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_ROWS;
+            const Frag<bf16>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_RS;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const Frag<bf16> a = arow[m * TIN];
@@ -279,6 +282,12 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
         const bool xin_tile = ar >= 1 && ar <= TO && gx < c.W;
         f32x4 pool[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
         TOut* y = reinterpret_cast<TOut*>(c.y);
+        // Coalesced store: one row of 16 pixels x this wave's 32 channels at a time through a wave-private fp32 tile in the (dead) input image:
+        // accumulator layout in (pixel on the lane axis), 16-byte pieces out with adjacent lanes on adjacent addresses of ONE pixel.
+        constexpr int S = 2 * 64 + 16;                          // bytes per pixel row of the private tile
+        constexpr int NV = 16 / (int)sizeof(TOut);              // channels per 16-byte piece
+        constexpr int PP = 32 / NV, NI = 16 * PP / 64;          // pieces per pixel, store instructions per row
+        char* priv = smem + wave * (16 * S);
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             const int gy = y0 + wm * 7 + m;
@@ -286,9 +295,26 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
-                if (ok) {
-                    pool[n] += v;
-                    store4(y + ((size_t)(b * c.H + gy) * c.W + gx) * RC + (wn * 2 + n) * 16 + ag * 4, v);
+                if (ok) pool[n] += v;
+                *reinterpret_cast<f32x4*>(priv + ar * S + (n * 16 + ag * 4) * 4) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int idx = k * 64 + lane, px = idx / PP, pc = idx - px * PP;
+                const int gxp = x0 - 1 + px;
+                const float* src = reinterpret_cast<const float*>(priv + px * S) + pc * NV;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+                f32x4 hi = (f32x4)(0.0f);
+                if constexpr (sizeof(TOut) == 2) hi = *reinterpret_cast<const f32x4*>(src + 4);
+                if (px >= 1 && px <= TO && gxp < c.W && gy < c.H) {
+                    TOut* dst = y + ((size_t)(b * c.H + gy) * c.W + gxp) * RC + wn * 32 + pc * NV;
+                    if constexpr (sizeof(TOut) == 2) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (bf16)lo[q], o[4 + q] = (bf16)hi[q];
+                        *reinterpret_cast<bf16x8*>(dst) = o;
+                    } else
+                        store4(dst, lo);
                 }
             }
         }
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
 
 template <typename TIn, typename TOut, bool GATED>
 int launch_rcab(const SrRcab& c, hipStream_t st) {
-    constexpr int lds = (RKG * IN_ROWS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>) + (GATED ? GATE_SCRATCH : 0);
+    constexpr int lds = (RKG * IN_RS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>) + (GATED ? GATE_SCRATCH : 0);
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TIn, TOut, GATED>, lds); });
