@@ -23,7 +23,10 @@ constexpr int BH = BT + 2;              // halo width
 
 // TH = tile height (rows = MFMA row tiles per wave): 16, or 12 where that turns a half-empty second residency round
 // into one full round (72 x 72 images: 8 x 6 x 5 = 240 workgroups of 12 rows instead of 200 of 16)
-template <typename TIn, int TH, int NW, int KC, int PH>
+// PIPE: the LDS image holds ALL input channels and is staged in PH channel phases that are software-pipelined with the MFMAs: the global
+// loads of phase p + 1 are in flight (in registers) while phase p's nine taps run, and are converted / written to LDS afterwards -- the
+// one-workgroup-per-CU kernel no longer fetches its whole halo before the first MFMA.
+template <typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
 __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     constexpr int HH = TH + 2;                       // halo height
     constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
@@ -31,8 +34,11 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     constexpr int HALF = TH / 2;                     // row tiles per activation-fragment buffer
     static_assert(TH % 2 == 0, "two half chunks");
     constexpr int KCP = KC / PH;                   // 32-channel chunks per phase
-    constexpr int RING = (KCP % 3 == 0) ? 3 : (KCP % 4 == 0 ? 4 : 2);  // divides KCP: ring slots are compile-time inside the tap loop
-    static_assert(KC % PH == 0 && KCP % RING == 0, "phase / ring geometry");
+    // ring slots are compile-time: the ring size divides KCP (run-time tap loop), or -- PIPE -- divides 9 * KCP with the tap loop unrolled.
+    // PIPE needs the DEEP ring: vector loads return in order, so a weight fragment issued after the next phase's halo loads (HBM latency)
+    // cannot be consumed before they land; five chunks of look-ahead (2.9 k MFMA cycles) issued BEFORE them cover that latency.
+    constexpr int RING = PIPE ? 6 : ((KCP % 3 == 0) ? 3 : (KCP % 4 == 0 ? 4 : 2));
+    static_assert(KC % PH == 0 && (PIPE ? (9 * KCP) % RING == 0 : KCP % RING == 0), "phase / ring geometry");
     constexpr int KGP = KCP * 4;                   // 8-channel groups per phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<bf16>* As = reinterpret_cast<Frag<bf16>*>(smem);  // [KGP][BROWS]
@@ -70,7 +76,59 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         }
     }
 
+    // PIPE staging: one phase = KGP K-groups of every halo pixel; 8 pixels x 8 K-groups per wave instruction, all BROWS / 32 pixel groups of a
+    // wave issued at once and kept in registers (raw input type) until commit() converts and writes them.
+    constexpr int NPG = (BROWS + 31) / 32;  // pixel groups per wave
+    struct Raw {
+        f32x4 lo, hi;  // 8 fp32 channels (fp32 input) or 8 bf16 in `lo` (bf16 input)
+    };
+    Raw raw[PIPE ? NPG : 1];
+    auto halo_pixel = [&](int p, bool& valid) -> size_t {
+        const int py = p / BH, px = p - py * BH;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        valid = p < HH * BH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+        return ((size_t)(b * c.H + (valid ? gy : 0)) * c.W + (valid ? gx : 0)) * c.Cin_p;
+    };
+    auto issue = [&](int ph) {
+        static_assert(!PIPE || KGP == 8, "PIPE stages 8 K-groups (64 channels) per phase");
+        const int kq = lane & 7, r8 = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < (PIPE ? NPG : 0); ++j) {
+            bool valid;
+            const TIn* src = xin + halo_pixel(wave * 8 + j * 32 + r8, valid) + (ph * KGP + kq) * 8;
+            if constexpr (sizeof(TIn) == 4) {
+                raw[j].lo = *reinterpret_cast<const f32x4*>(src);
+                raw[j].hi = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + 4);
+            } else {
+                raw[j].lo = *reinterpret_cast<const f32x4*>(src);  // 8 bf16 = 16 B
+            }
+        }
+    };
+    auto commit = [&](int ph) {
+        const int kq = lane & 7, r8 = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < (PIPE ? NPG : 0); ++j) {
+            const int p = wave * 8 + j * 32 + r8;
+            bool valid;
+            (void)halo_pixel(p, valid);
+            Frag<bf16> f;
+            if constexpr (sizeof(TIn) == 4) {
+                f.v[0] = (bf16)raw[j].lo[0]; f.v[1] = (bf16)raw[j].lo[1]; f.v[2] = (bf16)raw[j].lo[2]; f.v[3] = (bf16)raw[j].lo[3];
+                f.v[4] = (bf16)raw[j].hi[0]; f.v[5] = (bf16)raw[j].hi[1]; f.v[6] = (bf16)raw[j].hi[2]; f.v[7] = (bf16)raw[j].hi[3];
+            } else {
+                f.v = __builtin_bit_cast(bf16x8, raw[j].lo);
+            }
+            if (p < BROWS) As[(ph * KGP + kq) * BRS + p] = frag_keep_if(valid, f);
+        }
+    };
+    if constexpr (PIPE) {
+        issue(0);
+        commit(0);
+        __syncthreads();
+    }
+
     for (int ph = 0; ph < PH; ++ph) {
+        if constexpr (!PIPE) {
         if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
         // ---- stage channels [ph * KGP * 8, +KGP * 8) of the halo tile: 8 pixels x 8 K-groups per wave instruction
         {
@@ -103,9 +161,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             }
         }
         __syncthreads();
+        }
 
         // ---- 9 taps x KCP chunks of this phase; weight chunk index in the packed order = tap * KC + ph * KCP + kc
-        const Frag<bf16>* abase0 = As + ar + ag * BRS;
+        const Frag<bf16>* abase0 = As + ar + (ag + (PIPE ? ph * KGP : 0)) * BRS;
         Frag<bf16> br[RING][NW];
         auto wload = [&](int slot, int tap, int kc) {  // slot is compile-time at every call site
             int chunk = tap * KC + ph * KCP + kc;
@@ -114,11 +173,49 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
 #pragma unroll
             for (int n = 0; n < NW; ++n) br[slot][n] = Bp[((size_t)n * KCT + chunk) * 64];
         };
+        auto wload_lin = [&](int slot, int t) {  // PIPE: chunk t = tap * KCP + kc of this phase (t >= 9 * KCP: harmless re-load of the last one)
+            const int tt = t < 9 * KCP ? t : 9 * KCP - 1;
+            const int chunk = (tt / KCP) * KC + ph * KCP + tt % KCP;
 #pragma unroll
-        for (int s = 0; s < RING - 1; ++s) wload(s, 0, s);
+            for (int n = 0; n < NW; ++n) br[slot][n] = Bp[((size_t)n * KCT + chunk) * 64];
+        };
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) wload_lin(s, s);
+            if (ph + 1 < PH) issue(ph + 1);  // the next phase's halo channels: in flight (in registers) during this phase's MFMAs
+        } else {
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) wload(s, 0, s);
+        }
         Frag<bf16> af[2][HALF];
 #pragma unroll
         for (int m = 0; m < HALF; ++m) af[0][m] = abase0[m * BH];
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int t = 0; t < 9 * KCP; ++t) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int tap = t / KCP, kc = t % KCP;
+                const Frag<bf16>* abase = abase0 + (tap / 3) * BH + (tap % 3);
+                const int tn = t + 1 < 9 * KCP ? t + 1 : t;
+                const Frag<bf16>* nb = abase0 + ((tn / KCP) / 3) * BH + ((tn / KCP) % 3) + (tn % KCP) * 4 * BRS;
+                wload_lin((t + RING - 1) % RING, t + RING - 1);
+#pragma unroll
+                for (int m = 0; m < HALF; ++m) af[1][m] = abase[(HALF + m) * BH + kc * 4 * BRS];
+#pragma unroll
+                for (int m = 0; m < HALF; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], af[0][m], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < HALF; ++m) af[0][m] = nb[m * BH];
+#pragma unroll
+                for (int m = 0; m < HALF; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) mma(br[t % RING][n], af[1][m], acc[HALF + m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const Frag<bf16>* abase = abase0 + ky * BH + kx;
@@ -147,6 +244,12 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
 #pragma unroll
                     for (int n = 0; n < NW; ++n) mma(br[kc % RING][n], af[1][m], acc[HALF + m][n]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (PIPE) {
+            if (ph + 1 < PH) {
+                commit(ph + 1);   // the next phase's channels have been in flight under the MFMAs above
+                __syncthreads();  // ... and are now visible to every wave (no WAR hazard: each phase has its own K-group rows)
             }
         }
     }
@@ -226,18 +329,18 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     });
 }
 
-template <typename TIn, int TH, int NW, int KC, int PH>
+template <typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
 int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
-    constexpr int lds = (KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<bf16>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
+    constexpr int lds = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<bf16>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
     static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH, PIPE>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
-    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH, PIPE>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
 }
@@ -253,6 +356,9 @@ int big_tile_rows(const SrConv3x3& c) {
 
 template <typename TIn, int TH>
 int dispatch_big(const SrConv3x3& c, hipStream_t st) {
+    // 192 input channels: one phase.  (Three software-pipelined phases of 64 channels -- template parameter PIPE, K walk phase-major -- were
+    // measured and lost: 36.7 -> 40.6 us on the RSTB conv even with five chunks of weight look-ahead; vector loads return in order, so the
+    // next phase's halo fetch sits in front of every weight fragment issued after it, and all 240 workgroups fetch at the same time anyway.)
     if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<TIn, TH, 3, 6, 1>(c, st);
     if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<TIn, TH, 4, 8, 2>(c, st);
     return SR_EUNSUPPORTED;

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
         constexpr int RING = 3;
         constexpr int KCTS = 9 * KCS;
         // Walk order of the K-chunks.  256 input channels are summed as two phases of 128 (all nine taps of channels 0..127,
-        // then of 128..255) -- the order sr_conv_big.hip needs for its two-phase halo tile -- so that a pixel gets the SAME
-        // bits whichever of the two kernels the launch size selects; every other channel count is tap-major in both.
+        // then of 128..255) -- the order sr_conv_big.hip needs for its two-phase halo tile -- so that a
+        // pixel gets the SAME bits whichever of the two kernels the launch size selects; every other channel count is tap-major in both.
         constexpr int PHS = KCS == 8 ? 2 : 1, KCPH = KCS / PHS;
         auto tap_of = [](int t) { return (t % (9 * KCPH)) / KCPH; };
         auto kc_of = [](int t) { return (t / (9 * KCPH)) * KCPH + t % KCPH; };
