@@ -11,6 +11,7 @@ reference's state_dict layouts, so torch.optim and DistributedDataParallel see o
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -200,6 +201,53 @@ def _zeros_like(t: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------- nn.Linear / conv
+# --------------------------------------------------------------------------- independent backward work on a side stream
+_SIDE_STREAMS = {}
+_OVERLAP = os.environ.get("SR_WGRAD_STREAM", "0") == "1"  # off: measured 73.4 -> 81-84 ms per HAT step (two cross-stream event waits per layer cost more than the overlap buys)
+
+
+class _Side:
+    """`with _Side(t) as sd:` -- launches inside the block go to a per-device SIDE stream, ordered after everything enqueued on the current
+    (main) stream so far; `sd.join(*tensors)` after the block makes the main stream wait for them and hands the tensors they produced to
+    it.  A training step at the reference's per-rank batch (4 x 64 x 64: 16,384 tokens) is ~5,000 launches of 10-50 us that each fill a
+    fraction of the chip; the weight / bias / bias-table gradients of a layer do not feed its data gradient, so they can run beside it.
+    The join happens INSIDE the same backward: what autograd (AccumulateGrad, DDP's bucket hooks) sees is complete on the main stream.
+    EXPERIMENT, off by default (SR_WGRAD_STREAM=1 enables it): on one MI355X the HAT x4 step went from 73.4 to 81-84 ms -- every fork / join is a
+    pair of cross-stream event waits (a barrier packet each, ~5-10 us), ~600 per step, more than the overlapped kernels save."""
+
+    def __init__(self, t: Tensor, enable: bool = True) -> None:
+        self.on = _OVERLAP and enable and t.is_cuda and not torch.cuda.is_current_stream_capturing()
+        self.dev = t.device
+
+    def __enter__(self):
+        if self.on:
+            self.main = torch.cuda.current_stream(self.dev)
+            key = self.dev.index
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+            self.side = side
+            ready = torch.cuda.Event()
+            ready.record(self.main)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            side.wait_event(ready)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+            self.ctx.__exit__(*exc)
+
+    def join(self, *tensors) -> None:
+        if self.on:
+            self.main.wait_event(self.done)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)  # allocated under the side stream, consumed (and freed) on the main stream
+
+
 class _Linear(Fn):
     """y[M,N] = x[M,K] @ w[N,K]^T + b (swinir.py:69-71, common.py:184-195; 1x1 convs of the channel attention, common.py:161-167)."""
 
@@ -226,13 +274,15 @@ class _Linear(Fn):
             M = x.numel() // K
             N = w.shape[0]
             dx = dw = db = None
+            with _Side(dy, ctx.needs_input_grad[0]) as sd:  # weight / bias gradient beside the data gradient
+                if ctx.needs_input_grad[1]:
+                    dw = wgrad(dy, x, N, K, M).view_as(w)
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    db = colsum(dy, _zeros((N,), dy.device), 1, M, N)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 bgemm(dy, w, dx, M, K, N, (N, 1), (K, 1), (K, 1))
-            if ctx.needs_input_grad[1]:
-                dw = wgrad(dy, x, N, K, M).view_as(w)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = colsum(dy, _zeros((N,), dy.device), 1, M, N)
+            sd.join(dw, db)
             return dx, dw, db
 
 
@@ -279,18 +329,20 @@ class _Conv3x3(Fn):
             ld, cin = x.shape[3], ctx.cin
             Cout, M, K = w2.shape[0], B * H * W, 9 * cin
             dx = dw = db = None
+            with _Side(dy, ctx.needs_input_grad[0]) as sd:  # im2col + weight gradient + bias gradient beside the data gradient
+                if ctx.needs_input_grad[1]:
+                    col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
+                    dw2 = wgrad(dy, col, Cout, K, M)
+                    dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    db = colsum(dy, _zeros((Cout,), dy.device), 1, M, Cout)
             if ctx.needs_input_grad[0]:
                 assert ld == cin, "no input gradient through a channel-padded input buffer"
                 dcol = torch.empty(M, K, device=dy.device, dtype=torch.float32)
                 bgemm(dy, w2, dcol, M, K, Cout, (Cout, 1), (K, 1), (K, 1))
                 dx = torch.empty_like(x)
                 L.check(L.lib().sr_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, cin, _st()), "sr_col2im3x3")
-            if ctx.needs_input_grad[1]:
-                col = _im2col(x, (H * W * ld, W * ld, ld, 1), cin)
-                dw2 = wgrad(dy, col, Cout, K, M)
-                dw = dw2.view(Cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()  # back to [Cout, Cin, 3, 3]
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = colsum(dy, _zeros((Cout,), dy.device), 1, M, Cout)
+            sd.join(dw, db)
             return dx, dw, db, None
 
 
@@ -542,22 +594,29 @@ class _Attention(Fn):
             # columns outside the q / k / v slices receive no gradient: zero-filled unless the three slices tile the packed tensor
             dq = torch.empty_like(qs) if (same and ldq == 3 * Cn) else torch.zeros_like(qs)
             dkv = dq if same else torch.zeros_like(kvs)
+            # the q / k / v gradients land in disjoint column slices of the packed gradient: dv runs beside dP -> dS, then dk and the bias-table
+            # gradient beside dq (side stream, joined before the tensors are handed back)
+            with _Side(dO) as sd1:
+                # dv = P^T dO
+                bgemm(P, dO, dkv, Nk, hd, Nq, (1, Nk), (Cn, 1), (ldk, 1), c_off=v_off, nb=nbh, sab=sP, sbb=(Nq * Cn, hd), scb=(Nk * ldk, hd))
             # dP = dO v^T
             dP = torch.empty_like(P)
             bgemm(dO, kvs, dP, Nq, Nk, hd, (Cn, 1), (1, ldk), (Nk, 1), b_off=v_off, nb=nbh, sab=(Nq * Cn, hd), sbb=(Nk * ldk, hd), scb=sP)
-            # dv = P^T dO
-            bgemm(P, dO, dkv, Nk, hd, Nq, (1, Nk), (Cn, 1), (ldk, 1), c_off=v_off, nb=nbh, sab=sP, sbb=(Nq * Cn, hd), scb=(Nk * ldk, hd))
             # dS = P * (dP - rowsum(dP * P))
             L.check(L.lib().sr_softmax_bwd(P.data_ptr(), dP.data_ptr(), nbw * heads * Nq, Nk, _st()), "sr_softmax_bwd")
             dtable = None
-            if ctx.needs_input_grad[2]:
-                dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
-                L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
-                dtable = _zeros_like(table)
-                L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
-            # dq = scale * dS k ; dk = scale * dS^T q
+            with _Side(dO) as sd2:  # ordered after dS on the main stream (and after dv on the side stream itself)
+                if ctx.needs_input_grad[2]:
+                    dbias = torch.empty(heads, Nq * Nk, device=dev, dtype=torch.float32)
+                    L.check(L.lib().sr_batch_sum(dP.data_ptr(), dbias.data_ptr(), nbw, heads * Nq * Nk, heads * Nq * Nk, _st()), "sr_batch_sum")
+                    dtable = _zeros_like(table)
+                    L.check(L.lib().sr_bias_gather(None, rpi.data_ptr(), dbias.data_ptr(), dtable.data_ptr(), table.shape[0], heads, Nq * Nk, 0, _st()), "sr_bias_gather")
+                # dk = scale * dS^T q
+                bgemm(dP, qs, dkv, Nk, hd, Nq, (1, Nk), (ldq, 1), (ldk, 1), b_off=q_off, c_off=k_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nq * ldq, hd), scb=(Nk * ldk, hd))
+            # dq = scale * dS k
             bgemm(dP, kvs, dq, Nq, hd, Nk, (Nk, 1), (ldk, 1), (ldq, 1), b_off=k_off, c_off=q_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nk * ldk, hd), scb=(Nq * ldq, hd))
-            bgemm(dP, qs, dkv, Nk, hd, Nq, (1, Nk), (ldq, 1), (ldk, 1), b_off=q_off, c_off=k_off, alpha=scale, nb=nbh, sab=sP, sbb=(Nq * ldq, hd), scb=(Nk * ldk, hd))
+            sd1.join()
+            sd2.join(dtable)
             return dq, (None if same else dkv), dtable, None, None, None
 
 
