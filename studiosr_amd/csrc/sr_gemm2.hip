@@ -88,17 +88,29 @@ SR_DEV Frag<bf16> raw_to_frag(const Raw<float>& r) {
 
 // MT: 16-row tiles per workgroup; KC: K/32.  NW = 3 (N tile 192), 4 waves split N.
 // STAGE = false: the activation tile is already in LDS (single-pass QKV: the q, k and v column slices reuse one staged tile)
+// sum over the 8 adjacent lanes 8k .. 8k+7 (the K-groups of one activation row), result in all of them: DPP quad_perm xor 1, xor 2, then
+// row_half_mirror (lane i <- lane 7 - i of its group of 8: after the quad sums every lane of a quad holds the same value)
+SR_DEV float row8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
+
 template <typename TIn, int MT, int KC, bool SWAPPED, bool STAGE = true>
 SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int yblk) {
     constexpr int NW = 3;
     constexpr int M_T = MT * 16;
+    constexpr int MS = M_T + 1;  // row stride of the K-group-major LDS image in cells: odd, so that the staging writes of ONE row's 8 K-groups (8 adjacent lanes) hit 8 bank groups
     constexpr int RING = KC < 6 ? KC : 6;
     constexpr int NP = M_T / 32;  // row passes per wave (8 rows each)
     constexpr int KI = KC / 2;    // K-groups per lane per row (8 lanes share a row)
     const SrGemm& g = a.g;
     const int m0 = blockIdx.x * M_T;
     const int ar = lane & 15, ag = lane >> 4;
-    const int r8 = lane & 7, kq = lane >> 3;
+    // activation staging: the 8 lanes that share a row are ADJACENT lanes (K-group on the fast lane axis): they read its 128 / 256 contiguous
+    // bytes; row-fastest lanes made every quad of lanes touch four cache lines (four TA tag cycles per quad)
+    const int kq = lane & 7, r8 = lane >> 3;
     const int ntile0 = yblk * (4 * NW) + wave * NW;
 
     // ---- t0: weight fragments for the first RING chunks
@@ -165,9 +177,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
                     for (int i = 0; i < KI; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) s += raw[p][i].lo[j] + raw[p][i].hi[j];
-                    s = wave_sum_xor(s, 8);
-                    s = wave_sum_xor(s, 16);
-                    s = wave_sum_xor(s, 32);
+                    s = row8_sum(s);
                     const float inv = 1.0f / (float)g.k_real;
                     const float mean = s * inv;
                     float q = 0.f;
@@ -181,9 +191,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
                             q += d0 * d0 + d1 * d1;
                         }
                     }
-                    q = wave_sum_xor(q, 8);
-                    q = wave_sum_xor(q, 16);
-                    q = wave_sum_xor(q, 32);
+                    q = row8_sum(q);
                     const float rstd = rsqrtf(q * inv + g.ln_eps);
 #pragma unroll
                     for (int i = 0; i < KI; ++i) {
@@ -198,13 +206,13 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
                             o.lo = (raw[p][i].lo - mean) * rstd * g0 + b0;
                             o.hi = (raw[p][i].hi - mean) * rstd * g1 + b1;
                         }
-                        dst[kg * M_T] = raw_to_frag(o);
+                        dst[kg * MS] = raw_to_frag(o);
                     }
                     continue;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < KI; ++i) dst[(kq + 8 * i) * M_T] = raw_to_frag(raw[p][i]);
+            for (int i = 0; i < KI; ++i) dst[(kq + 8 * i) * MS] = raw_to_frag(raw[p][i]);
         }
     }
     if constexpr (!EARLY_ACC) init_acc();
@@ -214,7 +222,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int slot = c % RING;
-        const Frag<bf16>* arow = As + (c * 4 + ag) * M_T + ar;
+        const Frag<bf16>* arow = As + (c * 4 + ag) * MS + ar;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const Frag<bf16> av = arow[m * 16];
@@ -316,7 +324,7 @@ SR_DEV void gemm2_body(const Gemm2& a, Frag<bf16>* As, int lane, int wave, int y
 
 template <typename TIn, int MT, int KC>
 __global__ __launch_bounds__(256, 2) void sr_gemm2_kernel(Gemm2 a) {
-    __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * MT * 16];
+    __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * (MT * 16 + 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool vpart = (a.g.epi != SR_EPI_STD) && ((int)blockIdx.y * 192 >= 2 * a.g.heads * a.g.hd_p);
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void sr_gemm2_kernel(Gemm2 a) {
 // is fetched, normalised and staged once instead of three times (the projection is bound by that, not by its MFMAs).
 template <typename TIn, int MT, int KC>
 __global__ __launch_bounds__(256, 2) void sr_gemm2_qkv_kernel(Gemm2 a) {
-    __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * MT * 16];
+    __shared__ __attribute__((aligned(16))) Frag<bf16> As[KC * 4 * (MT * 16 + 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     gemm2_body<TIn, MT, KC, true, true>(a, As, lane, wave, 0);
