@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 5
+#define SR_ABI_VERSION 6
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -141,6 +141,29 @@ typedef struct SrSwinBlock {
 } SrSwinBlock;
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);
+
+typedef struct SrSwinTail {
+    /* Everything of a window-attention block BEHIND its attention kernel in ONE launch, ABI v6 (hat.py:172-194 HAB, hat.py:286-293 OCAB;
+     * swinir.py:169-174 for geometries sr_swin_block does not cover):
+     *     x1  = x + proj(O) + bproj [ + y * gate[image] ]      out = x1 + fc2(GELU(fc1(LayerNorm2(x1))))
+     * O = output of sr_window_attention / sr_oca: bf16 [B*H*W][heads*hd_p] in WINDOW order (window_reverse and the roll back are the row
+     * gather of this kernel); x, y, out in image order.  Replaces sr_gemm (projection, SR_EPI_STD with skip / gated skip2) + sr_mlp_fused.
+     * One workgroup per 64 consecutive window-order tokens; weights from ONE packed stream (packing.py pack_swin_tail_stream: 6 proj slots,
+     * then slots 24..47 of the sr_swin_block stream: fc1 / fc2 with their biases on the constant-one pad channels, LayerNorm2 folded). */
+    const float* x;        /* [B,H,W,ldx] fp32 stream (the shortcut) */
+    float* out;            /* may alias x */
+    const void* o;         /* bf16 [B*H*W][heads*hd_p] */
+    const void* wstream;   /* 30 slots x 12 fragments x 64 lanes x 8 bf16 */
+    const float* bproj;    /* [Cp] fp32, pad 0 */
+    const void* y;         /* optional second residual bf16 [B,H,W,ldy] (HAT: the CAB convolution output) or NULL */
+    const float* gate;     /* [B][ld_gate] fp32 per-image channel gates from sr_channel_gate (conv_scale folded in); read when y != NULL */
+    int B, H, W, C, Cp, ldx, ldy, ld_gate, heads, hd_p, ws, shift, Hp;
+    float eps;
+    int y_mode;            /* SR_Y_* */
+    int compute_dtype;     /* SR_BF16 */
+} SrSwinTail;
+int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
+int sr_swin_tail(const SrSwinTail* a, void* stream);
 
 typedef struct SrMlp {
     /* x_out = x + fc2(GELU(fc1(LayerNorm(x)))) in ONE kernel (common.py:173-195, swinir.py:172, hat.py:193,292):

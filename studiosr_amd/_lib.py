@@ -24,7 +24,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -57,6 +57,14 @@ class SrSwinBlock(C.Structure):
         ("x", _vp), ("out", _vp), ("wstream", _vp), ("bias", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("Hp", _i),
         ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
+    ]
+
+
+class SrSwinTail(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("out", _vp), ("o", _vp), ("wstream", _vp), ("bproj", _vp), ("y", _vp), ("gate", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldy", _i), ("ld_gate", _i), ("heads", _i), ("hd_p", _i), ("ws", _i),
+        ("shift", _i), ("Hp", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
     ]
 
 
@@ -140,6 +148,8 @@ SYMBOLS = {
     "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
     "sr_swin_block_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_block": (_i, [C.POINTER(SrSwinBlock), _vp]),
+    "sr_swin_tail_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "sr_swin_tail": (_i, [C.POINTER(SrSwinTail), _vp]),
     "sr_mlp_fused_supported": (_i, [_i, _i, _i]),
     "sr_mlp_fused": (_i, [C.POINTER(SrMlp), _vp]),
     "sr_conv3x3": (_i, [C.POINTER(SrConv3x3), _vp]),

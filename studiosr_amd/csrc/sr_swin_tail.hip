@@ -1,0 +1,274 @@
+// Everything of a window-attention transformer block that follows the attention kernel, in ONE launch (C ABI v6 sr_swin_tail):
+//     x1  = x + proj(O) + b_proj  [ + y * gate[image] ]        (hat.py:172-192: attention output, shortcut, conv_scale * CAB(x))
+//     out = x1 + fc2( GELU( fc1( LayerNorm2(x1) ) ) )          (hat.py:194; swinir.py:172-174; common.py:173-195)
+// for the geometries whose attention does not fit the one-kernel block (HAT: 16 x 16 windows, overlapping cross attention): O is the
+// [tokens, heads * hd_p] output of sr_window_attention / sr_oca in WINDOW order, x / y / out are the image-order stream (window_reverse +
+// roll back = the row gather of the block kernel).  Replaces the projection GEMM (sr_gemm, 25 us at HAT's 4 x 64 x 64 tokens) and the
+// MLP kernel (16.5 us) with one pass of the stream-form kernel's own stages (sr_swin_stream.h):
+//   * one workgroup = 64 consecutive window-order tokens (a quarter of a 16 x 16 window), 4 waves, wave w owns output channels [48 w, +48);
+//   * O reaches LDS as the K-group-major operand image by a gathering LDS-DMA (lane = token, one 16-B k-group per instruction): no
+//     registers, conflict-free fragment reads;
+//   * projection = 6 uniform steps, MLP = 2 x (6 fc1 + 6 fc2) steps from ONE 30-slot weight stream two slots ahead in registers;
+//     fc1 / fc2 biases ride on the constant-one pad channels exactly as in sr_swin_block (same slots 24..47 of that stream);
+//   * x1 never leaves the registers; the result leaves through the LDS row tile as full 768-B rows.
+#include "sr_swin_stream.h"
+
+namespace {
+
+constexpr int TAIL_SLOTS = 30;  // 6 proj, then per hidden half 6 fc1 + 6 fc2
+
+struct SwinTailDev {
+    SrSwinTail a;
+    FastDiv div_parts_img, div_parts_win, div_nwx;  // 64-token parts per image, per window; windows per row
+    int ws_log2;
+};
+
+// one k-group (16 B per token) of 64 consecutive O rows -> 64 consecutive image cells: lane = token
+SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void sr_swin_tail_kernel(SwinTailDev dv) {
+    static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
+    const SrSwinTail& a = dv.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);  // O image [24 k-groups][64 tokens], then the LayerNorm2 image
+    Frag<T>* Himg = Aimg + CELLS_A;                    // hidden half [24][64]
+    float* red = reinterpret_cast<float*>(smem + Lds<T>::RED_OFF);
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    int lane = lane0, ar = lane & 15, ag = lane >> 4;
+    auto relane = [&]() {  // see sr_swin_block3.hip: keeps hipcc from hoisting (and spilling) every per-lane offset to kernel entry
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        ar = lane & 15;
+        ag = lane >> 4;
+    };
+
+    // ---- geometry: workgroup = part `part` (64 tokens = 64 / ws window rows) of window `win` of image `bimg`
+    uint32_t bimg, rem, win, part, wy, wx;
+    dv.div_parts_img.divmod((uint32_t)blockIdx.x, bimg, rem);
+    dv.div_parts_win.divmod(rem, win, part);
+    dv.div_nwx.divmod(win, wy, wx);
+    const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;
+    const int wsl = dv.ws_log2, wsm = a.ws - 1;
+    auto pixel_row = [&](int t) {  // image-order row of token t of this workgroup (window_reverse + roll back as one gather)
+        const int tw = (int)part * NTOK + t;
+        int y = ((int)wy << wsl) + (tw >> wsl) + shift_y;
+        int x = ((int)wx << wsl) + (tw & wsm) + a.shift;
+        if (y >= a.H) y -= a.H;
+        if (x >= a.W) x -= a.W;
+        return ((int)bimg * a.H + y) * a.W + x;
+    };
+
+    // ---- loads, all in flight together: O image (LDS-DMA), the first weight slots, x / y in the accumulator layout, gate and bias vectors
+    {
+        const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NTOK * (a.heads * a.hd_p) * 2;
+        const int lane_off = lane * (a.heads * a.hd_p) * 2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int kg = 6 * w + i;
+            dma_gather16(orow + kg * 16, lane_off, __builtin_amdgcn_readfirstlane(img_lds + kg * NTOK * 16));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WStream<T, TAIL_SLOTS> ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, TAIL_SLOTS * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
+    ws.wave_frag = w * 3;
+#pragma unroll
+    for (int s0 = 0; s0 < WStream<T, TAIL_SLOTS>::DIST; ++s0) ws.load(s0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
+    f32x4 gt[3];
+    bf16x4 yv[4][3];
+    const int ch0 = w * 48 + ag * 4;
+    {
+        int prow[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) prow[m] = pixel_row(m * 16 + ar);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) x1[m][n] = *reinterpret_cast<const f32x4*>(a.x + (size_t)prow[m] * a.ldx + ch0 + n * 16);
+        if (a.y) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)bimg * a.ld_gate + ch0 + n * 16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) yv[m][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.y) + (size_t)prow[m] * a.ldy + ch0 + n * 16);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // everything was issued together (one latency); the O image must be complete before the barrier, x and slot 0 are needed right behind it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BLOCK_SYNC();
+
+    auto loada_img = [&](const Frag<T>* img) {
+        return [&, img](int c, int h, Frag<T> (&av)[2]) {
+            const Frag<T>* arow = img + (c * 4 + ag) * NTOK + h * 32 + ar;
+            av[0] = arow[0];
+            av[1] = arow[16];
+        };
+    };
+
+    // ---- projection on top of the shortcut: x1 += O @ Wproj^T (K = 6 heads x 32 features, the pad features are 0 on both sides)
+    ws.template run<6>(0, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) mma(b[n], ov[m], x1[2 * h + m][n]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    relane();
+    {
+        f32x4 bp[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bp[n] = *reinterpret_cast<const f32x4*>(a.bproj + w * 48 + ag * 4 + n * 16);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                x1[m][n] += bp[n];
+                if (a.y) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x1[m][n][r] = __builtin_fmaf((float)yv[m][n][r], gt[n][r], x1[m][n][r]);  // as sr_gemm's gated second residual
+                }
+            }
+    }
+
+    // ---- LayerNorm2 of x1 -> bf16 image over the O image (the barrier between its two halves orders the last O reads before the writes)
+    const bool one_lane = (w == ONE_C / 48) && (ag == (ONE_C % 16) / 4);
+    {
+        {
+            float q1[4], q2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];
+                f32x4 t2 = x1[m][0] * x1[m][0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2[r] = __builtin_fmaf(x1[m][2][r], x1[m][2][r], __builtin_fmaf(x1[m][1][r], x1[m][1][r], t2[r]));
+                q1[m] = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+                q2[m] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+            }
+            const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);
+            const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
+            *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);
+        }
+        BLOCK_SYNC();
+        const float inv = 1.0f / (float)a.C;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
+            const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf(x1[m][n][r], rstd, nmr);
+                if (n == 2) {
+                    nv[0] = one_lane ? 1.0f : nv[0];
+                    nv[1] = one_lane ? 1.0f : nv[1];
+                }
+                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, nv);
+            }
+        }
+    }
+    BLOCK_SYNC();
+
+    // ---- MLP in two hidden halves of 192 columns (sr_swin_block3.hip, same slots)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        relane();
+        f32x4 acc[4][3];
+        ws.template run<6>(6 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    if (c == 0)
+                        mma0(b[n], av[m], acc[2 * h + m][n]);
+                    else
+                        mma(b[n], av[m], acc[2 * h + m][n]);
+                }
+        });
+        if (hf == 1) BLOCK_SYNC();  // fc2 of the first half has read the hidden image everywhere
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = gelu_op<T>(acc[m][n][r]);
+                st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, g);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        BLOCK_SYNC();
+        ws.template run<6>(12 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&hv)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) mma(b[n], hv[m], x1[2 * h + m][n]);
+        });
+    }
+
+    // ---- store: accumulator layout -> LDS tile -> 16 full rows per wave
+    relane();
+    BLOCK_SYNC();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xm + n * 64) = x1[m][n];
+    }
+    BLOCK_SYNC();
+    {
+        f32x4 rowv[16];
+        const int l48 = lane < 48 ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
+    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16 || ws == 32) && Hp == 384) ? 1 : 0;
+}
+
+extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->out && p->o && p->wstream && p->bproj, "sr_swin_tail: null pointer");
+    const SrSwinTail& a = *p;
+    SR_REQUIRE(sr_swin_tail_supported(a.C, a.Cp, a.heads, a.hd_p, a.ws, a.Hp, a.compute_dtype), "sr_swin_tail: unsupported geometry / compute type (use sr_gemm + sr_mlp_fused)");
+    SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
+                   a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
+               "sr_swin_tail: bad geometry");
+    SR_REQUIRE(!a.y || (a.gate && a.ldy >= a.Cp && a.ldy % 4 == 0 && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate, ldy, ld_gate");
+    SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
+    SwinTailDev dv;
+    dv.a = a;
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws, parts = a.ws * a.ws / 64;
+    dv.div_parts_img = make_fastdiv((uint32_t)(nwx * nwy * parts));
+    dv.div_parts_win = make_fastdiv((uint32_t)parts);
+    dv.div_nwx = make_fastdiv((uint32_t)nwx);
+    dv.ws_log2 = a.ws == 8 ? 3 : (a.ws == 16 ? 4 : 5);
+    static SrDeviceOnce attr_once;
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16>, Lds<bf16>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(sr_swin_tail_kernel<bf16>, dim3(a.B * nwx * nwy * parts), dim3(256), Lds<bf16>::TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
+    SR_CHECK_LAUNCH("sr_swin_tail");
+    return SR_OK;
+}

@@ -39,8 +39,11 @@ from .swinir import (
     pack_attention,
     pack_ln,
     pack_mlp,
+    pack_tail_stream,
     run_mlp,
+    run_swin_tail,
     run_window_msa,
+    swin_tail_usable,
 )
 
 Tensor = torch.Tensor
@@ -222,6 +225,7 @@ class HAT(Model):
                 e = dict(shift=blk.shift_size, ln1=pack_ln(blk.norm1, Cp), ln2=pack_ln(blk.norm2, Cp))
                 e.update(pack_attention(blk.attn, geo, dt, rpi=self.relative_position_index_SA, norm=blk.norm1))
                 e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
+                e.update(pack_tail_stream(blk.attn.proj, blk.mlp, blk.norm2, geo, dt))
                 cab = blk.conv_block.cab
                 e["cab1"] = packing.pack_conv3x3(cab[0].weight, cab[0].bias, Cp, packing.identity_idx(c3, c3p), dt)
                 e["cab2"] = packing.pack_conv3x3(cab[2].weight, cab[2].bias, c3p, ident, dt)
@@ -240,6 +244,7 @@ class HAT(Model):
             obf[:, :, :nk] = ob
             o["oca_bias_frag"], o["oca_nk_frag"] = packing.bias_fragments(obf), nk_frag
             o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
+            o.update(pack_tail_stream(oc.proj, oc.mlp, oc.norm2, geo, dt))
             conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, ident, dt)
             P["layers"].append(dict(blocks=blocks, ocab=o, conv=conv, geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)
@@ -302,7 +307,10 @@ class HAT(Model):
             return dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
-        if not run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join):
+        used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True)
+        if used == "tail":  # projection + both residuals + LayerNorm2 + MLP ran as one launch (sr_swin_tail)
+            return
+        if not used:
             # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
             if side is not main:
                 main.wait_stream(side)
@@ -333,6 +341,9 @@ class HAT(Model):
             hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt, bias_frag=op["oca_bias_frag"].data_ptr(),
             nk_frag=op["oca_nk_frag"],
         )
+        if swin_tail_usable(op, geo, Cp, cdt):
+            run_swin_tail(op, geo, o, t, t, 0)
+            return
         ops.gemm(
             A=o.data_ptr(), Wp=op["proj_w"].data_ptr(), bias=op["proj_b"].data_ptr(), out=t.data_ptr(), skip=t.data_ptr(), M=M, K=geo.HP, N=Cp,
             lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,

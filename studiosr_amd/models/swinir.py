@@ -160,6 +160,35 @@ def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dic
     return dict(stream=stream, bias_frag_l2=packing.bias_fragments(bias * packing.LOG2E), stream_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
 
 
+def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
+    """Weight stream of sr_swin_tail (ABI v6: projection + shortcut + LayerNorm2 + MLP behind a separate attention kernel; hat.py:172-194,
+    286-293) when the kernel covers the geometry (bf16 path only)."""
+    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.hidden == 360 and geo.ws in (8, 16, 32)):
+        return {}
+    w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, norm2.weight, norm2.bias)
+    return dict(tail_stream=packing.pack_swin_tail_stream(proj.weight, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden))
+
+
+def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
+    """SR_SWIN_TAIL=0 keeps the projection GEMM + MLP kernel (A/B switch, read per call)."""
+    return ("tail_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_TAIL", "1") != "0"
+            and ops.swin_tail_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, L.SR_BF16))
+
+
+def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Tensor, shift: int, y_mode: int = L.Y_ROLL, extra: Optional[Dict] = None) -> None:
+    """t_out = x1 + MLP(LayerNorm2(x1)),  x1 = skip + proj(o) (+ gated second residual from `extra`, the sr_gemm skip2 fields)."""
+    B, H, W, Cp = skip.shape
+    kw = {}
+    if extra:
+        assert extra["skip2_dtype"] == L.SR_BF16 and extra["gate_rows"] == H * W
+        kw = dict(y=extra["skip2"], gate=extra["skip2_gate"], ldy=extra["ldskip2"], ld_gate=extra["ld_gate"])
+    ops.swin_tail(
+        x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=p["tail_stream"].data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
+        C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
+        compute_dtype=L.SR_BF16, **kw,
+    )
+
+
 def swin_block_kernel_choice() -> str:
     """SR_SWIN_BLOCK = v3 (default: sr_swin_block, one weight stream) | v2 (round-2 one-window kernel) | v1 (round-1 kernel); read per call."""
     return os.environ.get("SR_SWIN_BLOCK", "v3")
@@ -193,11 +222,13 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL, before_proj=None) -> bool:
+                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False):
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
     before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
-    second residual).  Returns True iff it was used (the one-kernel attention half has no hook)."""
+    second residual).  Returns True iff it was used (the one-kernel attention half has no hook).
+    with_mlp: the caller's next step is run_mlp(p, ...) on t_out; when sr_swin_tail covers the geometry the projection AND that MLP run as
+    one launch and the function returns "tail" (the caller must then skip run_mlp)."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -224,6 +255,9 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
         hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
     )
     extra = before_proj() if before_proj is not None else {}
+    if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
+        run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)
+        return "tail"
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,

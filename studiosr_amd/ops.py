@@ -85,6 +85,18 @@ def swin_block(**kw) -> None:
     L.check(L.lib().sr_swin_block(C.byref(a), _stream()), "sr_swin_block")
 
 
+def swin_tail_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, Hp: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_swin_tail_supported(C_, Cp, heads, hd_p, ws, Hp, compute_dtype))
+
+
+def swin_tail(**kw) -> None:
+    """Projection + shortcut (+ gated second residual) + LayerNorm2 + MLP behind an attention kernel in one launch (ABI v6; hat.py:172-194)."""
+    a = L.SrSwinTail()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_swin_tail(C.byref(a), _stream()), "sr_swin_tail")
+
+
 def mlp_fused_supported(Cp: int, Hp: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_mlp_fused_supported(Cp, Hp, compute_dtype))
 

@@ -257,3 +257,25 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
         lo = (out - hi.to(f32)).to(torch.bfloat16)
         return torch.cat([hi, lo], dim=-1).reshape(-1).contiguous()  # [slot][fragment][lane][8 hi | 8 lo]
     return out.to(torch.bfloat16).reshape(-1).contiguous()
+
+
+SWIN_TAIL_SLOTS = 30
+
+
+def pack_swin_tail_stream(proj_w: Tensor, fc1_w: Tensor, fc1_b: Optional[Tensor], fc2_w: Tensor, fc2_b: Optional[Tensor], C: int, heads: int,
+                          hidden: int) -> Tensor:
+    """The weight stream of sr_swin_tail (include/studiosr_hip.h SrSwinTail; hat.py:172-194): 30 slots x 12 fragments x [64 lanes][8] bf16 --
+    6 projection slots (slot = head: K = the head's 32 padded features of the attention output, no bias: the kernel adds bproj itself),
+    then the 24 MLP slots of pack_swin_block_stream (fc1 with LayerNorm2 folded by the caller; fc1 / fc2 biases on the constant-one pad
+    channels)."""
+    assert C == 180 and heads == 6 and hidden == 360, "sr_swin_tail geometry"
+    hd, hdp, Cp = C // heads, 32, 192
+    dev = proj_w.device
+    f32 = torch.float32
+    M_proj = torch.zeros(Cp, heads, hdp, dtype=f32, device=dev)
+    M_proj[:C, :, :hd] = proj_w.detach().to(f32).reshape(C, heads, hd)
+    # M_proj[ch = 48 w + 16 n + i, head = c, d = 8 g + j] -> [c, 3 w + n, 16 g + i, j]
+    proj = M_proj.reshape(4, 3, 16, heads, 4, 8).permute(3, 0, 1, 4, 2, 5).reshape(heads, 12, 64, 8).to(torch.bfloat16).reshape(-1)
+    zero = torch.zeros(3 * C, C, dtype=f32, device=dev)
+    full = pack_swin_block_stream(zero, None, proj_w, None, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden)
+    return torch.cat([proj, full.reshape(SWIN_STREAM_SLOTS, -1)[24:].reshape(-1)]).contiguous()

@@ -453,6 +453,26 @@ def test_hat_full_width_against_oracle(prec, tol, ws):
     assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
+def test_swin_tail_kernel_equals_the_projection_gemm_and_mlp_kernel(monkeypatch):
+    """sr_swin_tail (projection + shortcut + gated CAB term + LayerNorm2 + MLP in one launch, ABI v6) against the launches it replaces
+    (sr_gemm with the gated second residual, sr_mlp_fused) inside the same HAT forward: 16 x 16 windows in four 64-token parts, shifted
+    and unshifted blocks, a non-square image, the overlapping cross-attention block's tail; and against the CPU oracle."""
+    torch.manual_seed(11)
+    m = _randomised(S.HAT(scale=2, depths=[2, 2], num_heads=[6, 6], window_size=16), seed=11).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(2, 3, 48, 32)
+    with torch.no_grad():
+        monkeypatch.setenv("SR_SWIN_TAIL", "1")
+        y1 = m(x.to(DEV)).cpu()
+        monkeypatch.setenv("SR_SWIN_TAIL", "0")
+        y0 = m(x.to(DEV)).cpu()
+    sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
+    ref = OM.hat_forward(sd, x, m.get_model_config())
+    scale = max(1.0, float(ref.abs().max()))
+    e1, e0 = float((y1 - ref).abs().max()) / scale, float((y0 - ref).abs().max()) / scale
+    assert e1 <= BF16_TOL and e0 <= BF16_TOL
+    assert float((y1 - y0).abs().max()) <= 0.5 * BF16_TOL * scale  # same operands, same products: only the summation order differs
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
 def test_rcan_full_width_against_oracle(prec, tol):
     """Default-width RCAN (64 features: in bf16 the conv-ReLU-conv of every RCAB is the one-launch sr_rcab_conv_pair with its
