@@ -142,6 +142,22 @@ typedef struct SrSwinBlock {
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);
 
+typedef struct SrSwinQkv {
+    /* q, k, v = qkv(LayerNorm1(x)) in front of sr_window_attention, ABI v6 (hat.py:164-176; swinir.py:146-160 for geometries sr_swin_block
+     * does not cover): the stream-form replacement of sr_gemm's SR_EPI_QKV launch.  One workgroup per 64 consecutive window-order tokens
+     * (roll + window_partition = its row gather); weights from ONE packed stream (packing.py pack_swin_qkv_stream: 18 slots; LayerNorm1
+     * affine, attention scale and all three biases folded in).  Outputs bf16: q, k [B*nW][heads][ws*ws][hd_p], vt [B*nW][heads][hd_p][ws*ws]. */
+    const float* x;        /* [B,H,W,ldx] fp32 stream */
+    void* q; void* k; void* vt;
+    const void* wstream;   /* 18 slots x 12 fragments x 64 lanes x 8 bf16 */
+    int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift;
+    float eps;
+    int y_mode;            /* SR_Y_* */
+    int compute_dtype;     /* SR_BF16 */
+} SrSwinQkv;
+int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype);
+int sr_swin_qkv(const SrSwinQkv* a, void* stream);
+
 typedef struct SrSwinTail {
     /* Everything of a window-attention block BEHIND its attention kernel in ONE launch, ABI v6 (hat.py:172-194 HAB, hat.py:286-293 OCAB;
      * swinir.py:169-174 for geometries sr_swin_block does not cover):
@@ -161,6 +177,12 @@ typedef struct SrSwinTail {
     float eps;
     int y_mode;            /* SR_Y_* */
     int compute_dtype;     /* SR_BF16 */
+    /* optional side output: n1 = LayerNorm(out) * n1_gamma + n1_beta as bf16 [B,H,W,ldn] (HAT: norm1 of the NEXT block, whose CAB
+     * convolutions read it, hat.py:165-170 -- replaces that block's sr_layernorm_to launch).  NULL: not written. */
+    void* n1;
+    const float* n1_gamma; /* [Cp] fp32, pad 0 */
+    const float* n1_beta;
+    int ldn;
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);

@@ -60,11 +60,20 @@ class SrSwinBlock(C.Structure):
     ]
 
 
+class SrSwinQkv(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("q", _vp), ("k", _vp), ("vt", _vp), ("wstream", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
+        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
+    ]
+
+
 class SrSwinTail(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("o", _vp), ("wstream", _vp), ("bproj", _vp), ("y", _vp), ("gate", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldy", _i), ("ld_gate", _i), ("heads", _i), ("hd_p", _i), ("ws", _i),
         ("shift", _i), ("Hp", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
+        ("n1", _vp), ("n1_gamma", _vp), ("n1_beta", _vp), ("ldn", _i),
     ]
 
 
@@ -148,6 +157,8 @@ SYMBOLS = {
     "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
     "sr_swin_block_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_block": (_i, [C.POINTER(SrSwinBlock), _vp]),
+    "sr_swin_qkv_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sr_swin_qkv": (_i, [C.POINTER(SrSwinQkv), _vp]),
     "sr_swin_tail_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_tail": (_i, [C.POINTER(SrSwinTail), _vp]),
     "sr_mlp_fused_supported": (_i, [_i, _i, _i]),

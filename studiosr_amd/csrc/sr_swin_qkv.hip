@@ -1,0 +1,193 @@
+// LayerNorm1 + QKV projection in front of a separate window-attention kernel, stream form (C ABI v6 sr_swin_qkv):
+//     q, k, v = qkv( LayerNorm1(x) )  in the layouts sr_window_attention reads            (hat.py:164-176, 55-83; swinir.py:78-90, 146-160)
+// for the geometries the one-kernel block does not cover (HAT: 16 x 16 windows).  Replaces sr_gemm's SR_EPI_QKV launch (three column
+// slices x 64-row tiles, each re-reading and re-normalising its x tile: 19-21 us at HAT's 4 x 64 x 64 tokens) by the first stage of
+// sr_swin_block3.hip: one workgroup = 64 consecutive window-order tokens, x arrives once as full rows by LDS-DMA (roll + window_partition
+// = the row gather), LayerNorm in the accumulator layout into the K-group-major bf16 image, then three passes of six uniform steps
+// (pass p: heads 2p, 2p+1; wave w: d-half w & 1 of head 2p + (w >> 1): q, k as [token][feature] tiles, v transposed) from ONE
+// 18-slot weight stream.  All three biases ride on the constant-one pad channels 180 / 181 of the image; the attention scale is in the q rows.
+// No barrier after the LayerNorm: the passes only read the image and write global memory.
+#include "sr_swin_stream.h"
+
+namespace {
+
+constexpr int QKV_SLOTS = 18;
+#ifndef SR_QKV_DIST
+#define SR_QKV_DIST 4
+#endif
+
+struct SwinQkvDev {
+    SrSwinQkv a;
+    FastDiv div_parts_img, div_parts_win, div_nwx;
+    int ws_log2, nw;  // windows per image
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
+    static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
+    const SrSwinQkv& a = dv.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);
+    float* red = reinterpret_cast<float*>(smem + Lds<T>::RED_OFF);
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    int lane = lane0, ar = lane & 15, ag = lane >> 4;
+    auto relane = [&]() {
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        ar = lane & 15;
+        ag = lane >> 4;
+    };
+
+    uint32_t bimg, rem, win, part, wy, wx;
+    dv.div_parts_img.divmod((uint32_t)blockIdx.x, bimg, rem);
+    dv.div_parts_win.divmod(rem, win, part);
+    dv.div_nwx.divmod(win, wy, wx);
+    const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;
+    const int wsl = dv.ws_log2, wsm = a.ws - 1;
+    auto pixel_row = [&](int t) {  // image-order row of token t of this workgroup (roll + window_partition as one gather)
+        const int tw = (int)part * NTOK + t;
+        int y = ((int)wy << wsl) + (tw >> wsl) + shift_y;
+        int x = ((int)wx << wsl) + (tw & wsm) + a.shift;
+        if (y >= a.H) y -= a.H;
+        if (x >= a.W) x -= a.W;
+        return ((int)bimg * a.H + y) * a.W + x;
+    };
+
+    // ---- x: 16 full token rows per wave by LDS-DMA, then the first weight slots
+    {
+        const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = 16 * w + i;
+            dma_row48(a.x + (size_t)pixel_row(t) * a.ldx, __builtin_amdgcn_readfirstlane(tile_lds + t * XS), lane);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WStream<T, QKV_SLOTS, SR_QKV_DIST> ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, QKV_SLOTS * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
+    ws.wave_frag = w * 3;
+#pragma unroll
+    for (int s0 = 0; s0 < SR_QKV_DIST; ++s0) ws.load(s0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * SR_QKV_DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
+    BLOCK_SYNC();
+    {
+        f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) x1[m][n] = *reinterpret_cast<const f32x4*>(xm + n * 64);
+        }
+        {
+            float q1[4], q2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];  // pad channels of the stream are exactly 0
+                f32x4 t2 = x1[m][0] * x1[m][0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2[r] = __builtin_fmaf(x1[m][2][r], x1[m][2][r], __builtin_fmaf(x1[m][1][r], x1[m][1][r], t2[r]));
+                q1[m] = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+                q2[m] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+            }
+            const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);
+            const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
+            *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);
+        }
+        BLOCK_SYNC();  // (also: every wave has read its part of the x tile, which the image overwrites)
+        const bool one_lane = (w == ONE_C / 48) && (ag == (ONE_C % 16) / 4);
+        const float inv = 1.0f / (float)a.C;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
+            const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf(x1[m][n][r], rstd, nmr);
+                if (n == 2) {
+                    nv[0] = one_lane ? 1.0f : nv[0];
+                    nv[1] = one_lane ? 1.0f : nv[1];
+                }
+                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, nv);
+            }
+        }
+    }
+    BLOCK_SYNC();
+
+    auto loada = [&](int c, int h, Frag<T> (&av)[2]) {
+        const Frag<T>* arow = Aimg + (c * 4 + ag) * NTOK + h * 32 + ar;
+        av[0] = arow[0];
+        av[1] = arow[16];
+    };
+    const int hh = w >> 1, half = w & 1;
+    const int ntok_log2 = 2 * wsl;
+    const size_t bwin = (size_t)bimg * dv.nw + win;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        relane();
+        f32x4 acc[4][3];
+        ws.template run<6>(6 * p, lane, loada, [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (c == 0) {
+                    mma0(b[0], av[m], acc[2 * h + m][0]);  // q: lane = token, registers = 4 features
+                    mma0(b[1], av[m], acc[2 * h + m][1]);  // k: likewise
+                    mma0(av[m], b[2], acc[2 * h + m][2]);  // v: lane = feature, registers = 4 tokens
+                } else {
+                    mma(b[0], av[m], acc[2 * h + m][0]);
+                    mma(b[1], av[m], acc[2 * h + m][1]);
+                    mma(av[m], b[2], acc[2 * h + m][2]);
+                }
+            }
+        });
+        const size_t bh = bwin * a.heads + (2 * p + hh);
+        bf16* qd = reinterpret_cast<bf16*>(a.q) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
+        bf16* kd = reinterpret_cast<bf16*>(a.k) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
+        bf16* vd = reinterpret_cast<bf16*>(a.vt) + (((bh * a.hd_p + 16 * half + ar) << ntok_log2) + part * NTOK + 4 * ag);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            *reinterpret_cast<bf16x4*>(qd + m * 16 * a.hd_p) = cvt4(acc[m][0]);
+            *reinterpret_cast<bf16x4*>(kd + m * 16 * a.hd_p) = cvt4(acc[m][1]);
+            *reinterpret_cast<bf16x4*>(vd + m * 16) = cvt4(acc[m][2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace
+
+extern "C" int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype) {
+    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16 || ws == 32)) ? 1 : 0;
+}
+
+extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->q && p->k && p->vt && p->wstream, "sr_swin_qkv: null pointer");
+    const SrSwinQkv& a = *p;
+    SR_REQUIRE(sr_swin_qkv_supported(a.C, a.Cp, a.heads, a.hd_p, a.ws, a.compute_dtype), "sr_swin_qkv: unsupported geometry / compute type (use sr_gemm with SR_EPI_QKV)");
+    SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
+                   a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
+               "sr_swin_qkv: bad geometry");
+    SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");
+    SwinQkvDev dv;
+    dv.a = a;
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws, parts = a.ws * a.ws / 64;
+    dv.div_parts_img = make_fastdiv((uint32_t)(nwx * nwy * parts));
+    dv.div_parts_win = make_fastdiv((uint32_t)parts);
+    dv.div_nwx = make_fastdiv((uint32_t)nwx);
+    dv.ws_log2 = a.ws == 8 ? 3 : (a.ws == 16 ? 4 : 5);
+    dv.nw = nwx * nwy;
+    static SrDeviceOnce attr_once;
+    {
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_qkv_kernel<bf16>, Lds<bf16>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_qkv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(sr_swin_qkv_kernel<bf16>, dim3(a.B * nwx * nwy * parts), dim3(256), Lds<bf16>::TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
+    SR_CHECK_LAUNCH("sr_swin_qkv");
+    return SR_OK;
+}

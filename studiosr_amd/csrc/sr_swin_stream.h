@@ -188,9 +188,9 @@ SR_DEV void buf_load_frag(Frag<bf3>& f, __amdgpu_buffer_rsrc_t rsrc, int lane, i
 #ifndef SR_RING_DIST
 #define SR_RING_DIST 2
 #endif
-template <typename T, int NS = NSLOT>
+template <typename T, int NS = NSLOT, int D = SR_RING_DIST>
 struct WStream {
-    static constexpr int DIST = SR_RING_DIST, RING = DIST + 1;
+    static constexpr int DIST = D, RING = DIST + 1;
     static constexpr int LOADS_PER_SLOT = 3 * (int)sizeof(Frag<T>) / 16;  // buffer_load instructions per slot (vmcnt bookkeeping)
     Frag<T> r[RING][3];
     __amdgpu_buffer_rsrc_t rsrc;

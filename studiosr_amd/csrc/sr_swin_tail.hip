@@ -16,6 +16,14 @@
 namespace {
 
 constexpr int TAIL_SLOTS = 30;  // 6 proj, then per hidden half 6 fc1 + 6 fc2
+// HAT's launches are 256..1024 workgroups, i.e. one to four per CU with nothing else resident: weights four slots ahead (two workgroups
+// per CU by registers) instead of sr_swin_block's two: -2.7 % on the x4 b4 forward, +-0 at b16 (SR_TAIL_DIST / SR_TAIL_WGS: A/B knobs)
+#ifndef SR_TAIL_DIST
+#define SR_TAIL_DIST 4
+#endif
+#ifndef SR_TAIL_WGS
+#define SR_TAIL_WGS 2
+#endif
 
 struct SwinTailDev {
     SrSwinTail a;
@@ -33,7 +41,7 @@ SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void sr_swin_tail_kernel(SwinTailDev dv) {
+__global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTailDev dv) {
     static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
     const SrSwinTail& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,11 +87,11 @@ __global__ __launch_bounds__(256, 3) void sr_swin_tail_kernel(SwinTailDev dv) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    WStream<T, TAIL_SLOTS> ws;
+    WStream<T, TAIL_SLOTS, SR_TAIL_DIST> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, TAIL_SLOTS * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
     ws.wave_frag = w * 3;
 #pragma unroll
-    for (int s0 = 0; s0 < WStream<T, TAIL_SLOTS>::DIST; ++s0) ws.load(s0, lane);
+    for (int s0 = 0; s0 < SR_TAIL_DIST; ++s0) ws.load(s0, lane);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
     f32x4 gt[3];
@@ -221,14 +229,53 @@ __global__ __launch_bounds__(256, 3) void sr_swin_tail_kernel(SwinTailDev dv) {
         });
     }
 
-    // ---- store: accumulator layout -> LDS tile -> 16 full rows per wave
+    // ---- store: accumulator layout -> LDS tile -> 16 full rows per wave; optionally LayerNorm(out) with an affine as a bf16 side output
+    //      (HAT: norm1 of the NEXT block, the input of its CAB convolutions, hat.py:165-170 -- saves that block's LayerNorm launch)
     relane();
-    BLOCK_SYNC();
+    if (a.n1) {
+        float q1[4], q2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];
+            f32x4 t2 = x1[m][0] * x1[m][0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t2[r] = __builtin_fmaf(x1[m][2][r], x1[m][2][r], __builtin_fmaf(x1[m][1][r], x1[m][1][r], t2[r]));
+            q1[m] = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+            q2[m] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+        }
+        const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);
+        const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
+        *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);  // (LayerNorm2's partials were consumed many barriers ago)
+    }
+    BLOCK_SYNC();  // every wave has read its last hidden fragments: the tile region is free
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
 #pragma unroll
         for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xm + n * 64) = x1[m][n];
+    }
+    if (a.n1) {
+        f32x4 gm[3], bt[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            gm[n] = *reinterpret_cast<const f32x4*>(a.n1_gamma + w * 48 + ag * 4 + n * 16);
+            bt[n] = *reinterpret_cast<const f32x4*>(a.n1_beta + w * 48 + ag * 4 + n * 16);
+        }
+        const float inv = 1.0f / (float)a.C;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
+            const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
+            bf16* nrow = reinterpret_cast<bf16*>(a.n1) + (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean) * rstd, gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
+                *reinterpret_cast<bf16x4*>(nrow + n * 16) = cvt4(nv);
+            }
+        }
     }
     BLOCK_SYNC();
     {
@@ -255,6 +302,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_tail: bad geometry");
     SR_REQUIRE(!a.y || (a.gate && a.ldy >= a.Cp && a.ldy % 4 == 0 && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate, ldy, ld_gate");
+    SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0), "sr_swin_tail: the LayerNorm side output needs n1_gamma, n1_beta, ldn");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;
     dv.a = a;

@@ -39,6 +39,7 @@ from .swinir import (
     pack_attention,
     pack_ln,
     pack_mlp,
+    pack_qkv_stream,
     pack_tail_stream,
     run_mlp,
     run_swin_tail,
@@ -226,6 +227,7 @@ class HAT(Model):
                 e.update(pack_attention(blk.attn, geo, dt, rpi=self.relative_position_index_SA, norm=blk.norm1))
                 e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
                 e.update(pack_tail_stream(blk.attn.proj, blk.mlp, blk.norm2, geo, dt))
+                e.update(pack_qkv_stream(blk.attn, blk.norm1, geo, dt))
                 cab = blk.conv_block.cab
                 e["cab1"] = packing.pack_conv3x3(cab[0].weight, cab[0].bias, Cp, packing.identity_idx(c3, c3p), dt)
                 e["cab2"] = packing.pack_conv3x3(cab[2].weight, cab[2].bias, c3p, ident, dt)
@@ -267,14 +269,16 @@ class HAT(Model):
             object.__setattr__(self, "_side", st)
         return st
 
-    def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt) -> None:
-        """t = HAB(t_in); t_in may be t (in place)."""
+    def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt, n1_ready: bool = False, next_ln=None) -> bool:
+        """t = HAB(t_in); t_in may be t (in place).
+        n1_ready: "hab.n1" already holds LayerNorm1(t_in) (written by the previous block's sr_swin_tail).  next_ln: norm1 (gamma, beta) of the
+        block that follows; returns True iff this block's tail kernel wrote that block's LayerNorm1 output into "hab.n1"."""
         B, H, W, Cp = t_in.shape
         f32 = torch.float32
         # conv branch on LayerNorm1(x)  (hat.py:165-170)
         n1 = ws_.get("hab.n1", (B, H, W, Cp), cdt)  # consumed only by the conv, which rounds to the compute dtype anyway
         unfused = not (ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sr_dtype(cdt)))  # run_window_msa will take its GEMM path
-        if not unfused:  # the one-kernel attention half writes t (= t_in when in place) before any join: LayerNorm1 must run ahead of it
+        if not unfused and not n1_ready:  # the one-kernel attention half writes t (= t_in when in place) before any join: LayerNorm1 must run ahead of it
             ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
@@ -293,7 +297,7 @@ class HAT(Model):
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            if unfused:
+            if unfused and not n1_ready:
                 ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
             conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
             conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
@@ -304,18 +308,22 @@ class HAT(Model):
         def join():  # the projection is the first launch that needs the conv branch
             if side is not main:
                 main.wait_stream(side)
-            return dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
+            d = dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
+            if next_ln is not None and n1.dtype == torch.bfloat16:  # n1's last reader (this block's first conv) has joined: the tail may overwrite it
+                d.update(n1=n1, n1_ln=next_ln)
+            return d
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
         used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True)
-        if used == "tail":  # projection + both residuals + LayerNorm2 + MLP ran as one launch (sr_swin_tail)
-            return
+        if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1) ran as one launch (sr_swin_tail)
+            return next_ln is not None and n1.dtype == torch.bfloat16
         if not used:
             # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
             if side is not main:
                 main.wait_stream(side)
             run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
         run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")
+        return False
 
     def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt) -> None:
         """t = OCAB(t) in place (hat.py:239-293)."""
@@ -377,8 +385,10 @@ class HAT(Model):
         for lp in P["layers"]:
             geo = lp["geo"]
             cur = ta
-            for bp in lp["blocks"]:
-                self._run_hab(bp, geo, P, cur, tb, ws_, cdt)
+            ready = False
+            for i, bp in enumerate(lp["blocks"]):
+                nxt = lp["blocks"][i + 1]["ln1"] if i + 1 < len(lp["blocks"]) else None
+                ready = self._run_hab(bp, geo, P, cur, tb, ws_, cdt, n1_ready=ready, next_ln=nxt)
                 cur = tb
             if cur is ta:
                 tb.copy_(ta)

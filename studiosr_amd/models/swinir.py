@@ -169,6 +169,20 @@ def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: Swi
     return dict(tail_stream=packing.pack_swin_tail_stream(proj.weight, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden))
 
 
+def pack_qkv_stream(attn: nn.Module, norm1: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
+    """Weight stream of sr_swin_qkv (ABI v6: LayerNorm1 + QKV projection in front of sr_window_attention; hat.py:164-176), bf16 path only."""
+    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws in (8, 16, 32)):
+        return {}
+    qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, norm1.weight, norm1.bias)
+    return dict(qkv_stream=packing.pack_swin_qkv_stream(qw, qb, geo.C, geo.heads))
+
+
+def swin_qkv_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
+    """SR_SWIN_QKV=0 keeps the QKV GEMM (A/B switch, read per call)."""
+    return ("qkv_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_QKV", "1") != "0"
+            and ops.swin_qkv_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, L.SR_BF16))
+
+
 def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_TAIL=0 keeps the projection GEMM + MLP kernel (A/B switch, read per call)."""
     return ("tail_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_TAIL", "1") != "0"
@@ -176,12 +190,18 @@ def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> b
 
 
 def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Tensor, shift: int, y_mode: int = L.Y_ROLL, extra: Optional[Dict] = None) -> None:
-    """t_out = x1 + MLP(LayerNorm2(x1)),  x1 = skip + proj(o) (+ gated second residual from `extra`, the sr_gemm skip2 fields)."""
+    """t_out = x1 + MLP(LayerNorm2(x1)),  x1 = skip + proj(o) (+ gated second residual from `extra`, the sr_gemm skip2 fields;
+    + the LayerNorm side output n1 = LN(t_out) * gamma + beta when extra carries n1 / n1_ln)."""
     B, H, W, Cp = skip.shape
     kw = {}
+    extra = dict(extra or {})
+    n1, n1_ln = extra.pop("n1", None), extra.pop("n1_ln", None)
+    if n1 is not None:
+        assert n1.dtype == torch.bfloat16 and n1.shape == skip.shape
+        kw.update(n1=n1.data_ptr(), n1_gamma=n1_ln[0].data_ptr(), n1_beta=n1_ln[1].data_ptr(), ldn=Cp)
     if extra:
         assert extra["skip2_dtype"] == L.SR_BF16 and extra["gate_rows"] == H * W
-        kw = dict(y=extra["skip2"], gate=extra["skip2_gate"], ldy=extra["ldskip2"], ld_gate=extra["ld_gate"])
+        kw.update(y=extra["skip2"], gate=extra["skip2_gate"], ldy=extra["ldskip2"], ld_gate=extra["ld_gate"])
     ops.swin_tail(
         x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=p["tail_stream"].data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
         C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
@@ -244,12 +264,16 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
-    ops.gemm(
-        A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
-        ln_beta=None if fold_ln(cdt) else ln[1].data_ptr(), ln_norm_only=int(fold_ln(cdt)), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
-        a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
-        H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5, y_mode=y_mode,
-    )
+    if swin_qkv_usable(p, geo, Cp, cdt):
+        ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
+                     Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=L.SR_BF16)
+    else:
+        ops.gemm(
+            A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
+            ln_beta=None if fold_ln(cdt) else ln[1].data_ptr(), ln_norm_only=int(fold_ln(cdt)), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(), M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp,
+            a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
+            H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5, y_mode=y_mode,
+        )
     ops.window_attention(
         q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
         hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
@@ -258,6 +282,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
         run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)
         return "tail"
+    extra.pop("n1", None), extra.pop("n1_ln", None)  # the LayerNorm side output exists only in sr_swin_tail
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,

@@ -85,6 +85,18 @@ def swin_block(**kw) -> None:
     L.check(L.lib().sr_swin_block(C.byref(a), _stream()), "sr_swin_block")
 
 
+def swin_qkv_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_swin_qkv_supported(C_, Cp, heads, hd_p, ws, compute_dtype))
+
+
+def swin_qkv(**kw) -> None:
+    """LayerNorm1 + QKV projection in front of sr_window_attention from one packed weight stream (ABI v6; hat.py:164-176)."""
+    a = L.SrSwinQkv()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_swin_qkv(C.byref(a), _stream()), "sr_swin_qkv")
+
+
 def swin_tail_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, Hp: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_swin_tail_supported(C_, Cp, heads, hd_p, ws, Hp, compute_dtype))
 

@@ -279,3 +279,30 @@ def pack_swin_tail_stream(proj_w: Tensor, fc1_w: Tensor, fc1_b: Optional[Tensor]
     zero = torch.zeros(3 * C, C, dtype=f32, device=dev)
     full = pack_swin_block_stream(zero, None, proj_w, None, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden)
     return torch.cat([proj, full.reshape(SWIN_STREAM_SLOTS, -1)[24:].reshape(-1)]).contiguous()
+
+
+SWIN_QKV_SLOTS = 18
+
+
+def pack_swin_qkv_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], C: int, heads: int) -> Tensor:
+    """The weight stream of sr_swin_qkv (include/studiosr_hip.h SrSwinQkv; hat.py:164-176, 55-83): 18 slots x 12 fragments x [64 lanes][8] bf16
+    -- per pass p (heads 2p, 2p+1) six K-chunk slots; wave w = (head 2p + (w >> 1), d-half w & 1) reads fragments 3w .. 3w+2 = its q, k, v
+    tiles.  qkv_w / qkv_b are the LayerNorm-folded fp32 matrices; the attention scale hd^-0.5 goes into the q rows (plain exp softmax in the
+    attention kernel: no log2(e) here), all three biases as hi + lo bf16 pairs into the columns of the constant-one channels C, C+1."""
+    assert C == 180 and heads == 6, "sr_swin_qkv geometry"
+    hd, hdp, Cp = C // heads, 32, 192
+    dev = qkv_w.device
+    f32 = torch.float32
+    qkv_w = qkv_w.detach().to(f32)
+    qkv_b = torch.zeros(3 * C, dtype=f32, device=dev) if qkv_b is None else qkv_b.detach().to(f32)
+    M = torch.zeros(3, heads, hdp, Cp, dtype=f32, device=dev)
+    M[:, :, :hd, :C] = qkv_w.reshape(3, heads, hd, C)
+    b = qkv_b.reshape(3, heads, hd).clone()
+    M[0] *= hd ** -0.5
+    b[0] *= hd ** -0.5
+    b_hi, b_lo = _bf16_hi_lo(b)
+    M[:, :, :hd, C] = b_hi
+    M[:, :, :hd, C + 1] = b_lo
+    # M[t, head = 2p + hh, d = 16 half + i, k = 32 c + 8 g + j] -> [p, c, 3 (2 hh + half) + t, 16 g + i, j]
+    out = M.reshape(3, 3, 2, 2, 16, 6, 4, 8).permute(1, 5, 2, 3, 0, 6, 4, 7).reshape(3, 6, 12, 64, 8)
+    return out.to(torch.bfloat16).reshape(-1).contiguous()

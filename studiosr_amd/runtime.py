@@ -80,6 +80,9 @@ class Workspace:
     def __init__(self, device: torch.device, budget_bytes: int = 0) -> None:
         import os
 
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:  # "cuda" must compare equal to a tensor's "cuda:N" (Model._workspace)
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.bufs: Dict[Tuple, Tensor] = {}
         self.guard = bool(os.environ.get("SR_WS_GUARD"))

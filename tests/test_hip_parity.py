@@ -453,17 +453,20 @@ def test_hat_full_width_against_oracle(prec, tol, ws):
     assert float((y - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
-def test_swin_tail_kernel_equals_the_projection_gemm_and_mlp_kernel(monkeypatch):
-    """sr_swin_tail (projection + shortcut + gated CAB term + LayerNorm2 + MLP in one launch, ABI v6) against the launches it replaces
-    (sr_gemm with the gated second residual, sr_mlp_fused) inside the same HAT forward: 16 x 16 windows in four 64-token parts, shifted
+def test_swin_qkv_and_tail_kernels_equal_the_gemm_path(monkeypatch):
+    """sr_swin_qkv (LayerNorm1 + QKV) and sr_swin_tail (projection + shortcut + gated CAB term + LayerNorm2 + MLP + the next block's
+    LayerNorm1 in one launch), ABI v6, against the launches they replace (sr_gemm SR_EPI_QKV; sr_gemm with the gated second residual,
+    sr_mlp_fused, sr_layernorm_to) inside the same HAT forward: 16 x 16 windows in four 64-token parts, shifted
     and unshifted blocks, a non-square image, the overlapping cross-attention block's tail; and against the CPU oracle."""
     torch.manual_seed(11)
     m = _randomised(S.HAT(scale=2, depths=[2, 2], num_heads=[6, 6], window_size=16), seed=11).to(DEV).eval().set_precision("bf16")
     x = torch.rand(2, 3, 48, 32)
     with torch.no_grad():
         monkeypatch.setenv("SR_SWIN_TAIL", "1")
+        monkeypatch.setenv("SR_SWIN_QKV", "1")
         y1 = m(x.to(DEV)).cpu()
-        monkeypatch.setenv("SR_SWIN_TAIL", "0")
+        monkeypatch.setenv("SR_SWIN_TAIL", "0")  # the projection GEMM + MLP kernel, LayerNorm1 launches for the conv branch
+        monkeypatch.setenv("SR_SWIN_QKV", "0")   # the QKV GEMM
         y0 = m(x.to(DEV)).cpu()
     sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
     ref = OM.hat_forward(sd, x, m.get_model_config())

@@ -5,7 +5,8 @@ set -eo pipefail
 cd "$(dirname "$0")/../studiosr_amd/csrc"
 mkdir -p ../lib/variants
 NAME=$1; shift
-OBJS=$(ls ../lib/obj/*.o | grep -v sr_swin_block3.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops "$@" -c sr_swin_block3.hip -o /tmp/sr_swin_block3_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$NAME.so $OBJS /tmp/sr_swin_block3_$NAME.o
+SRC=${SR_EXP_SRC:-sr_swin_block3}  # SR_EXP_SRC=sr_swin_tail builds a variant of another translation unit
+OBJS=$(ls ../lib/obj/*.o | grep -v $SRC.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops "$@" -c $SRC.hip -o /tmp/${SRC}_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$NAME.so $OBJS /tmp/${SRC}_$NAME.o
 echo built $NAME
