@@ -6,8 +6,8 @@
 // roll back = the row gather of the block kernel).  Replaces the projection GEMM (sr_gemm, 25 us at HAT's 4 x 64 x 64 tokens) and the
 // MLP kernel (16.5 us) with one pass of the stream-form kernel's own stages (sr_swin_stream.h):
 //   * one workgroup = 64 consecutive window-order tokens (a quarter of a 16 x 16 window), 4 waves, wave w owns output channels [48 w, +48);
-//   * O reaches LDS as the K-group-major operand image by a gathering LDS-DMA (lane = token, one 16-B k-group per instruction): no
-//     registers, conflict-free fragment reads;
+//   * O reaches LDS by coalesced LDS-DMA (no registers) as a token-major image with a 400-B row stride: conflict-free fragment reads
+//     (a gathering DMA straight into the K-group-major layout -- lane = token -- took 500 cycles per instruction to issue);
 //   * projection = 6 uniform steps, MLP = 2 x (6 fc1 + 6 fc2) steps from ONE 30-slot weight stream two slots ahead in registers;
 //     fc1 / fc2 biases ride on the constant-one pad channels exactly as in sr_swin_block (same slots 24..47 of that stream);
 //   * x1 never leaves the registers; the result leaves through the LDS row tile as full 768-B rows.
@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int TAIL_SLOTS = 30;  // 6 proj, then per hidden half 6 fc1 + 6 fc2
+constexpr int OROW = 384;       // bytes per attention-output row (6 heads x 32 features bf16)
+constexpr int OSTRIDE = 400;    // its row stride in LDS
+static_assert(NTOK * OSTRIDE == 25 * 1024 && NTOK * OSTRIDE <= CELLS_A * 16 + 1024, "25 one-KiB pieces; the image ends inside the (still unused) hidden-half region");
 // HAT's launches are 256..1024 workgroups, i.e. one to four per CU with nothing else resident: weights four slots ahead (two workgroups
 // per CU by registers) instead of sr_swin_block's two: -2.7 % on the x4 b4 forward, +-0 at b16 (SR_TAIL_DIST / SR_TAIL_WGS: A/B knobs)
 #ifndef SR_TAIL_DIST
@@ -25,13 +28,25 @@ constexpr int TAIL_SLOTS = 30;  // 6 proj, then per hidden half 6 fc1 + 6 fc2
 #define SR_TAIL_WGS 2
 #endif
 
+#ifdef SR_STAMPS
+__device__ unsigned long long sr_dbg_tail[32];
+#define TSTAMP(i)                                                                                 \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (blockIdx.x == 7 && threadIdx.x == 0) sr_dbg_tail[i] = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 struct SwinTailDev {
     SrSwinTail a;
     FastDiv div_parts_img, div_parts_win, div_nwx;  // 64-token parts per image, per window; windows per row
     int ws_log2;
 };
 
-// one k-group (16 B per token) of 64 consecutive O rows -> 64 consecutive image cells: lane = token
+// 16 B per lane from base + lane_off to LDS at lds_dst + 16 lane
 SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -45,7 +60,7 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
     const SrSwinTail& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);  // O image [24 k-groups][64 tokens], then the LayerNorm2 image
+    Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);  // O image (token-major, 400-B rows) first, then the LayerNorm2 image [24 k-groups][64 tokens]
     Frag<T>* Himg = Aimg + CELLS_A;                    // hidden half [24][64]
     float* red = reinterpret_cast<float*>(smem + Lds<T>::RED_OFF);
 
@@ -75,26 +90,35 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         return ((int)bimg * a.H + y) * a.W + x;
     };
 
+    TSTAMP(0);
     // ---- loads, all in flight together: O image (LDS-DMA), the first weight slots, x / y in the accumulator layout, gate and bias vectors
     {
+        // O: 64 rows of 384 B, contiguous in memory -> token-major LDS image with a 400-B row stride (conflict-free fragment reads): 25
+        // coalesced 1-KiB LDS-DMA pieces; cell q = 64 j + lane of piece j is 16-B column q % 25 of row q / 25 (column 24 = padding, masked)
         const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-        const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NTOK * (a.heads * a.hd_p) * 2;
-        const int lane_off = lane * (a.heads * a.hd_p) * 2;
+        const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NTOK * OROW;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int kg = 6 * w + i;
-            dma_gather16(orow + kg * 16, lane_off, __builtin_amdgcn_readfirstlane(img_lds + kg * NTOK * 16));
+        for (int i = 0; i < 7; ++i) {
+            const int j = w + 4 * i;
+            if (j < 25) {
+                const int q = j * 64 + lane;
+                const int row = (q * 1311) >> 15;  // q / 25 for q < 1600
+                const int cc = q - row * 25;
+                if (cc < 24) dma_gather16(orow, row * OROW + cc * 16, __builtin_amdgcn_readfirstlane(img_lds + j * 1024));
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(15);
     WStream<T, TAIL_SLOTS, SR_TAIL_DIST> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, TAIL_SLOTS * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
     ws.wave_frag = w * 3;
 #pragma unroll
     for (int s0 = 0; s0 < SR_TAIL_DIST; ++s0) ws.load(s0, lane);
     __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(16);
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
-    f32x4 gt[3];
+    f32x4 gt[3], bp[3];
     bf16x4 yv[4][3];
     const int ch0 = w * 48 + ag * 4;
     {
@@ -105,6 +129,8 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) x1[m][n] = *reinterpret_cast<const f32x4*>(a.x + (size_t)prow[m] * a.ldx + ch0 + n * 16);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bp[n] = *reinterpret_cast<const f32x4*>(a.bproj + ch0 + n * 16);
         if (a.y) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)bimg * a.ld_gate + ch0 + n * 16);
@@ -116,8 +142,10 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     }
     __builtin_amdgcn_sched_barrier(0);
     // everything was issued together (one latency); the O image must be complete before the barrier, x and slot 0 are needed right behind it
+    TSTAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BLOCK_SYNC();
+    TSTAMP(2);
 
     auto loada_img = [&](const Frag<T>* img) {
         return [&, img](int c, int h, Frag<T> (&av)[2]) {
@@ -128,18 +156,21 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     };
 
     // ---- projection on top of the shortcut: x1 += O @ Wproj^T (K = 6 heads x 32 features, the pad features are 0 on both sides)
-    ws.template run<6>(0, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
+    auto loada_o = [&](int c, int h, Frag<T> (&av)[2]) {
+        const char* ob = smem + (h * 32 + ar) * OSTRIDE + (c * 4 + ag) * 16;
+        av[0] = *reinterpret_cast<const Frag<T>*>(ob);
+        av[1] = *reinterpret_cast<const Frag<T>*>(ob + 16 * OSTRIDE);
+    };
+    ws.template run<6>(0, lane, loada_o, [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) mma(b[n], ov[m], x1[2 * h + m][n]);
     });
     __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(3);
     relane();
     {
-        f32x4 bp[3];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) bp[n] = *reinterpret_cast<const f32x4*>(a.bproj + w * 48 + ag * 4 + n * 16);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         }
     }
     BLOCK_SYNC();
+    TSTAMP(4);
 
     // ---- MLP in two hidden halves of 192 columns (sr_swin_block3.hip, same slots)
 #pragma unroll
@@ -209,6 +241,7 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
                         mma(b[n], av[m], acc[2 * h + m][n]);
                 }
         });
+        TSTAMP(5 + 4 * hf);
         if (hf == 1) BLOCK_SYNC();  // fc2 of the first half has read the hidden image everywhere
 #pragma unroll
         for (int n = 0; n < 3; ++n)
@@ -220,15 +253,19 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
                 st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, g);
             }
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(6 + 4 * hf);
         BLOCK_SYNC();
+        TSTAMP(7 + 4 * hf);
         ws.template run<6>(12 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&hv)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 3; ++n) mma(b[n], hv[m], x1[2 * h + m][n]);
         });
+        TSTAMP(8 + 4 * hf);
     }
 
+    TSTAMP(13);
     // ---- store: accumulator layout -> LDS tile -> 16 full rows per wave; optionally LayerNorm(out) with an affine as a bf16 side output
     //      (HAT: norm1 of the NEXT block, the input of its CAB convolutions, hat.py:165-170 -- saves that block's LayerNorm launch)
     relane();
@@ -286,9 +323,16 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
 #pragma unroll
         for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
     }
+    TSTAMP(14);
 }
 
 }  // namespace
+
+#ifdef SR_STAMPS
+extern "C" int sr_debug_tail_stamps(unsigned long long* host32) {
+    return hipMemcpyFromSymbol(host32, HIP_SYMBOL(sr_dbg_tail), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
     return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16 || ws == 32) && Hp == 384) ? 1 : 0;

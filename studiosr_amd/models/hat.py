@@ -294,18 +294,34 @@ class HAT(Model):
         side = self._side_stream(t_in.device) if self.dual_stream else main
         gate = ws_.get("hab.gate", (B, Cp), f32)
         w1, b1, w2, b2 = bp["ca"]
-        if side is not main:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if unfused and not n1_ready:
-                ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
-            conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
-            conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
-            # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
-            ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
-                             C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
+        def conv_branch():
+            with torch.cuda.stream(side):
+                if unfused and not n1_ready:
+                    ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+                conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
+                conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
+                # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
+                ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
+                                 C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
+
+        # Launch ORDER: a captured HIP graph keeps the FIRST-created successor of a node on that node's queue and moves the others to another
+        # queue behind an ~8-13 us cross-queue signal.  The attention branch (QKV, attention: the longer chain once QKV is sr_swin_qkv) must
+        # therefore be created before the conv branch: the fork point is recorded first, the conv branch is enqueued from the projection hook.
+        # (SR_HAT_SIDE_FIRST=1: the round-2 order, conv branch first.)
+        late = unfused and side is not main and os.environ.get("SR_HAT_SIDE_FIRST", "0") != "1"
+        fork = None
+        if late:
+            fork = torch.cuda.Event()
+            fork.record(main)
+        else:
+            if side is not main:
+                side.wait_stream(main)
+            conv_branch()
 
         def join():  # the projection is the first launch that needs the conv branch
+            if late:
+                side.wait_event(fork)
+                conv_branch()
             if side is not main:
                 main.wait_stream(side)
             d = dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
