@@ -183,6 +183,13 @@ typedef struct SrSwinTail {
     const float* n1_gamma; /* [Cp] fp32, pad 0 */
     const float* n1_beta;
     int ldn;
+    /* optional in-kernel gate (replaces sr_channel_gate + `gate`): when pool_partial != NULL every workgroup recomputes
+     * gate[c] = y_scale * sigmoid(W2 relu(W1 mean + b1) + b2) of its image from the per-tile channel sums of the CAB convolution
+     * (same code and arithmetic as sr_channel_gate; fields as in SrChannelAttn). */
+    const float* pool_partial; /* [B, ca_n_tiles, Cp] or NULL */
+    const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;
+    int ca_Cr, ca_n_tiles;
+    float y_scale;
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);

@@ -74,6 +74,7 @@ class SrSwinTail(C.Structure):
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldy", _i), ("ld_gate", _i), ("heads", _i), ("hd_p", _i), ("ws", _i),
         ("shift", _i), ("Hp", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
         ("n1", _vp), ("n1_gamma", _vp), ("n1_beta", _vp), ("ldn", _i),
+        ("pool_partial", _vp), ("ca_w1", _vp), ("ca_b1", _vp), ("ca_w2", _vp), ("ca_b2", _vp), ("ca_Cr", _i), ("ca_n_tiles", _i), ("y_scale", _f),
     ]
 
 

@@ -12,6 +12,7 @@
 //     fc1 / fc2 biases ride on the constant-one pad channels exactly as in sr_swin_block (same slots 24..47 of that stream);
 //   * x1 never leaves the registers; the result leaves through the LDS row tile as full 768-B rows.
 #include "sr_swin_stream.h"
+#include "sr_ca.h"
 
 namespace {
 
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
 #pragma unroll
         for (int n = 0; n < 3; ++n) bp[n] = *reinterpret_cast<const f32x4*>(a.bproj + ch0 + n * 16);
         if (a.y) {
+            if (!a.pool_partial) {
 #pragma unroll
-            for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)bimg * a.ld_gate + ch0 + n * 16);
+                for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)bimg * a.ld_gate + ch0 + n * 16);
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -141,6 +144,17 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (a.y && a.pool_partial) {
+        // the channel-attention squeeze of this image (hat.py:25-38: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid, times conv_scale), recomputed per
+        // workgroup from the pool partials of the CAB convolution while the loads above fly: replaces the sr_channel_gate launch at the end of
+        // the conv branch.  Scratch behind the O image, in the hidden-half region (unused until the MLP).
+        SrChannelAttn ca;
+        ca.pool_partial = a.pool_partial; ca.w1 = a.ca_w1; ca.b1 = a.ca_b1; ca.w2 = a.ca_w2; ca.b2 = a.ca_b2;
+        ca.B = a.B; ca.H = a.H; ca.W = a.W; ca.C = a.C; ca.C_p = a.Cp; ca.Cr = a.ca_Cr; ca.n_tiles = a.ca_n_tiles; ca.y_scale = a.y_scale;
+        const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + NTOK * OSTRIDE));
+#pragma unroll
+        for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
+    }
     // everything was issued together (one latency); the O image must be complete before the barrier, x and slot 0 are needed right behind it
     TSTAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,7 +359,11 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_tail: bad geometry");
-    SR_REQUIRE(!a.y || (a.gate && a.ldy >= a.Cp && a.ldy % 4 == 0 && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate, ldy, ld_gate");
+    SR_REQUIRE(!a.y || (a.ldy >= a.Cp && a.ldy % 4 == 0), "sr_swin_tail: gated second residual needs ldy");
+    SR_REQUIRE(!a.y || a.pool_partial || (a.gate && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate / ld_gate or the pool partials");
+    SR_REQUIRE(!a.y || !a.pool_partial || (a.ca_w1 && a.ca_b1 && a.ca_w2 && a.ca_b2 && a.ca_Cr > 0 && a.ca_n_tiles > 0 &&
+                                           (2 * a.Cp + a.ca_Cr + 8 * a.Cp) * 4 <= 22 * 1024),
+               "sr_swin_tail: in-kernel gate needs the squeeze weights (scratch: 22 KiB)");
     SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0), "sr_swin_tail: the LayerNorm side output needs n1_gamma, n1_beta, ldn");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;

@@ -294,6 +294,8 @@ class HAT(Model):
         side = self._side_stream(t_in.device) if self.dual_stream else main
         gate = ws_.get("hab.gate", (B, Cp), f32)
         w1, b1, w2, b2 = bp["ca"]
+        gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and os.environ.get("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
+
         def conv_branch():
             with torch.cuda.stream(side):
                 if unfused and not n1_ready:
@@ -301,8 +303,10 @@ class HAT(Model):
                 conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
                 conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
                 # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
-                ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
-                                 C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
+                # (sr_swin_tail recomputes it per workgroup from the pool partials instead: one launch less at the end of this branch)
+                if not gate_in_tail:
+                    ops.channel_gate(gate, pool_partial=pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), B=B, H=H, W=W,
+                                     C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
 
         # Launch ORDER: a captured HIP graph keeps the FIRST-created successor of a node on that node's queue and moves the others to another
         # queue behind an ~8-13 us cross-queue signal.  The attention branch (QKV, attention: the longer chain once QKV is sr_swin_qkv) must
@@ -325,6 +329,9 @@ class HAT(Model):
             if side is not main:
                 main.wait_stream(side)
             d = dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
+            if gate_in_tail:
+                d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
+                                 ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))
             if next_ln is not None and n1.dtype == torch.bfloat16:  # n1's last reader (this block's first conv) has joined: the tail may overwrite it
                 d.update(n1=n1, n1_ln=next_ln)
             return d

@@ -196,6 +196,7 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     kw = {}
     extra = dict(extra or {})
     n1, n1_ln = extra.pop("n1", None), extra.pop("n1_ln", None)
+    kw.update(extra.pop("ca", None) or {})  # in-kernel channel-attention gate (pool partials + squeeze weights)
     if n1 is not None:
         assert n1.dtype == torch.bfloat16 and n1.shape == skip.shape
         kw.update(n1=n1.data_ptr(), n1_gamma=n1_ln[0].data_ptr(), n1_beta=n1_ln[1].data_ptr(), ldn=Cp)
@@ -282,7 +283,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
         run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)
         return "tail"
-    extra.pop("n1", None), extra.pop("n1_ln", None)  # the LayerNorm side output exists only in sr_swin_tail
+    extra.pop("n1", None), extra.pop("n1_ln", None), extra.pop("ca", None)  # the LayerNorm side output / in-kernel gate exist only in sr_swin_tail
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,
