@@ -270,6 +270,24 @@ typedef struct SrRcab {
 int sr_rcab_conv_pair(const SrRcab* a, void* stream);
 int sr_rcab_pool_tiles(int H, int W); /* n_tiles of pool_partial */
 
+typedef struct SrCab {
+    /* y = conv2(GELU(conv1(x))): the body of HAT's CAB (hat.py:41-49: Conv2d(180, 60, 3), GELU, Conv2d(60, 180, 3)) in ONE launch, ABI v6 --
+     * the intermediate stays in LDS -- plus per-tile channel sums of y for the ChannelAttention squeeze (sr_channel_gate / sr_swin_tail).
+     * bf16 NHWC in and out, fp32 accumulate; weights packed as for sr_conv3x3 (packing.pack_conv3x3). */
+    const void* x;        /* NHWC [B,H,W,Cin_p] bf16 (HAT: LayerNorm1 output) */
+    const void* w1p;      /* conv1: Cout_p = Cmid_p rows, Cin_p input channels */
+    const float* b1;      /* [Cmid_p] */
+    const void* w2p;      /* conv2: Cout_p rows, Cmid_p input channels */
+    const float* b2;      /* [Cout_p] */
+    void* y;              /* NHWC [B,H,W,Cout_p] bf16; must not alias x */
+    float* pool_partial;  /* optional [B, sr_cab_pool_tiles(H, W), Cout_p] */
+    int B, H, W, Cin_p, Cmid_p, Cout_p;  /* 192, 64, 192 */
+    int dtype;            /* SR_BF16 */
+} SrCab;
+int sr_cab_supported(int Cin_p, int Cmid_p, int Cout_p, int dtype);
+int sr_cab_pool_tiles(int H, int W);
+int sr_cab_fused(const SrCab* a, void* stream);
+
 typedef struct SrWindowAttn {
     /* softmax(q k^T + bias[head] + shift mask) v per (window, head)
      * (swinir.py:83-102; common.py:250-274; hat.py:90-107).  q is pre-scaled (scale folded into Wq). */

@@ -60,6 +60,13 @@ class SrSwinBlock(C.Structure):
     ]
 
 
+class SrCab(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cmid_p", _i), ("Cout_p", _i), ("dtype", _i),
+    ]
+
+
 class SrSwinQkv(C.Structure):
     _fields_ = [
         ("x", _vp), ("q", _vp), ("k", _vp), ("vt", _vp), ("wstream", _vp),
@@ -158,6 +165,9 @@ SYMBOLS = {
     "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
     "sr_swin_block_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_block": (_i, [C.POINTER(SrSwinBlock), _vp]),
+    "sr_cab_supported": (_i, [_i, _i, _i, _i]),
+    "sr_cab_pool_tiles": (_i, [_i, _i]),
+    "sr_cab_fused": (_i, [C.POINTER(SrCab), _vp]),
     "sr_swin_qkv_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sr_swin_qkv": (_i, [C.POINTER(SrSwinQkv), _vp]),
     "sr_swin_tail_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),

@@ -284,7 +284,9 @@ class HAT(Model):
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
         # small batches: 4-row conv tiles (twice the workgroups) also for the conv with the pool side output
         th = 4 if (cdt == torch.bfloat16 and ((W + 15) // 16) * ((H + 7) // 8) * B < 256) else 0
-        n_tiles = ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th)
+        # conv -> GELU -> conv as ONE launch (sr_cab_fused; SR_CAB_FUSED=0: two sr_conv3x3 launches)
+        cab_fused = cdt == torch.bfloat16 and os.environ.get("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, L.SR_BF16)
+        n_tiles = ops.cab_pool_tiles(H, W) if cab_fused else ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th)
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
         # tile sizes of this model every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention
@@ -300,8 +302,13 @@ class HAT(Model):
             with torch.cuda.stream(side):
                 if unfused and not n1_ready:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
-                conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
-                conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
+                if cab_fused:
+                    ops.cab_fused(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(),
+                                  b2=bp["cab2"][1].data_ptr(), y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"],
+                                  Cout_p=Cp, dtype=L.SR_BF16)
+                else:
+                    conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
+                    conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
                 # conv_scale * sigmoid(squeeze MLP(mean(y))) per (image, channel): consumed by the projection GEMM's gated second residual
                 # (sr_swin_tail recomputes it per workgroup from the pool partials instead: one launch less at the end of this branch)
                 if not gate_in_tail:

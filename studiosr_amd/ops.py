@@ -85,6 +85,22 @@ def swin_block(**kw) -> None:
     L.check(L.lib().sr_swin_block(C.byref(a), _stream()), "sr_swin_block")
 
 
+def cab_supported(cin_p: int, cmid_p: int, cout_p: int, dtype: int) -> bool:
+    return bool(L.lib().sr_cab_supported(cin_p, cmid_p, cout_p, dtype))
+
+
+def cab_pool_tiles(H: int, W: int) -> int:
+    return int(L.lib().sr_cab_pool_tiles(H, W))
+
+
+def cab_fused(**kw) -> None:
+    """conv -> GELU -> conv of HAT's CAB in one launch, with the pool partials of the channel-attention squeeze (ABI v6; hat.py:41-49)."""
+    a = L.SrCab()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_cab_fused(C.byref(a), _stream()), "sr_cab_fused")
+
+
 def swin_qkv_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_swin_qkv_supported(C_, Cp, heads, hd_p, ws, compute_dtype))
 

@@ -467,6 +467,7 @@ def test_swin_qkv_and_tail_kernels_equal_the_gemm_path(monkeypatch):
         y1 = m(x.to(DEV)).cpu()
         monkeypatch.setenv("SR_SWIN_TAIL", "0")  # the projection GEMM + MLP kernel, LayerNorm1 launches for the conv branch
         monkeypatch.setenv("SR_SWIN_QKV", "0")   # the QKV GEMM
+        monkeypatch.setenv("SR_CAB_FUSED", "0")  # two sr_conv3x3 launches + sr_channel_gate
         y0 = m(x.to(DEV)).cpu()
     sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in m.state_dict().items()}
     ref = OM.hat_forward(sd, x, m.get_model_config())
@@ -572,6 +573,46 @@ def test_rgb_tail_conv_persistent_kernel_against_conv2d(cin, shape):
     ref = (ref * fs.view(1, 3, 1, 1) + fb.view(1, 3, 1, 1))[:, :, :fh, :fw]
     assert not torch.isnan(out).any()
     assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_cab_fused_equals_two_conv_launches_and_a_torch_reference():
+    """sr_cab_fused (hat.py:41-49: conv 180 -> 60, GELU, conv 60 -> 180 in one launch, intermediate in LDS, per-tile pool sums) against the
+    two sr_conv3x3 launches it replaces (same packed weights) and against torch convs on the bf16-rounded operands, on an image that is not a
+    multiple of the 14 x 6 tile; the pool partials must add up to the channel sums of y."""
+    from studiosr_amd.models.common import conv_call
+
+    torch.manual_seed(23)
+    B, H, W, C, Cp, c3, c3p = 2, 37, 50, 180, 192, 60, 64
+    w1, b1 = torch.randn(c3, C, 3, 3, device=DEV) * 0.03, torch.randn(c3, device=DEV) * 0.1
+    w2, b2 = torch.randn(C, c3, 3, 3, device=DEV) * 0.05, torch.randn(C, device=DEV) * 0.1
+    p1 = packing.pack_conv3x3(w1, b1, Cp, packing.identity_idx(c3, c3p), torch.bfloat16)
+    p2 = packing.pack_conv3x3(w2, b2, c3p, packing.identity_idx(C, Cp), torch.bfloat16)
+    x = torch.randn(B, H, W, Cp, device=DEV).to(torch.bfloat16)
+    x[..., C:] = 0
+    assert ops.cab_supported(Cp, c3p, Cp, L.SR_BF16)
+    nt = ops.cab_pool_tiles(H, W)
+    assert nt == 4 * 7
+    y = torch.full((B, H, W, Cp), float("nan"), device=DEV).to(torch.bfloat16)
+    pool = torch.full((B, nt, Cp), float("nan"), device=DEV)
+    ops.cab_fused(x=x.data_ptr(), w1p=p1[0].data_ptr(), b1=p1[1].data_ptr(), w2p=p2[0].data_ptr(), b2=p2[1].data_ptr(), y=y.data_ptr(),
+                  pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=c3p, Cout_p=Cp, dtype=L.SR_BF16)
+    mid = torch.empty(B, H, W, c3p, device=DEV).to(torch.bfloat16)
+    want = torch.empty_like(y)
+    conv_call(x, *p1, mid, torch.bfloat16, act=L.ACT_GELU)
+    conv_call(mid, *p2, want, torch.bfloat16)
+    torch.cuda.synchronize()
+    yf, wf = y.float(), want.float()
+    assert not torch.isnan(yf).any() and not torch.isnan(pool).any()
+    assert float(yf[..., C:].abs().max()) == 0.0
+    scale = float(wf.abs().max())
+    assert float((yf - wf).abs().max()) <= 1.0e-2 * scale  # the intermediate is rounded to bf16 in both; GELU: erf polynomial vs erff
+    # torch reference on the same rounded operands (fp32 accumulate, bf16 intermediate)
+    xr = x.float()[..., :C].permute(0, 3, 1, 2)
+    r1 = torch.nn.functional.gelu(torch.nn.functional.conv2d(xr, w1.to(torch.bfloat16).float(), b1, padding=1)).to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv2d(r1, w2.to(torch.bfloat16).float(), b2, padding=1).permute(0, 2, 3, 1)
+    assert float((yf[..., :C] - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())
+    # pool partials: fp32 sums of the un-rounded outputs over each tile's valid pixels
+    assert torch.allclose(pool.sum(1)[:, :C], ref.sum((1, 2)), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) * 8)
 
 
 def test_gated_second_residual_of_the_projection_gemm_equals_channel_attention():
