@@ -293,7 +293,7 @@ class HAT(Model):
         # branch and joins before the projection GEMM -- the first writer of t (which may be t_in) and the consumer of the conv branch.
         # Also valid under HIP-graph capture.
         main = torch.cuda.current_stream(t_in.device)
-        side = self._side_stream(t_in.device) if self.dual_stream else main
+        side = self._side_stream(t_in.device) if (self.dual_stream and os.environ.get("SR_HAT_DUAL", "1") != "0") else main
         gate = ws_.get("hab.gate", (B, Cp), f32)
         w1, b1, w2, b2 = bp["ca"]
         gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and os.environ.get("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
