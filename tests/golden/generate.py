@@ -312,9 +312,21 @@ def grads(M) -> None:
         arrs.update(sd_arrays(model))
         for n_, p_ in model.named_parameters():
             if p_.grad is not None:
-                arrs["grad/" + n_] = p_.grad.numpy()
+                arrs["grad/" + n_] = p_.grad.numpy().copy()
         if tag in ("swinfir", "han"):
             arrs["y_eval"] = y_eval
+        if tag in ("swinir", "hat", "edsr", "rcan"):
+            # the same step under the reference Trainer's autocast context (trainer.py:80,102; CPU autocast as its proxy here): how far the
+            # REFERENCE's own bf16 step sits from its fp32 step -- the yardstick for our bf16-operand step (tests/test_training.py)
+            model.zero_grad()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out_ac = model(x)
+                loss_ac = F.l1_loss(out_ac.float(), tgt)
+            loss_ac.backward()
+            arrs["loss_ac"] = np.float64(loss_ac.item())
+            for n_, p_ in model.named_parameters():
+                if p_.grad is not None:
+                    arrs["grad_ac/" + n_] = p_.grad.float().numpy().copy()
         save(f"f15_grads_{tag}", **arrs)
 
 
