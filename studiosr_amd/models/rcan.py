@@ -170,25 +170,33 @@ class RCAN(Model):
             from ..runtime import WorkspaceView
 
             main = torch.cuda.current_stream(x.device)
-            side = self._side_stream(x.device)
-            h = B // 2
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._forward_into(P, x[h:], out[h:], WorkspaceView(ws_, "h1."), cdt)
+            # parts (SR_RCAN_PARTS): b16 5.89 (2) / 5.70 (4) / 9.63 ms (8: the captured graph's cross-queue signalling takes over); b32 8.50 / 8.26 / 11.86
+            parts = int(os.environ.get("SR_RCAN_PARTS", "4"))
+            if parts < 2 or B % parts:
+                parts = 2
+            h = B // parts
+            sides = [self._side_stream(x.device, i) for i in range(parts - 1)]
+            for i, side in enumerate(sides):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._forward_into(P, x[(i + 1) * h:(i + 2) * h], out[(i + 1) * h:(i + 2) * h], WorkspaceView(ws_, f"h{i + 1}."), cdt)
             self._forward_into(P, x[:h], out[:h], WorkspaceView(ws_, "h0."), cdt)
-            main.wait_stream(side)
+            for side in sides:
+                main.wait_stream(side)
         else:
             self._forward_into(P, x, out, ws_, cdt)
         return out
 
     pipeline_halves = True
 
-    def _side_stream(self, device) -> "torch.cuda.Stream":
-        st = getattr(self, "_side", None)
-        if st is None or st.device != torch.device(device):
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_side", st)
-        return st
+    def _side_stream(self, device, i: int = 0) -> "torch.cuda.Stream":
+        sts = getattr(self, "_side", None)
+        if not isinstance(sts, dict) or sts.get("device") != torch.device(device):
+            sts = {"device": torch.device(device)}
+            object.__setattr__(self, "_side", sts)
+        if i not in sts:
+            sts[i] = torch.cuda.Stream(device=device)
+        return sts[i]
 
     def _forward_into(self, P: Dict, x: Tensor, out: Tensor, ws_, cdt) -> None:
         B, _, H, W = x.shape
