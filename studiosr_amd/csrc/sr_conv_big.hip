@@ -16,6 +16,10 @@
 
 #include <cstdlib>
 
+#ifndef SR_BIG_RING
+#define SR_BIG_RING 3
+#endif
+
 namespace {
 
 constexpr int BT = 16;                  // tile width (pixels) = one MFMA row tile
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     // ring slots are compile-time: the ring size divides KCP (run-time tap loop), or -- PIPE -- divides 9 * KCP with the tap loop unrolled.
     // PIPE needs the DEEP ring: vector loads return in order, so a weight fragment issued after the next phase's halo loads (HBM latency)
     // cannot be consumed before they land; five chunks of look-ahead (2.9 k MFMA cycles) issued BEFORE them cover that latency.
-    constexpr int RING = PIPE ? 6 : ((KCP % 3 == 0) ? 3 : (KCP % 4 == 0 ? 4 : 2));
+    constexpr int RING = PIPE ? 6 : ((KCP % SR_BIG_RING == 0) ? SR_BIG_RING : ((KCP % 3 == 0) ? 3 : (KCP % 4 == 0 ? 4 : 2)));
     static_assert(KC % PH == 0 && (PIPE ? (9 * KCP) % RING == 0 : KCP % RING == 0), "phase / ring geometry");
     constexpr int KGP = KCP * 4;                   // 8-channel groups per phase
     extern __shared__ __attribute__((aligned(16))) char smem[];

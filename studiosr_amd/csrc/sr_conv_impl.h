@@ -23,6 +23,11 @@
 
 #include <cstdlib>
 
+// weight ring depth of the unrolled K walk: chunk t + SR_CONV_RING - 1 is requested while chunk t runs
+#ifndef SR_CONV_RING
+#define SR_CONV_RING 3
+#endif
+
 namespace sr_conv_impl {
 
 static __device__ unsigned long long sr_dbg_conv[16];  // per translation unit (diagnostic STAMPS builds only)
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     if constexpr (KCS > 0) {
         // Fully unrolled (tap, chunk) walk: K-chunk count is a compile-time constant, so the 3-slot weight ring
         // (chunk t in slot t % 3, fetched 2 chunks = 2*MTW*NW MFMAs ahead) and every accumulator stay in fixed registers.
-        constexpr int RING = 3;
+        constexpr int RING = SR_CONV_RING;
         constexpr int KCTS = 9 * KCS;
         // Walk order of the K-chunks.  256 input channels are summed as two phases of 128 (all nine taps of channels 0..127,
         // then of 128..255) -- the order sr_conv_big.hip needs for its two-phase halo tile -- so that a

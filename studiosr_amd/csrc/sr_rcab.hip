@@ -28,7 +28,10 @@ constexpr int TIN = 18;            // input halo edge
 constexpr int IN_ROWS = 328;       // 18 * 18 = 324 halo pixels, padded to a multiple of 8
 constexpr int IN_RS = IN_ROWS + 1;  // row stride of the input image in cells: odd, so that the staging writes of one pixel's 8 K-groups (8 adjacent lanes) hit 8 bank groups
 constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 1 margin cell, padded to a multiple of 8
-constexpr int RRING = 3;
+#ifndef SR_RCAB_RING
+#define SR_RCAB_RING 6  // five chunks of weight look-ahead (16 MFMAs each): RCAN x4 b16 5.92 -> 5.20 ms, b32 8.26 -> 7.69 ms against 3 slots; 8 / 10 slots: 6.4 ms
+#endif
+constexpr int RRING = SR_RCAB_RING;
 
 constexpr int GATE_SCRATCH = (8 * RC + RC + 8 + RC) * (int)sizeof(float);  // slice sums | mean | hidden | gate
 
