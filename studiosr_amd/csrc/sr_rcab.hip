@@ -33,10 +33,22 @@ constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 
 #endif
 constexpr int RRING = SR_RCAB_RING;
 
+#ifdef SR_STAMPS
+__device__ unsigned long long sr_dbg_rcab[16];
+#define RSTAMP(i)                                                                                 \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (blockIdx.x == 7 && threadIdx.x == 0) sr_dbg_rcab[i] = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+
 constexpr int GATE_SCRATCH = (8 * RC + RC + 8 + RC) * (int)sizeof(float);  // slice sums | mean | hidden | gate
 
 template <typename TIn, typename TOut, bool GATED>
-__global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
+__global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two workgroups per CU: <= 256 VGPRs (the gated form sits at the limit)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [RKG][IN_ROWS]
     Frag<bf16>* Amid = Ain + RKG * IN_RS;                     // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
@@ -53,6 +65,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
     const int b = t / tiles_y;
     const int x0 = tx * TO, y0 = ty * TO;  // output tile origin; intermediate tile origin = (y0 - 1, x0 - 1), halo origin = (y0 - 2, x0 - 2)
 
+    RSTAMP(0);
     const Frag<bf16>* W1 = reinterpret_cast<const Frag<bf16>*>(c.w1p) + (size_t)(wn * 2) * RKCT * 64 + lane;
     const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wn * 2) * RKCT * 64 + lane;
     Frag<bf16> br[RRING][2];
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
                 }
             };
             issue(wave * 8);
+            RSTAMP(1);
             {
                 float* part = reinterpret_cast<float*>(Amid + RKG * MID_ROWS);  // [8][RC]
                 float* mean = part + 8 * RC;
@@ -131,8 +145,27 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
                 float s0 = 0.f, s1 = 0.f;
                 if (ch < C) {
                     const float* pp = c.gate_pool + (size_t)b * nt * RC + ch;
+                    constexpr int PF = 4;  // (8: 296 VGPRs = one workgroup per CU: b16 5.2 -> 5.7 ms, b32 7.7 -> 10.3 ms)
+                    // 2 x PF partials in flight per thread, added in slot order (the same sums as one dependent load at a time, which was 9.4 k of
+                    // this kernel's 41.9 k cycles: profiles/r03_rcab_kernel_stamps.txt)
+#ifdef SR_RCAB_SEQPOOL
                     for (int tt = sl; tt < nt; tt += 8) s0 += pp[(size_t)tt * RC];
                     for (int tt = sl + 4; tt < nt; tt += 8) s1 += pp[(size_t)tt * RC];
+#else
+                    for (int t0 = 0; t0 < nt; t0 += 8 * PF) {
+                        float v0[PF], v1[PF];
+#pragma unroll
+                        for (int k = 0; k < PF; ++k) {
+                            v0[k] = pp[(size_t)min(t0 + sl + 8 * k, nt - 1) * RC];
+                            v1[k] = pp[(size_t)min(t0 + sl + 4 + 8 * k, nt - 1) * RC];
+                        }
+#pragma unroll
+                        for (int k = 0; k < PF; ++k) {
+                            if (t0 + sl + 8 * k < nt) s0 += v0[k];
+                            if (t0 + sl + 4 + 8 * k < nt) s1 += v1[k];
+                        }
+                    }
+#endif
                 }
                 part[sl * RC + ch] = s0;
                 part[(sl + 4) * RC + ch] = s1;
@@ -173,6 +206,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
         #pragma unroll
                 for (int i = 0; i < 8; ++i) gk[i] = gate[(lane & 7) * 8 + i];
             }
+            RSTAMP(2);
             commit(wave * 8);
             issue(wave * 8 + 32 * GP);
             commit(wave * 8 + 32 * GP);
@@ -204,7 +238,9 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
             Amid[(threadIdx.x >> 1) * MID_ROWS + ((threadIdx.x & 1) ? 1 + TI * TI : 0)] = z;
         }
     }
+    RSTAMP(3);
     __syncthreads();
+    RSTAMP(4);
 
     // ---- conv1 + bias + ReLU -> intermediate image.  Wave (wm, wn): rows [8 wm, 8 wm + 8) x channels [32 wn, 32 wn + 32)
     {
@@ -234,6 +270,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        RSTAMP(5);
         const f32x4 bias0 = load4(c.b1 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b1 + (wn * 2 + 1) * 16 + ag * 4);
         const int gx = x0 - 1 + ar;
 #pragma unroll
@@ -253,6 +290,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
         }
     }
     __syncthreads();
+    RSTAMP(6);
 
     // ---- conv2 + bias on output rows oy = 1 + 7 wm .. 7 wm + 7 of the intermediate tile; 16 columns per row, the inner 14 are kept
     {
@@ -280,6 +318,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        RSTAMP(7);
         const f32x4 bias0 = load4(c.b2 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b2 + (wn * 2 + 1) * 16 + ag * 4);
         const int gx = x0 - 1 + ar;
         const bool xin_tile = ar >= 1 && ar <= TO && gx < c.W;
@@ -321,6 +360,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
                 }
             }
         }
+        RSTAMP(8);
         if (c.pool_partial) {  // per (tile, row half) channel sums over the valid pixels: deterministic, no atomics
             const int n_slots = tiles_x * tiles_y * 2;
             const int slot = (ty * tiles_x + tx) * 2 + wm;
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(256) void sr_rcab_kernel(SrRcab c) {
             }
         }
     }
+    RSTAMP(9);
 }
 
 template <typename TIn, typename TOut, bool GATED>
@@ -357,6 +398,12 @@ int launch_rcab(const SrRcab& c, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SR_STAMPS
+extern "C" int sr_debug_rcab_stamps(unsigned long long* host16) {
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(sr_dbg_rcab), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int sr_rcab_pool_tiles(int H, int W) { return ((W + TO - 1) / TO) * ((H + TO - 1) / TO) * 2; }
 
