@@ -8,7 +8,8 @@
 //     K-group-major image as in sr_conv.hip), computes the 16 x 16 intermediate tile (conv1 + bias + ReLU; positions
 //     outside the image are ZERO: they are conv2's padding) into a second LDS image, then the 14 x 14 outputs from it;
 //   * an MFMA row tile is 16 horizontally adjacent pixels in both convs (conv2 evaluates 16 columns per row and keeps the
-//     inner 14); waves split 2 x 2 over (rows, output channels); weights stream L2 -> registers through a 3-slot ring;
+//     inner 14); conv1: four rows x all channels per wave, conv2: waves split 2 x 2 over (rows, output channels); weights stream
+//     L2 -> registers through rings of 5 / 6 slots;
 //   * K is walked tap-major exactly like sr_conv3x3, so y has the same bits as the two-launch path.
 // 76 KiB LDS -> two workgroups per CU.
 // Gated form: the previous block's channel-attention tail (gate * y + skip) is applied while staging the halo, so a chain of RCABs is
@@ -32,6 +33,10 @@ constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 
 #define SR_RCAB_RING 6  // five chunks of weight look-ahead (16 MFMAs each): RCAN x4 b16 5.92 -> 5.20 ms, b32 8.26 -> 7.69 ms against 3 slots; 8 / 10 slots: 6.4 ms
 #endif
 constexpr int RRING = SR_RCAB_RING;
+#ifndef SR_RCAB_RING1
+#define SR_RCAB_RING1 5
+#endif
+constexpr int R1RING = SR_RCAB_RING1;  // conv1's ring: 4 fragments per slot
 
 #ifdef SR_STAMPS
 __device__ unsigned long long sr_dbg_rcab[16];
@@ -66,13 +71,14 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
     const int x0 = tx * TO, y0 = ty * TO;  // output tile origin; intermediate tile origin = (y0 - 1, x0 - 1), halo origin = (y0 - 2, x0 - 2)
 
     RSTAMP(0);
-    const Frag<bf16>* W1 = reinterpret_cast<const Frag<bf16>*>(c.w1p) + (size_t)(wn * 2) * RKCT * 64 + lane;
     const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wn * 2) * RKCT * 64 + lane;
-    Frag<bf16> br[RRING][2];
+    Frag<bf16> br[RRING][2];     // conv2: this wave's two channel tiles
+    Frag<bf16> b1r[R1RING][4];   // conv1: all four channel tiles (see there)
+    const Frag<bf16>* W1a = reinterpret_cast<const Frag<bf16>*>(c.w1p) + lane;
 #pragma unroll
-    for (int s = 0; s < RRING - 1; ++s)
+    for (int s = 0; s < R1RING - 1; ++s)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) br[s][n] = W1[((size_t)n * RKCT + s) * 64];
+        for (int n = 0; n < 4; ++n) b1r[s][n] = W1a[((size_t)n * RKCT + s) * 64];
 
     float gk[8];  // gated input: this lane's 8 channel gates
     // ---- stage the input halo: 8 pixels x 8 K-groups per wave instruction with the K-GROUP on the fast lane axis (the 8 lanes of a pixel read
@@ -242,48 +248,55 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
     __syncthreads();
     RSTAMP(4);
 
-    // ---- conv1 + bias + ReLU -> intermediate image.  Wave (wm, wn): rows [8 wm, 8 wm + 8) x channels [32 wn, 32 wn + 32)
+    // ---- conv1 + bias + ReLU -> intermediate image.  Wave w: rows [4 w, 4 w + 4) x ALL 64 channels: 4 activation fragments (LDS) x 4 weight
+    //      fragments per step instead of 8 x 2 -- the LDS fragment reads were as long as the MFMAs (8 KiB per wave and step at 128 B/clk per CU);
+    //      per output element the K walk is unchanged (same bits)
     {
-        f32x4 acc[8][2];
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            acc[m][0] = (f32x4)(0.0f);
-            acc[m][1] = (f32x4)(0.0f);
-        }
-        const Frag<bf16>* abase0 = Ain + (wm * 8) * TIN + ar + ag * IN_RS;
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4)(0.0f);
+        const Frag<bf16>* abase0 = Ain + (wave * 4) * TIN + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < RKCT; ++tt) {
             const int tap = tt / RKC, kc = tt - tap * RKC;
-            if (tt + RRING - 1 < RKCT) {
+            if (tt + R1RING - 1 < RKCT) {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W1[((size_t)n * RKCT + tt + RRING - 1) * 64];
-            } else {  // tail of conv1: start conv2's weight stream
+                for (int n = 0; n < 4; ++n) b1r[(tt + R1RING - 1) % R1RING][n] = W1a[((size_t)n * RKCT + tt + R1RING - 1) * 64];
+            } else if (tt + R1RING - 1 - RKCT < RRING - 1) {  // tail of conv1: start conv2's weight stream
 #pragma unroll
-                for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W2[((size_t)n * RKCT + tt + RRING - 1 - RKCT) * 64];
+                for (int n = 0; n < 2; ++n) br[tt + R1RING - 1 - RKCT][n] = W2[((size_t)n * RKCT + tt + R1RING - 1 - RKCT) * 64];
             }
             const Frag<bf16>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_RS;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < 4; ++m) {
                 const Frag<bf16> a = arow[m * TIN];
-                mma(br[tt % RRING][0], a, acc[m][0]);
-                mma(br[tt % RRING][1], a, acc[m][1]);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma(b1r[tt % R1RING][n], a, acc[m][n]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int s2 = R1RING - 1; s2 < RRING - 1; ++s2)  // the rest of conv2's first slots (its ring is the deeper one)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) br[s2][n] = W2[((size_t)n * RKCT + s2) * 64];
         RSTAMP(5);
-        const f32x4 bias0 = load4(c.b1 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b1 + (wn * 2 + 1) * 16 + ag * 4);
+        f32x4 bias[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bias[n] = load4(c.b1 + n * 16 + ag * 4);
         const int gx = x0 - 1 + ar;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int iy = wm * 8 + m, gy = y0 - 1 + iy;
+        for (int m = 0; m < 4; ++m) {
+            const int iy = wave * 4 + m, gy = y0 - 1 + iy;
             const bool inside = gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;  // outside the image the intermediate is conv2's zero padding
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+            for (int n = 0; n < 4; ++n) {
+                f32x4 v = acc[m][n] + bias[n];
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? fmaxf(v[r], 0.0f) : 0.0f);
-                const int kg = (wn * 2 + n) * 2 + (ag >> 1);
+                const int kg = n * 2 + (ag >> 1);
                 char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TI + ar) + (ag & 1) * 8;
                 *reinterpret_cast<bf16x4*>(dst) = o;
             }
