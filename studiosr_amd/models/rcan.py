@@ -163,7 +163,9 @@ class RCAN(Model):
         B, _, H, W = x.shape
         s = self.scale
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
-        if self.pipeline_halves and B >= 16 and B % 2 == 0:
+        # part batches on several streams pay off only when the launches cost no CPU time, i.e. inside a HIP-graph capture: an eager forward
+        # is launch-bound at 4 x 222 launches (b16 eager: 12.5 ms with four parts, 7.2 with two, 6.4 with one)
+        if self.pipeline_halves and B >= 16 and B % 2 == 0 and (torch.cuda.is_current_stream_capturing() or os.environ.get("SR_RCAN_PARTS")):
             # Every RCAB launch is whole residency rounds whose load, MFMA and store phases run one after the other chip-wide; two half
             # batches on two streams are out of phase, so one's HBM phases run under the other's MFMAs.  Measured (tools/rcan_ab.py,
             # same box): b8 4.81 -> 5.58 ms (worse: off below 16), b16 6.43 -> 6.04 ms, b32 12.08 -> 9.13 ms.

@@ -284,6 +284,22 @@ def test_forwards_with_side_streams_or_torch_glue_replay_from_a_hip_graph(kind, 
             assert torch.equal(gf(x), w)
 
 
+def test_rcan_batch16_graph_replay_on_four_streams_equals_the_eager_forward():
+    """RCAN at B >= 16 captures as four quarter batches on four streams (models/rcan.py: the launches of one quarter run under the MFMAs of the
+    others); eager forwards stay one launch sequence.  Both must give the same bits, image by image."""
+    from studiosr_amd.runtime import GraphedForward
+
+    torch.manual_seed(6)
+    m = _randomised(S.RCAN(scale=2, n_feats=64, n_resblocks=3, n_resgroups=2, reduction=16), seed=6).to(DEV).eval().set_precision("bf16")
+    xs = [torch.rand(16, 3, 24, 20, device=DEV) for _ in range(2)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+        assert torch.equal(m(xs[0][3:4].contiguous())[0], want[0][3])  # batch independence (the gate is per image)
+        gf = GraphedForward(lambda t: m(t), xs[0])
+        for x, w in zip(xs, want):
+            assert torch.equal(gf(x), w)
+
+
 def test_edsr_x4_batch16_invariants():
     """BASELINE config 2 (EDSR x4, batch 16, 64x64): batch independence + eval-pad-free shape; fp32 vs bf16 PSNR."""
     torch.manual_seed(0)
