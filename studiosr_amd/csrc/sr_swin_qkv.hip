@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
 }  // namespace
 
 extern "C" int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype) {
-    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16 || ws == 32)) ? 1 : 0;
+    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16)) ? 1 : 0;
 }
 
 extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
@@ -180,7 +180,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     dv.div_parts_img = make_fastdiv((uint32_t)(nwx * nwy * parts));
     dv.div_parts_win = make_fastdiv((uint32_t)parts);
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
-    dv.ws_log2 = a.ws == 8 ? 3 : (a.ws == 16 ? 4 : 5);
+    dv.ws_log2 = a.ws == 8 ? 3 : 4;
     dv.nw = nwx * nwy;
     static SrDeviceOnce attr_once;
     {

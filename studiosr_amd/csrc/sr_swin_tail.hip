@@ -349,7 +349,7 @@ extern "C" int sr_debug_tail_stamps(unsigned long long* host32) {
 #endif
 
 extern "C" int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
-    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16 || ws == 32) && Hp == 384) ? 1 : 0;
+    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16) && Hp == 384) ? 1 : 0;
 }
 
 extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
@@ -372,7 +372,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     dv.div_parts_img = make_fastdiv((uint32_t)(nwx * nwy * parts));
     dv.div_parts_win = make_fastdiv((uint32_t)parts);
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
-    dv.ws_log2 = a.ws == 8 ? 3 : (a.ws == 16 ? 4 : 5);
+    dv.ws_log2 = a.ws == 8 ? 3 : 4;
     static SrDeviceOnce attr_once;
     {
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16>, Lds<bf16>::TOTAL); });

@@ -69,7 +69,8 @@ class Model(nn.Module):
     def __getstate__(self):  # deepcopy / pickle: derived device state (workspace, packed weights) is rebuilt on demand
         state = dict(self.__dict__)
         state["_packed"], state["_ws"] = {}, None
-        state.pop("_side", None)  # HIP stream of the two-branch blocks: per process, re-created on demand
+        state.pop("_side", None)  # HIP stream(s) of the two-branch blocks / part batches: per process, re-created on demand
+        state.pop("_part_streams", None)
         return state
 
     def __call__(self, *args, **kwargs):

@@ -163,7 +163,7 @@ def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dic
 def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
     """Weight stream of sr_swin_tail (ABI v6: projection + shortcut + LayerNorm2 + MLP behind a separate attention kernel; hat.py:172-194,
     286-293) when the kernel covers the geometry (bf16 path only)."""
-    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.hidden == 360 and geo.ws in (8, 16, 32)):
+    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.hidden == 360 and geo.ws in (8, 16)):
         return {}
     w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, norm2.weight, norm2.bias)
     return dict(tail_stream=packing.pack_swin_tail_stream(proj.weight, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden))
@@ -171,7 +171,7 @@ def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: Swi
 
 def pack_qkv_stream(attn: nn.Module, norm1: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
     """Weight stream of sr_swin_qkv (ABI v6: LayerNorm1 + QKV projection in front of sr_window_attention; hat.py:164-176), bf16 path only."""
-    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws in (8, 16, 32)):
+    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws in (8, 16)):
         return {}
     qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, norm1.weight, norm1.bias)
     return dict(qkv_stream=packing.pack_swin_qkv_stream(qw, qb, geo.C, geo.heads))
@@ -444,6 +444,40 @@ class SwinIR(Model):
         P = self._get_packed(cdt)
         ws_ = self._workspace(x.device)
         B, _, H, W = x.shape
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
+        # Inside a HIP-graph capture a batch can run as part batches on several streams: the parts' launches are out of phase, so one part's
+        # x-fetch / store / convolution phases run under the other's MFMAs (what bench.py's two batches in flight do across steps).  Eager
+        # forwards stay one launch sequence (they are launch-bound).  SR_SWIN_PARTS: 1 = off (default), 2 = two half batches.
+        parts = int(os.environ.get("SR_SWIN_PARTS", "1"))
+        if parts > 1 and B % parts == 0 and B // parts >= 2 and x.is_cuda and torch.cuda.is_current_stream_capturing():
+            from ..runtime import WorkspaceView
+
+            main = torch.cuda.current_stream(x.device)
+            h = B // parts
+            sides = [self._part_stream(x.device, i) for i in range(parts - 1)]
+            for i, side in enumerate(sides):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._forward_into(P, x[(i + 1) * h:(i + 2) * h], out[(i + 1) * h:(i + 2) * h], WorkspaceView(ws_, f"p{i + 1}."), cdt)
+            self._forward_into(P, x[:h], out[:h], WorkspaceView(ws_, "p0."), cdt)
+            for side in sides:
+                main.wait_stream(side)
+        else:
+            self._forward_into(P, x, out, ws_, cdt)
+        return out
+
+    def _part_stream(self, device, i: int) -> "torch.cuda.Stream":
+        sts = getattr(self, "_part_streams", None)
+        if not isinstance(sts, dict) or sts.get("device") != torch.device(device):
+            sts = {"device": torch.device(device)}
+            object.__setattr__(self, "_part_streams", sts)
+        if i not in sts:
+            sts[i] = torch.cuda.Stream(device=device)
+        return sts[i]
+
+    def _forward_into(self, P: Dict, x: Tensor, out: Tensor, ws_, cdt) -> None:
+        B, _, H, W = x.shape
         w8 = self.window_size
         if self.training:  # check_image_size: reflect pad to the next multiple (swinir.py:356, common.py:277-282)
             Hp, Wp, pad_mode = H + (w8 - H % w8) % w8, W + (w8 - W % w8) % w8, L.PAD_REFLECT
@@ -479,7 +513,6 @@ class SwinIR(Model):
         self._run_resi(P["after_body"], normed, body, first, cdt)  # conv_after_body(features) + x  (swinir.py:362)
 
         s = self.scale
-        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
         fin = (*P["fin"], self.n_colors, H * s, W * s)
         if self.upsampler == "pixelshuffle":
             feat = ws_.get("feat", (B, Hp, Wp, 64), cdt)
@@ -489,7 +522,6 @@ class SwinIR(Model):
         else:
             wp, b, r, cps_p = P["up"][0]
             conv_call(body, wp, b, out, cdt, out_mode=L.OUT_FINAL_NCHW, ps_r=r, cps_p=cps_p, fin=fin, cout_p=r * r * cps_p)
-        return out
 
     def forward_strips(self, x: Tensor, comm) -> Tensor:
         """forward() of ONE image, row-strip sharded with per-layer halo exchange (studiosr_amd/strips.py; SURVEY.md

@@ -591,6 +591,43 @@ def test_rgb_tail_conv_persistent_kernel_against_conv2d(cin, shape):
     assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("ws", [8, 16])
+def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launches(ws, monkeypatch):
+    """run_window_msa + MLP of one packed HAT block on a stream tensor, with the stream-form kernels (sr_swin_qkv, sr_swin_tail) and with the
+    launches they replace (sr_gemm SR_EPI_QKV, sr_gemm projection, sr_mlp_fused): windows of 8 x 8 (one 64-token part) and 16 x 16 (four
+    parts), shifted and unshifted, separate skip tensor (so that the one-kernel attention half of the 8 x 8 geometry is not taken)."""
+    from studiosr_amd.models import swinir as SW
+    from studiosr_amd.runtime import Workspace
+
+    torch.manual_seed(31)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=31).to(DEV).eval().set_precision("bf16")
+    cdt = torch.bfloat16
+    lp = m._get_packed(cdt)["layers"][0]
+    geo = lp["geo"]
+    B, H, W = 2, 3 * ws, 2 * ws
+    t_in = torch.randn(B, H, W, geo.Cp, device=DEV)
+    t_in[..., geo.C:] = 0
+    skip = torch.randn(B, H, W, geo.Cp, device=DEV)
+    skip[..., geo.C:] = 0
+    for bp in lp["blocks"]:  # shift 0 and ws / 2
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("SR_SWIN_QKV", flag)
+            monkeypatch.setenv("SR_SWIN_TAIL", flag)
+            out = torch.full_like(t_in, float("nan"))
+            used = SW.run_window_msa(bp, bp["ln1"], geo, t_in, out, skip, Workspace(DEV), cdt, bp["shift"], name=f"t{flag}", with_mlp=True)
+            assert (used == "tail") == (flag == "1")
+            if used != "tail":
+                SW.run_mlp(bp, bp["ln2"], geo, out, Workspace(DEV), cdt)
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+        new, old = outs
+        assert not torch.isnan(new).any() and float(new[..., geo.C:].abs().max()) == 0.0
+        scale = float(old.abs().max())
+        assert float((new - old).abs().max()) <= 1.0e-2 * scale, f"shift {bp['shift']}"
+        assert float((new - old).pow(2).mean().sqrt()) <= 1.5e-3 * scale
+
+
 def test_cab_fused_equals_two_conv_launches_and_a_torch_reference():
     """sr_cab_fused (hat.py:41-49: conv 180 -> 60, GELU, conv 60 -> 180 in one launch, intermediate in LDS, per-tile pool sums) against the
     two sr_conv3x3 launches it replaces (same packed weights) and against torch convs on the bf16-rounded operands, on an image that is not a
