@@ -169,7 +169,7 @@ typedef struct SrSwinTail {
     const float* x;        /* [B,H,W,ldx] fp32 stream (the shortcut) */
     float* out;            /* may alias x */
     const void* o;         /* bf16 [B*H*W][heads*hd_p] */
-    const void* wstream;   /* 30 slots x 12 fragments x 64 lanes x 8 bf16 */
+    const void* wstream;   /* 30 (48 with the fused next-block QKV, see q2) slots x 12 fragments x 64 lanes x 8 bf16 */
     const float* bproj;    /* [Cp] fp32, pad 0 */
     const void* y;         /* optional second residual bf16 [B,H,W,ldy] (HAT: the CAB convolution output) or NULL */
     const float* gate;     /* [B][ld_gate] fp32 per-image channel gates from sr_channel_gate (conv_scale folded in); read when y != NULL */
@@ -190,6 +190,11 @@ typedef struct SrSwinTail {
     const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;
     int ca_Cr, ca_n_tiles;
     float y_scale;
+    /* optional fused stage: q, k, v = qkv(LayerNorm1(out)) of the NEXT block (what sr_swin_qkv would compute from `out`), scattered into that
+     * block's window order (its shift is shift2).  When q2 != NULL, wstream continues with the 18 slots of packing.pack_swin_qkv_stream of
+     * the next block (48 slots in all).  Layouts as SrSwinQkv; y_mode must be SR_Y_ROLL; both shifts multiples of 4. */
+    void* q2; void* k2; void* vt2;
+    int shift2;
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);

@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int TAIL_SLOTS = 30;  // 6 proj, then per hidden half 6 fc1 + 6 fc2
+constexpr int QKV_SLOTS = 18;   // optional: the next block's QKV projection (3 passes of two heads x 6 K-chunks)
 constexpr int OROW = 384;       // bytes per attention-output row (6 heads x 32 features bf16)
 constexpr int OSTRIDE = 400;    // its row stride in LDS
 static_assert(NTOK * OSTRIDE == 25 * 1024 && NTOK * OSTRIDE <= CELLS_A * 16 + 1024, "25 one-KiB pieces; the image ends inside the (still unused) hidden-half region");
@@ -44,7 +45,7 @@ __device__ unsigned long long sr_dbg_tail[32];
 struct SwinTailDev {
     SrSwinTail a;
     FastDiv div_parts_img, div_parts_win, div_nwx;  // 64-token parts per image, per window; windows per row
-    int ws_log2;
+    int ws_log2, nw;                                // windows per image
 };
 
 // 16 B per lane from base + lane_off to LDS at lds_dst + 16 lane
@@ -56,7 +57,10 @@ SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
                  : "memory");
 }
 
-template <typename T>
+// QKV = true: the kernel goes on with LayerNorm1 + QKV projection of the NEXT block on the same 64 tokens (sr_swin_qkv.hip's passes; weight
+// slots 30..47 of the stream) and scatters q / k / v^T into that block's window order (its shift differs): one launch less on the critical
+// chain tail -> qkv -> attention of a HAB, and the ring prefetches the QKV weights through the MLP.
+template <typename T, bool QKV>
 __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTailDev dv) {
     static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
     const SrSwinTail& a = dv.a;
@@ -111,8 +115,9 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     }
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(15);
-    WStream<T, TAIL_SLOTS, SR_TAIL_DIST> ws;
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, TAIL_SLOTS * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
+    constexpr int NSL = QKV ? TAIL_SLOTS + QKV_SLOTS : TAIL_SLOTS;
+    WStream<T, NSL, SR_TAIL_DIST> ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, NSL * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
     ws.wave_frag = w * 3;
 #pragma unroll
     for (int s0 = 0; s0 < SR_TAIL_DIST; ++s0) ws.load(s0, lane);
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     // ---- store: accumulator layout -> LDS tile -> 16 full rows per wave; optionally LayerNorm(out) with an affine as a bf16 side output
     //      (HAT: norm1 of the NEXT block, the input of its CAB convolutions, hat.py:165-170 -- saves that block's LayerNorm launch)
     relane();
-    if (a.n1) {
+    const bool want_ln = QKV || a.n1;
+    if (want_ln) {
         float q1[4], q2[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -305,6 +311,16 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
 #pragma unroll
         for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xm + n * 64) = x1[m][n];
     }
+    float mean[4], rstd[4];
+    if (want_ln) {
+        const float inv = 1.0f / (float)a.C;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
+            mean[m] = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            rstd[m] = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean[m] * mean[m], 0.f) + a.eps);
+        }
+    }
     if (a.n1) {
         f32x4 gm[3], bt[3];
 #pragma unroll
@@ -312,18 +328,14 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
             gm[n] = *reinterpret_cast<const f32x4*>(a.n1_gamma + w * 48 + ag * 4 + n * 16);
             bt[n] = *reinterpret_cast<const f32x4*>(a.n1_beta + w * 48 + ag * 4 + n * 16);
         }
-        const float inv = 1.0f / (float)a.C;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
-            const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
-            const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
             bf16* nrow = reinterpret_cast<bf16*>(a.n1) + (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
                 f32x4 nv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean) * rstd, gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean[m]) * rstd[m], gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
                 *reinterpret_cast<bf16x4*>(nrow + n * 16) = cvt4(nv);
             }
         }
@@ -336,6 +348,76 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
 #pragma unroll
         for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
+    }
+    if constexpr (QKV) {
+        // ---- the next block's LayerNorm1 + QKV on the same tokens (its LayerNorm affine, attention scale and biases are in the weight slots)
+        relane();
+        BLOCK_SYNC();  // every wave has read its rows of the tile: the image region is free again
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float nmr = -mean[m] * rstd[m];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf(x1[m][n][r], rstd[m], nmr);
+                if (n == 2) {
+                    nv[0] = one_lane ? 1.0f : nv[0];
+                    nv[1] = one_lane ? 1.0f : nv[1];
+                }
+                st_half(Aimg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, nv);
+            }
+        }
+        // destinations in the NEXT block's window order (shift2): token t of this workgroup sits at pixel (py, px) of the image
+        const int nwx = (int)dv.div_nwx.d, ntok_log2 = 2 * wsl;
+        auto dest = [&](int t, int& bw, int& tok) {
+            const int tw = (int)part * NTOK + t;
+            int y = ((int)wy << wsl) + (tw >> wsl) + a.shift, x = ((int)wx << wsl) + (tw & wsm) + a.shift;  // (y_mode == SR_Y_ROLL only)
+            if (y >= a.H) y -= a.H;
+            if (x >= a.W) x -= a.W;
+            y -= a.shift2;
+            x -= a.shift2;
+            if (y < 0) y += a.H;
+            if (x < 0) x += a.W;
+            bw = ((int)bimg * dv.nw + (y >> wsl) * nwx + (x >> wsl)) * a.heads;
+            tok = ((y & wsm) << wsl) + (x & wsm);
+        };
+        int qbw[4], qtok[4], vbw[4], vtok[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            dest(m * 16 + ar, qbw[m], qtok[m]);       // q, k: lane = token 16 m + ar
+            dest(m * 16 + 4 * ag, vbw[m], vtok[m]);   // v^T: registers = tokens 16 m + 4 ag .. + 3 (they stay adjacent: shifts are multiples of 4)
+        }
+        BLOCK_SYNC();
+        const int hh = w >> 1, half = w & 1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f32x4 acc[4][3];
+            ws.template run<6>(TAIL_SLOTS + 6 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (c == 0) {
+                        mma0(b[0], av[m], acc[2 * h + m][0]);  // q: lane = token, registers = 4 features
+                        mma0(b[1], av[m], acc[2 * h + m][1]);  // k: likewise
+                        mma0(av[m], b[2], acc[2 * h + m][2]);  // v: lane = feature, registers = 4 tokens
+                    } else {
+                        mma(b[0], av[m], acc[2 * h + m][0]);
+                        mma(b[1], av[m], acc[2 * h + m][1]);
+                        mma(av[m], b[2], acc[2 * h + m][2]);
+                    }
+                }
+            });
+            const int head = 2 * p + hh;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const size_t qo = ((((size_t)(qbw[m] + head)) << ntok_log2) + qtok[m]) * a.hd_p + 16 * half + 4 * ag;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.q2) + qo) = cvt4(acc[m][0]);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k2) + qo) = cvt4(acc[m][1]);
+                const size_t vo = (((size_t)(vbw[m] + head) * a.hd_p + 16 * half + ar) << ntok_log2) + vtok[m];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt2) + vo) = cvt4(acc[m][2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     TSTAMP(14);
 }
@@ -365,6 +447,8 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
                                            (2 * a.Cp + a.ca_Cr + 8 * a.Cp) * 4 <= 22 * 1024),
                "sr_swin_tail: in-kernel gate needs the squeeze weights (scratch: 22 KiB)");
     SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0), "sr_swin_tail: the LayerNorm side output needs n1_gamma, n1_beta, ldn");
+    SR_REQUIRE(!a.q2 || (a.k2 && a.vt2 && a.shift2 >= 0 && a.shift2 < a.ws && a.shift2 % 4 == 0 && a.shift % 4 == 0 && a.y_mode == SR_Y_ROLL),
+               "sr_swin_tail: the fused next-block QKV needs q2 / k2 / vt2, shifts that are multiples of 4 and y_mode SR_Y_ROLL");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;
     dv.a = a;
@@ -373,12 +457,20 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     dv.div_parts_win = make_fastdiv((uint32_t)parts);
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
     dv.ws_log2 = a.ws == 8 ? 3 : 4;
-    static SrDeviceOnce attr_once;
-    {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16>, Lds<bf16>::TOTAL); });
+    dv.nw = nwx * nwy;
+    const dim3 grid(a.B * nwx * nwy * parts);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.q2) {
+        static SrDeviceOnce attr_once;
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true>, Lds<bf16>::TOTAL); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, true>), grid, dim3(256), Lds<bf16>::TOTAL, st, dv);
+    } else {
+        static SrDeviceOnce attr_once;
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, false>, Lds<bf16>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, false>), grid, dim3(256), Lds<bf16>::TOTAL, st, dv);
     }
-    hipLaunchKernelGGL(sr_swin_tail_kernel<bf16>, dim3(a.B * nwx * nwy * parts), dim3(256), Lds<bf16>::TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
     SR_CHECK_LAUNCH("sr_swin_tail");
     return SR_OK;
 }

@@ -44,6 +44,7 @@ from .swinir import (
     run_mlp,
     run_swin_tail,
     run_window_msa,
+    swin_qkv_usable,
     swin_tail_usable,
 )
 
@@ -234,6 +235,9 @@ class HAT(Model):
                 att = cab[3].attention
                 e["ca"] = pack_ca(att[1].weight, att[1].bias, att[3].weight, att[3].bias)
                 blocks.append(e)
+            for i in range(len(blocks) - 1):  # sr_swin_tail of block i continues with block i + 1's LayerNorm1 + QKV: one stream
+                if "tail_stream" in blocks[i] and "qkv_stream" in blocks[i + 1]:
+                    blocks[i]["tail_qkv_stream"] = torch.cat([blocks[i]["tail_stream"], blocks[i + 1]["qkv_stream"]]).contiguous()
             oc = layer.residual_group.overlap_attn
             o = dict(ln1=pack_ln(oc.norm1, Cp), ln2=pack_ln(oc.norm2, Cp))
             o.update(pack_attention(oc, geo, dt, rpi=self.relative_position_index_SA, norm=oc.norm1))  # qkv / proj packing (bias replaced below)
@@ -269,10 +273,12 @@ class HAT(Model):
             object.__setattr__(self, "_side", st)
         return st
 
-    def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt, n1_ready: bool = False, next_ln=None) -> bool:
+    def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt, n1_ready: bool = False, next_ln=None,
+                 qkv_ready: bool = False, next_bp=None):
         """t = HAB(t_in); t_in may be t (in place).
-        n1_ready: "hab.n1" already holds LayerNorm1(t_in) (written by the previous block's sr_swin_tail).  next_ln: norm1 (gamma, beta) of the
-        block that follows; returns True iff this block's tail kernel wrote that block's LayerNorm1 output into "hab.n1"."""
+        n1_ready / qkv_ready: "hab.n1" already holds LayerNorm1(t_in) / "hab.q", "hab.k", "hab.vt" already hold this block's q, k, v^T (written by
+        the previous block's sr_swin_tail).  next_ln: norm1 (gamma, beta) of the block that follows, next_bp: its packed entry.  Returns
+        (n1 written for the next block, q / k / v^T written for the next block)."""
         B, H, W, Cp = t_in.shape
         f32 = torch.float32
         # conv branch on LayerNorm1(x)  (hat.py:165-170)
@@ -297,6 +303,9 @@ class HAT(Model):
         gate = ws_.get("hab.gate", (B, Cp), f32)
         w1, b1, w2, b2 = bp["ca"]
         gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and os.environ.get("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
+        # the tail kernel goes on with the next block's LayerNorm1 + QKV (its attention kernel is the next launch of the chain)
+        fuse_next_qkv = (unfused and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
+                         and os.environ.get("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
 
         def conv_branch():
             with torch.cuda.stream(side):
@@ -316,10 +325,11 @@ class HAT(Model):
                                      C=self.embed_dim, C_p=Cp, Cr=w1.shape[0], n_tiles=n_tiles, y_scale=float(self.conv_scale))
 
         # Launch ORDER: a captured HIP graph keeps the FIRST-created successor of a node on that node's queue and moves the others to another
-        # queue behind an ~8-13 us cross-queue signal.  The attention branch (QKV, attention: the longer chain once QKV is sr_swin_qkv) must
-        # therefore be created before the conv branch: the fork point is recorded first, the conv branch is enqueued from the projection hook.
-        # (SR_HAT_SIDE_FIRST=1: the round-2 order, conv branch first.)
-        late = unfused and side is not main and os.environ.get("SR_HAT_SIDE_FIRST", "0") != "1"
+        # queue behind an ~8-13 us cross-queue signal.  With the next block's QKV fused into sr_swin_tail the conv branch (one 30-35 us launch
+        # beside the attention kernel) is the longer one and is created first (default); SR_HAT_SIDE_FIRST=0 creates the attention branch first
+        # and enqueues the conv branch from the projection hook.  Measured on two boxes (HAT x4 b4, ms): fused QKV + conv first 3.42 / 3.43,
+        # fused + attention first 3.59 / 3.62, separate QKV + conv first 3.83 / 3.36, separate + attention first 3.85 / 3.42.
+        late = unfused and side is not main and os.environ.get("SR_HAT_SIDE_FIRST", "1") == "0"
         fork = None
         if late:
             fork = torch.cuda.Event()
@@ -336,6 +346,10 @@ class HAT(Model):
             if side is not main:
                 main.wait_stream(side)
             d = dict(skip2=y.data_ptr(), skip2_gate=gate.data_ptr(), skip2_dtype=sr_dtype(y.dtype), ldskip2=Cp, gate_rows=H * W, ld_gate=Cp)
+            if fuse_next_qkv:
+                nb_ = B * H * W // geo.ntok
+                d.update(qkv_next=dict(q=ws_.get("hab.q", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt), k=ws_.get("hab.k", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt),
+                                       vt=ws_.get("hab.vt", (nb_, geo.heads, geo.hd_p, geo.ntok), cdt), shift=next_bp["shift"]))
             if gate_in_tail:
                 d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
                                  ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))
@@ -344,16 +358,16 @@ class HAT(Model):
             return d
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
-        used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True)
-        if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1) ran as one launch (sr_swin_tail)
-            return next_ln is not None and n1.dtype == torch.bfloat16
+        used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready)
+        if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
+            return next_ln is not None and n1.dtype == torch.bfloat16, fuse_next_qkv
         if not used:
             # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
             if side is not main:
                 main.wait_stream(side)
             run_channel_attention(bp["ca"], y, pool, n_tiles, self.embed_dim, t, skip=t, y_scale=float(self.conv_scale))
         run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")
-        return False
+        return False, False
 
     def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt) -> None:
         """t = OCAB(t) in place (hat.py:239-293)."""
@@ -415,10 +429,11 @@ class HAT(Model):
         for lp in P["layers"]:
             geo = lp["geo"]
             cur = ta
-            ready = False
+            ready = qready = False
             for i, bp in enumerate(lp["blocks"]):
-                nxt = lp["blocks"][i + 1]["ln1"] if i + 1 < len(lp["blocks"]) else None
-                ready = self._run_hab(bp, geo, P, cur, tb, ws_, cdt, n1_ready=ready, next_ln=nxt)
+                nbp = lp["blocks"][i + 1] if i + 1 < len(lp["blocks"]) else None
+                ready, qready = self._run_hab(bp, geo, P, cur, tb, ws_, cdt, n1_ready=ready, next_ln=None if nbp is None else nbp["ln1"],
+                                              qkv_ready=qready, next_bp=nbp)
                 cur = tb
             if cur is ta:
                 tb.copy_(ta)

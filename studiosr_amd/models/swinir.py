@@ -197,6 +197,11 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     extra = dict(extra or {})
     n1, n1_ln = extra.pop("n1", None), extra.pop("n1_ln", None)
     kw.update(extra.pop("ca", None) or {})  # in-kernel channel-attention gate (pool partials + squeeze weights)
+    qkv_next = extra.pop("qkv_next", None)    # the next block's LayerNorm1 + QKV as the kernel's last stage (stream: tail + that block's QKV slots)
+    wstream = p["tail_stream"]
+    if qkv_next is not None:
+        wstream = p["tail_qkv_stream"]
+        kw.update(q2=qkv_next["q"].data_ptr(), k2=qkv_next["k"].data_ptr(), vt2=qkv_next["vt"].data_ptr(), shift2=int(qkv_next["shift"]))
     if n1 is not None:
         assert n1.dtype == torch.bfloat16 and n1.shape == skip.shape
         kw.update(n1=n1.data_ptr(), n1_gamma=n1_ln[0].data_ptr(), n1_beta=n1_ln[1].data_ptr(), ldn=Cp)
@@ -204,7 +209,7 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
         assert extra["skip2_dtype"] == L.SR_BF16 and extra["gate_rows"] == H * W
         kw.update(y=extra["skip2"], gate=extra["skip2_gate"], ldy=extra["ldskip2"], ld_gate=extra["ld_gate"])
     ops.swin_tail(
-        x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=p["tail_stream"].data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
+        x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=wstream.data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
         C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
         compute_dtype=L.SR_BF16, **kw,
     )
@@ -243,13 +248,14 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False):
+                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False):
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
     before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
     second residual).  Returns True iff it was used (the one-kernel attention half has no hook).
     with_mlp: the caller's next step is run_mlp(p, ...) on t_out; when sr_swin_tail covers the geometry the projection AND that MLP run as
-    one launch and the function returns "tail" (the caller must then skip run_mlp)."""
+    one launch and the function returns "tail" (the caller must then skip run_mlp).
+    qkv_ready: q / k / v^T of this block are already in the workspace (written by the previous block's sr_swin_tail): no QKV launch."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -265,7 +271,9 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
-    if swin_qkv_usable(p, geo, Cp, cdt):
+    if qkv_ready:
+        pass
+    elif swin_qkv_usable(p, geo, Cp, cdt):
         ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
                      Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=L.SR_BF16)
     else:
@@ -283,7 +291,8 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
         run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)
         return "tail"
-    extra.pop("n1", None), extra.pop("n1_ln", None), extra.pop("ca", None)  # the LayerNorm side output / in-kernel gate exist only in sr_swin_tail
+    for k_ in ("n1", "n1_ln", "ca", "qkv_next"):  # the LayerNorm side output / in-kernel gate / fused next QKV exist only in sr_swin_tail
+        extra.pop(k_, None)
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),
         M=M, K=geo.HP, N=Cp, lda=geo.HP, ldo=Cp, ldskip=Cp, a_dtype=sdt, out_dtype=L.SR_F32, compute_dtype=sdt, act=L.ACT_NONE,
