@@ -18,15 +18,19 @@ namespace {
 constexpr int CI = 192, CM = 64, CO = 192;
 constexpr int KG_IN = CI / 8, KC_IN = CI / 32, KCT1 = 9 * KC_IN;   // 24 K-groups, 6 chunks per tap, 54 steps
 constexpr int KG_MID = CM / 8, KC_MID = CM / 32, KCT2 = 9 * KC_MID;  // 8 K-groups, 2 chunks per tap, 18 steps
-constexpr int TOW = 14, TOH = 6;      // output tile
+#ifndef SR_CAB_TOH
+#define SR_CAB_TOH 6
+#endif
+constexpr int TOW = 14, TOH = SR_CAB_TOH;  // output tile; rows 4 (70 KiB of LDS = two workgroups per CU) / 6 / 8: HAT x4 b4 3.49 / 3.41 / 3.42 ms, b16 9.66 / 9.42 / 9.24 ms, b1 2.48 / 2.48 / 2.64 ms
 constexpr int TIW = 16, TIH = TOH + 2;   // intermediate tile (one MFMA row tile per row)
 constexpr int TINW = 18, TINH = TOH + 4; // input halo
-constexpr int IN_ROWS = 184;          // 18 * 10 = 180 halo pixels, padded to a multiple of 8
+constexpr int IN_ROWS = (TINW * TINH + 7) / 8 * 8;  // halo pixels (18 x 10 = 180 -> 184), padded to a multiple of 8
 constexpr int IN_RS = IN_ROWS + 1;    // odd cell stride: the 8 K-groups of one pixel (8 adjacent lanes of the staging writes) hit 8 bank groups
-constexpr int MID_ROWS = 136;         // 1 margin cell + 128 intermediate pixels + 1 margin cell, padded to a multiple of 8
+constexpr int MID_ROWS = (2 + TIW * TIH + 7) / 8 * 8;  // 1 margin cell + the intermediate pixels + 1 margin cell, padded to a multiple of 8
 constexpr int RING1 = 6, RING2 = 4;
 constexpr int LDS_BYTES = (KG_IN * IN_RS + KG_MID * MID_ROWS) * 16;
-static_assert(TINW * TINH <= IN_ROWS && 2 + TIW * TIH <= MID_ROWS, "image sizes");
+constexpr int R1 = TIH / 2;           // intermediate rows per wave pair in conv1
+static_assert(TINW * TINH <= IN_ROWS && 2 + TIW * TIH <= MID_ROWS && TIH % 2 == 0, "image sizes");
 
 __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,15 +94,15 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
     __syncthreads();
 
     Frag<bf16> r2[RING2][3];
-    // ---- conv1 + bias + GELU -> intermediate image.  Wave (wm, wn): rows [4 wm, 4 wm + 4) x channels [32 wn, 32 wn + 32)
+    // ---- conv1 + bias + GELU -> intermediate image.  Wave (wm, wn): rows [R1 wm, R1 wm + R1) x channels [32 wn, 32 wn + 32)
     {
-        f32x4 acc[4][2];
+        f32x4 acc[R1][2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < R1; ++m) {
             acc[m][0] = (f32x4)(0.0f);
             acc[m][1] = (f32x4)(0.0f);
         }
-        const Frag<bf16>* abase0 = Ain + (wm * 4) * TINW + ar + ag * IN_RS;
+        const Frag<bf16>* abase0 = Ain + (wm * R1) * TINW + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < KCT1; ++tt) {
             const int tap = tt / KC_IN, kc = tt - tap * KC_IN;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
             }
             const Frag<bf16>* arow = abase0 + (tap / 3) * TINW + (tap % 3) + kc * 4 * IN_RS;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < R1; ++m) {
                 const Frag<bf16> a = arow[m * TINW];
                 mma(r1[tt % RING1][0], a, acc[m][0]);
                 mma(r1[tt % RING1][1], a, acc[m][1]);
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
         const f32x4 bias0 = load4(c.b1 + (wn * 2) * 16 + ag * 4), bias1 = load4(c.b1 + (wn * 2 + 1) * 16 + ag * 4);
         const int gx = x0 - 1 + ar;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int iy = wm * 4 + m, gy = y0 - 1 + iy;
+        for (int m = 0; m < R1; ++m) {
+            const int iy = wm * R1 + m, gy = y0 - 1 + iy;
             const bool inside = gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;  // outside the image the intermediate is conv2's zero padding
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
