@@ -154,6 +154,8 @@ typedef struct SrSwinQkv {
     float eps;
     int y_mode;            /* SR_Y_* */
     int compute_dtype;     /* SR_BF16 */
+    int oca_pad;           /* 0: k / vt in window order (above).  > 0 (HAT OCAB, hat.py:247-264; as sr_gemm's SR_EPI_QKV_OCA): k -> zero-bordered image order
+                            * [B][H+2p][W+2p][heads][hd_p], vt -> transposed zero-bordered planes [B][heads][hd_p][(H+2p)(W+2p)], p = oca_pad (multiple of 4), shift 0 */
 } SrSwinQkv;
 int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype);
 int sr_swin_qkv(const SrSwinQkv* a, void* stream);

@@ -71,7 +71,7 @@ class SrSwinQkv(C.Structure):
     _fields_ = [
         ("x", _vp), ("q", _vp), ("k", _vp), ("vt", _vp), ("wstream", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
-        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
+        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i), ("oca_pad", _i),
     ]
 
 

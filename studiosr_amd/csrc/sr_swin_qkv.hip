@@ -146,15 +146,39 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
                 }
             }
         });
-        const size_t bh = bwin * a.heads + (2 * p + hh);
+        const int head = 2 * p + hh;
+        const size_t bh = bwin * a.heads + head;
         bf16* qd = reinterpret_cast<bf16*>(a.q) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
-        bf16* kd = reinterpret_cast<bf16*>(a.k) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
-        bf16* vd = reinterpret_cast<bf16*>(a.vt) + (((bh * a.hd_p + 16 * half + ar) << ntok_log2) + part * NTOK + 4 * ag);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            *reinterpret_cast<bf16x4*>(qd + m * 16 * a.hd_p) = cvt4(acc[m][0]);
-            *reinterpret_cast<bf16x4*>(kd + m * 16 * a.hd_p) = cvt4(acc[m][1]);
-            *reinterpret_cast<bf16x4*>(vd + m * 16) = cvt4(acc[m][2]);
+        for (int m = 0; m < 4; ++m) *reinterpret_cast<bf16x4*>(qd + m * 16 * a.hd_p) = cvt4(acc[m][0]);
+        if (a.oca_pad == 0) {
+            bf16* kd = reinterpret_cast<bf16*>(a.k) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
+            bf16* vd = reinterpret_cast<bf16*>(a.vt) + (((bh * a.hd_p + 16 * half + ar) << ntok_log2) + part * NTOK + 4 * ag);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *reinterpret_cast<bf16x4*>(kd + m * 16 * a.hd_p) = cvt4(acc[m][1]);
+                *reinterpret_cast<bf16x4*>(vd + m * 16) = cvt4(acc[m][2]);
+            }
+        } else {
+            // overlapping cross attention (hat.py:247-264): k -> zero-bordered image order [B][H+2e][W+2e][heads][hd_p], v -> transposed zero-bordered
+            // planes [B][heads][hd_p][(H+2e)(W+2e)] (4 consecutive tokens = 4 consecutive x; e = oca_pad); shift is 0 there
+            const int e = a.oca_pad, Wb = a.W + 2 * e;
+            const size_t plane = (size_t)(a.H + 2 * e) * Wb;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                {
+                    const int tw = (int)part * NTOK + m * 16 + ar;
+                    const int y = ((int)wy << wsl) + (tw >> wsl), x = ((int)wx << wsl) + (tw & wsm);
+                    const size_t off = ((((size_t)bimg * (a.H + 2 * e) + y + e) * Wb + x + e) * a.heads + head) * a.hd_p + 16 * half + 4 * ag;
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k) + off) = cvt4(acc[m][1]);
+                }
+                {
+                    const int tw = (int)part * NTOK + m * 16 + 4 * ag;
+                    const int y = ((int)wy << wsl) + (tw >> wsl), x = ((int)wx << wsl) + (tw & wsm);
+                    const size_t off = (((size_t)bimg * a.heads + head) * a.hd_p + 16 * half + ar) * plane + (size_t)(y + e) * Wb + x + e;
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt) + off) = cvt4(acc[m][2]);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -173,6 +197,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_qkv: bad geometry");
+    SR_REQUIRE(a.oca_pad == 0 || (a.oca_pad > 0 && a.oca_pad % 4 == 0 && a.shift == 0 && a.y_mode == SR_Y_ROLL), "sr_swin_qkv: OCA layouts need shift 0 and a border that is a multiple of 4");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");
     SwinQkvDev dv;
     dv.a = a;

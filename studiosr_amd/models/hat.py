@@ -251,6 +251,7 @@ class HAT(Model):
             o["oca_bias_frag"], o["oca_nk_frag"] = packing.bias_fragments(obf), nk_frag
             o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
             o.update(pack_tail_stream(oc.proj, oc.mlp, oc.norm2, geo, dt))
+            o.update(pack_qkv_stream(oc, oc.norm1, geo, dt))
             conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, ident, dt)
             P["layers"].append(dict(blocks=blocks, ocab=o, conv=conv, geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)
@@ -381,13 +382,17 @@ class HAT(Model):
         vt = ws_.get("oca.vt", (B, geo.heads, geo.hd_p, H + 2 * e, W + 2 * e), cdt)  # 5-D key: the zero border must never alias another geometry
         o = ws_.get("oca.o", (M, geo.HP), cdt)
         fold = fold_ln(cdt)
-        ops.gemm(
-            A=t.data_ptr(), Wp=op["qkv_w"].data_ptr(), bias=op["qkv_b"].data_ptr(), ln_gamma=None if fold else op["ln1"][0].data_ptr(),
-            ln_beta=None if fold else op["ln1"][1].data_ptr(), ln_norm_only=int(fold), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(),
-            M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp, a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
-            a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=H, W=W, ws=geo.ws, shift=0, epi=L.EPI_QKV_OCA, heads=geo.heads, hd_p=geo.hd_p,
-            ntok=geo.ntok, ln_eps=1e-5, oca_pad=e,
-        )
+        if swin_qkv_usable(op, geo, Cp, cdt) and e % 4 == 0:  # stream form: LayerNorm1 + QKV with k / v^T in the zero-bordered layouts
+            ops.swin_qkv(x=t.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=op["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp,
+                         ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=0, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, oca_pad=e)
+        else:
+            ops.gemm(
+                A=t.data_ptr(), Wp=op["qkv_w"].data_ptr(), bias=op["qkv_b"].data_ptr(), ln_gamma=None if fold else op["ln1"][0].data_ptr(),
+                ln_beta=None if fold else op["ln1"][1].data_ptr(), ln_norm_only=int(fold), out=q.data_ptr(), out_k=k.data_ptr(), out_vt=vt.data_ptr(),
+                M=M, K=Cp, N=3 * geo.HP, k_real=geo.C, lda=Cp, a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0,
+                a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=H, W=W, ws=geo.ws, shift=0, epi=L.EPI_QKV_OCA, heads=geo.heads, hd_p=geo.hd_p,
+                ntok=geo.ntok, ln_eps=1e-5, oca_pad=e,
+            )
         ops.oca_attention(
             q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=op["oca_bias"].data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=geo.heads,
             hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt, bias_frag=op["oca_bias_frag"].data_ptr(),
