@@ -28,14 +28,27 @@ constexpr int IN_ROWS = (TINW * TINH + 7) / 8 * 8;  // halo pixels (18 x 10 = 18
 constexpr int IN_RS = IN_ROWS + 1;    // odd cell stride: the 8 K-groups of one pixel (8 adjacent lanes of the staging writes) hit 8 bank groups
 constexpr int MID_ROWS = (2 + TIW * TIH + 7) / 8 * 8;  // 1 margin cell + the intermediate pixels + 1 margin cell, padded to a multiple of 8
 constexpr int RING1 = 6, RING2 = 4;
-constexpr int LDS_BYTES = (KG_IN * IN_RS + KG_MID * MID_ROWS) * 16;
+// K phases of conv1: PH = 2 keeps only 96 of the 192 input channels of the halo resident (52 KiB of LDS instead of 88: two workgroups per CU
+// where the launch is several residency rounds, e.g. HAT x4 b16: 880 workgroups); the second phase's halo loads fly under the first phase's MFMAs
+#ifndef SR_CAB_PH
+#define SR_CAB_PH 1
+#endif
+constexpr int PH = SR_CAB_PH;
+constexpr int KG_RES = KG_IN / PH, KC_PH = KC_IN / PH;   // resident K-groups, chunks per tap and phase
+constexpr int LP = KG_RES / 3, PPI = 64 / LP;            // staging: lanes per pixel (8 / 4), pixels per wave instruction (8 / 16); 3 passes per pixel group
+constexpr int UNITS = (IN_ROWS + PPI - 1) / PPI * 3, NU = (UNITS + 3) / 4;  // (pixel group, pass) units; per wave
+static_assert(KG_IN % PH == 0 && KG_RES % 3 == 0 && (LP == 8 || LP == 4), "phase geometry");
+constexpr int LDS_BYTES = (KG_RES * IN_RS + KG_MID * MID_ROWS) * 16;
 constexpr int R1 = TIH / 2;           // intermediate rows per wave pair in conv1
 static_assert(TINW * TINH <= IN_ROWS && 2 + TIW * TIH <= MID_ROWS && TIH % 2 == 0, "image sizes");
 
-__global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
+#ifndef SR_CAB_WGS
+#define SR_CAB_WGS (SR_CAB_PH == 1 ? 1 : 2)
+#endif
+__global__ __launch_bounds__(256, SR_CAB_WGS) void sr_cab_kernel(SrCab c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [KG_IN][IN_RS]
-    Frag<bf16>* Amid = Ain + KG_IN * IN_RS;                   // [KG_MID][MID_ROWS], pixel p of the 16 x 8 tile at cell 1 + p
+    Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [KG_RES][IN_RS]
+    Frag<bf16>* Amid = Ain + KG_RES * IN_RS;                   // [KG_MID][MID_ROWS], pixel p of the 16 x 8 tile at cell 1 + p
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -51,39 +64,48 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
 
     const Frag<bf16>* W1 = reinterpret_cast<const Frag<bf16>*>(c.w1p) + (size_t)(wn * 2) * KCT1 * 64 + lane;
     const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wave * 3) * KCT2 * 64 + lane;
+    // conv1 walks K phase-major: step t = (phase, tap, chunk in phase) -> packed chunk index tap * KC_IN + phase * KC_PH + chunk (PH = 1: t itself)
+    auto chunk_of = [](int t) { return ((t % (9 * KC_PH)) / KC_PH) * KC_IN + (t / (9 * KC_PH)) * KC_PH + t % KC_PH; };
     Frag<bf16> r1[RING1][2];
 #pragma unroll
     for (int s = 0; s < RING1 - 1; ++s)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) r1[s][n] = W1[((size_t)n * KCT1 + s) * 64];
+        for (int n = 0; n < 2; ++n) r1[s][n] = W1[((size_t)n * KCT1 + chunk_of(s)) * 64];
 
-    // ---- stage the input halo: 8 pixels x 8 K-groups per wave instruction, K-group on the fast lane axis (the 8 lanes of a pixel read 128
-    //      contiguous bytes); unit u = (pixel group of 8, K-group third), 69 units over 4 waves, 6 loads in flight
-    {
-        const int kq = lane & 7, r8 = lane >> 3;
-        constexpr int UNITS = (IN_ROWS / 8) * 3, NP = 6;
-        const bf16* xin = reinterpret_cast<const bf16*>(c.x);
+    // ---- stage the input halo: PPI pixels x LP K-groups per wave instruction, K-group on the fast lane axis (the LP lanes of a pixel read 16 LP
+    //      contiguous bytes); unit u = (pixel group, pass), UNITS over 4 waves
+    const int kq = lane & (LP - 1), rp = lane / LP;
+    const bf16* xin = reinterpret_cast<const bf16*>(c.x);
+    auto issue = [&](int ph, int k0, int nk, Frag<bf16>* f, bool* valid) {  // units k0 .. k0 + nk - 1 of this wave
 #pragma unroll
-        for (int u0 = 0; u0 < UNITS; u0 += 4 * NP) {
+        for (int k = 0; k < nk; ++k) {
+            const int u = 4 * (k0 + k) + wave;
+            const int pg = u / 3, j = u - pg * 3;
+            const int p = pg * PPI + rp;
+            const int py = p / TINW, px = p - py * TINW;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            valid[k] = u < UNITS && p < TINW * TINH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
+            const bf16* src = xin + ((size_t)(b * c.H + (valid[k] ? gy : 0)) * c.W + (valid[k] ? gx : 0)) * CI + (ph * KG_RES + j * LP + kq) * 8;
+            f[k] = *reinterpret_cast<const Frag<bf16>*>(src);
+        }
+    };
+    auto commit = [&](int k0, int nk, const Frag<bf16>* f, const bool* valid) {
+#pragma unroll
+        for (int k = 0; k < nk; ++k) {
+            const int u = 4 * (k0 + k) + wave;
+            const int pg = u / 3, j = u - pg * 3;
+            const int p = pg * PPI + rp;
+            if (u < UNITS && p < IN_ROWS) Ain[(j * LP + kq) * IN_RS + p] = frag_keep_if(valid[k], f[k]);
+        }
+    };
+    {
+        constexpr int NP = PH == 1 ? 6 : NU;  // loads in flight
+#pragma unroll
+        for (int k0 = 0; k0 < NU; k0 += NP) {
             Frag<bf16> f[NP];
             bool valid[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int u = u0 + 4 * k + wave;
-                const int pg = u / 3, j = u - pg * 3;
-                const int p = pg * 8 + r8;
-                const int py = p / TINW, px = p - py * TINW;
-                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-                valid[k] = u < UNITS && p < TINW * TINH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
-                const bf16* src = xin + ((size_t)(b * c.H + (valid[k] ? gy : 0)) * c.W + (valid[k] ? gx : 0)) * CI + (j * 8 + kq) * 8;
-                f[k] = *reinterpret_cast<const Frag<bf16>*>(src);
-            }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int u = u0 + 4 * k + wave;
-                const int pg = u / 3, j = u - pg * 3;
-                if (u < UNITS) Ain[(j * 8 + kq) * IN_RS + pg * 8 + r8] = frag_keep_if(valid[k], f[k]);
-            }
+            issue(0, k0, NP, f, valid);
+            commit(k0, NP, f, valid);
         }
         if (threadIdx.x < 2 * KG_MID) {  // margin cells of the intermediate image (read by discarded edge columns only; keep them finite)
             Frag<bf16> z;
@@ -91,6 +113,9 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
             Amid[(threadIdx.x >> 1) * MID_ROWS + ((threadIdx.x & 1) ? 1 + TIW * TIH : 0)] = z;
         }
     }
+    Frag<bf16> f1[PH == 1 ? 1 : NU];  // phase 1 of the halo: requested now, written to LDS between the phases
+    bool v1[PH == 1 ? 1 : NU];
+    if constexpr (PH == 2) issue(1, 0, NU, f1, v1);
     __syncthreads();
 
     Frag<bf16> r2[RING2][3];
@@ -105,10 +130,15 @@ __global__ __launch_bounds__(256) void sr_cab_kernel(SrCab c) {
         const Frag<bf16>* abase0 = Ain + (wm * R1) * TINW + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < KCT1; ++tt) {
-            const int tap = tt / KC_IN, kc = tt - tap * KC_IN;
+            const int tp = tt % (9 * KC_PH), tap = tp / KC_PH, kc = tp - tap * KC_PH;
+            if (PH == 2 && tt == 9 * KC_PH) {  // phase boundary: every wave is done with the first 96 channels of the halo
+                __syncthreads();
+                commit(0, NU, f1, v1);
+                __syncthreads();
+            }
             if (tt + RING1 - 1 < KCT1) {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) r1[(tt + RING1 - 1) % RING1][n] = W1[((size_t)n * KCT1 + tt + RING1 - 1) * 64];
+                for (int n = 0; n < 2; ++n) r1[(tt + RING1 - 1) % RING1][n] = W1[((size_t)n * KCT1 + chunk_of(tt + RING1 - 1)) * 64];
             } else if (tt + RING1 - 1 - KCT1 < RING2 - 1) {  // tail of conv1: start conv2's weight stream
                 const int s = tt + RING1 - 1 - KCT1;
 #pragma unroll
