@@ -189,8 +189,13 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
 //     each S^T tile is initialised by one coalesced 1 KiB load and the K Q^T MFMAs accumulate on top of it;
 //   * the 4 waves of a workgroup are 4 consecutive windows of the same (head, query block): they read the same bias
 //     tiles, which therefore come from the CU's L1.
+// 221 VGPRs at two workgroups per CU (HAT x4 b4: 768 workgroups = 1.5 residency rounds); forcing three (168 VGPRs) spills 53 registers:
+// HAT b4 3.37 -> 4.49 ms.  The double-buffered bias + K fragments of the next key block are most of the registers.
+#ifndef SR_ATTN_FLASH_WGS
+#define SR_ATTN_FLASH_WGS 2
+#endif
 template <typename TC, int KT, int QT, int DC>
-__global__ __launch_bounds__(256, 2) void sr_window_attn_flash_kernel(SrWindowAttn a) {
+__global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_kernel(SrWindowAttn a) {
     static_assert(KT % 4 == 0 && KT % QT == 0, "key blocks of 64");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
