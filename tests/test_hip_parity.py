@@ -628,6 +628,48 @@ def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launche
         assert float((new - old).pow(2).mean().sqrt()) <= 1.5e-3 * scale
 
 
+@pytest.mark.parametrize("ws", [8, 16])
+def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
+    """sr_swin_tail's optional last stage (LayerNorm1 + QKV of the NEXT block on the same tokens, scattered into that block's window order:
+    q2 / k2 / vt2, shift2) against sr_swin_qkv run on the tail's output with the next block's stream: same bits, both shift orders."""
+    from studiosr_amd.models import swinir as SW
+
+    torch.manual_seed(33)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=33).to(DEV).eval().set_precision("bf16")
+    cdt = torch.bfloat16
+    lp = m._get_packed(cdt)["layers"][0]
+    geo = lp["geo"]
+    b0, b1 = lp["blocks"]  # shifts 0 and ws / 2
+    B, H, W = 2, 3 * ws, 2 * ws
+    M = B * H * W
+    nb = M // geo.ntok
+    skip = torch.randn(B, H, W, geo.Cp, device=DEV)
+    skip[..., geo.C:] = 0
+    o = (torch.randn(M, geo.HP, device=DEV) * 0.5).to(cdt)
+    o.view(M, geo.heads, geo.hd_p)[..., geo.hd:] = 0
+    for cur, nxt in ((b0, b1), (b1, b0)):
+        stream = torch.cat([cur["tail_stream"], nxt["qkv_stream"]]).contiguous()
+        out = torch.full_like(skip, float("nan"))
+        q2 = torch.full((nb, geo.heads, geo.ntok, geo.hd_p), float("nan"), device=DEV).to(cdt)
+        k2, vt2 = torch.full_like(q2, float("nan")), torch.full((nb, geo.heads, geo.hd_p, geo.ntok), float("nan"), device=DEV).to(cdt)
+        ops.swin_tail(x=skip.data_ptr(), out=out.data_ptr(), o=o.data_ptr(), wstream=stream.data_ptr(), bproj=cur["proj_b"].data_ptr(), B=B, H=H, W=W,
+                      C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=cur["shift"], Hp=geo.hid_p, eps=1e-5,
+                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, q2=q2.data_ptr(), k2=k2.data_ptr(), vt2=vt2.data_ptr(), shift2=nxt["shift"])
+        want = [torch.full_like(q2, float("nan")), torch.full_like(k2, float("nan")), torch.full_like(vt2, float("nan"))]
+        ops.swin_qkv(x=out.data_ptr(), q=want[0].data_ptr(), k=want[1].data_ptr(), vt=want[2].data_ptr(), wstream=nxt["qkv_stream"].data_ptr(), B=B, H=H, W=W,
+                     C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=nxt["shift"], eps=1e-5, y_mode=L.Y_ROLL,
+                     compute_dtype=L.SR_BF16)
+        torch.cuda.synchronize()
+        plain = torch.full_like(skip, float("nan"))  # and the stream output itself does not depend on the fused stage
+        ops.swin_tail(x=skip.data_ptr(), out=plain.data_ptr(), o=o.data_ptr(), wstream=cur["tail_stream"].data_ptr(), bproj=cur["proj_b"].data_ptr(), B=B, H=H,
+                      W=W, C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=cur["shift"], Hp=geo.hid_p, eps=1e-5,
+                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16)
+        assert torch.equal(out, plain) and not torch.isnan(out).any()
+        for got, ref, name in zip((q2, k2, vt2), want, "q k vt".split()):
+            assert not torch.isnan(got.float()).any(), name
+            assert torch.equal(got, ref), f"{name}: shift {cur['shift']} -> {nxt['shift']}, max diff {float((got.float() - ref.float()).abs().max()):.3e}"
+
+
 def test_cab_fused_equals_two_conv_launches_and_a_torch_reference():
     """sr_cab_fused (hat.py:41-49: conv 180 -> 60, GELU, conv 60 -> 180 in one launch, intermediate in LDS, per-tile pool sums) against the
     two sr_conv3x3 launches it replaces (same packed weights) and against torch convs on the bf16-rounded operands, on an image that is not a
