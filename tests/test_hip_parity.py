@@ -670,6 +670,43 @@ def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
             assert torch.equal(got, ref), f"{name}: shift {cur['shift']} -> {nxt['shift']}, max diff {float((got.float() - ref.float()).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("ws", [8, 16])
+def test_swin_qkv_overlapping_cross_attention_layouts_against_the_gemm_epilogue(ws):
+    """sr_swin_qkv with oca_pad > 0 (hat.py:247-264: k in zero-bordered image order, v^T in zero-bordered planes, q in window order) against
+    sr_gemm's SR_EPI_QKV_OCA on the same stream tensor: same values to bf16 rounding, and the zero border is never written."""
+    torch.manual_seed(35)
+    m = _randomised(S.HAT(scale=2, depths=[1], num_heads=[6], window_size=ws), seed=35).to(DEV).eval().set_precision("bf16")
+    cdt = torch.bfloat16
+    P = m._get_packed(cdt)
+    op, geo, e = P["layers"][0]["ocab"], P["layers"][0]["geo"], P["border"]
+    assert e % 4 == 0 and "qkv_stream" in op
+    B, H, W = 2, 2 * ws, 3 * ws
+    M = B * H * W
+    nb = M // geo.ntok
+    t = torch.randn(B, H, W, geo.Cp, device=DEV)
+    t[..., geo.C:] = 0
+
+    def buffers():
+        return (torch.zeros(nb, geo.heads, geo.ntok, geo.hd_p, device=DEV).to(cdt), torch.zeros(B, H + 2 * e, W + 2 * e, geo.heads, geo.hd_p, device=DEV).to(cdt),
+                torch.zeros(B, geo.heads, geo.hd_p, H + 2 * e, W + 2 * e, device=DEV).to(cdt))
+
+    q1, k1, v1 = buffers()
+    ops.swin_qkv(x=t.data_ptr(), q=q1.data_ptr(), k=k1.data_ptr(), vt=v1.data_ptr(), wstream=op["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=geo.Cp,
+                 ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=0, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, oca_pad=e)
+    q0, k0, v0 = buffers()
+    ops.gemm(A=t.data_ptr(), Wp=op["qkv_w"].data_ptr(), bias=op["qkv_b"].data_ptr(), ln_gamma=None, ln_beta=None, ln_norm_only=1, out=q0.data_ptr(),
+             out_k=k0.data_ptr(), out_vt=v0.data_ptr(), M=M, K=geo.Cp, N=3 * geo.HP, k_real=geo.C, lda=geo.Cp, a_dtype=L.SR_F32, out_dtype=L.SR_BF16,
+             compute_dtype=L.SR_BF16, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY, H=H, W=W, ws=geo.ws, shift=0,
+             epi=L.EPI_QKV_OCA, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5, oca_pad=e)
+    torch.cuda.synchronize()
+    for got, ref, name in ((q1, q0, "q"), (k1, k0, "k"), (v1, v0, "vt")):
+        g, r = got.float(), ref.float()
+        assert float((g - r).abs().max()) <= 2.0e-2 * max(1.0, float(r.abs().max())), name
+    assert float(k1[:, :e].abs().max()) == 0.0 and float(k1[:, -e:].abs().max()) == 0.0 and float(k1[:, :, :e].abs().max()) == 0.0 and float(k1[:, :, -e:].abs().max()) == 0.0
+    assert float(v1[..., :e, :].abs().max()) == 0.0 and float(v1[..., -e:, :].abs().max()) == 0.0 and float(v1[..., :e].abs().max()) == 0.0 and float(v1[..., -e:].abs().max()) == 0.0
+    assert float(k1[:, e:-e, e:-e].abs().max()) > 0.0 and float(v1[..., e:-e, e:-e].abs().max()) > 0.0
+
+
 def test_cab_fused_equals_two_conv_launches_and_a_torch_reference():
     """sr_cab_fused (hat.py:41-49: conv 180 -> 60, GELU, conv 60 -> 180 in one launch, intermediate in LDS, per-tile pool sums) against the
     two sr_conv3x3 launches it replaces (same packed weights) and against torch convs on the bf16-rounded operands, on an image that is not a
