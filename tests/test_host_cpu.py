@@ -221,3 +221,49 @@ def test_swin_block_stream_packing_places_every_fragment():
         else:
             want = 0.0
         assert frag(8 * p + 6 + c2, 3 * w + n, i, k) == want, ("proj", p, c2, w, n, i, k)
+
+
+def test_swin_qkv_and_tail_stream_packing_places_every_fragment():
+    """packing.pack_swin_qkv_stream / pack_swin_tail_stream (HAT: sr_swin_qkv, sr_swin_tail) against a fragment-by-fragment restatement of the
+    layout the kernels read: slot, fragment 3 w + t, lane 16 g + i, element j  <->  row 16 tile + i, k = 32 chunk + 8 g + j."""
+    import torch
+
+    from studiosr_amd import packing as P
+
+    g = torch.Generator().manual_seed(5)
+    C, heads, hidden, hd = 180, 6, 360, 30
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * 0.05, torch.randn(3 * C, generator=g) * 0.1
+    proj_w = torch.randn(C, C, generator=g) * 0.05
+    fc1_w, fc1_b = torch.randn(hidden, C, generator=g) * 0.05, torch.randn(hidden, generator=g) * 0.1
+    fc2_w, fc2_b = torch.randn(C, hidden, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    sq = P.pack_swin_qkv_stream(qkv_w, qkv_b, C, heads).to(torch.float32).reshape(P.SWIN_QKV_SLOTS, 12, 64, 8)
+    stl = P.pack_swin_tail_stream(proj_w, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden).to(torch.float32).reshape(P.SWIN_TAIL_SLOTS, 12, 64, 8)
+    full = P.pack_swin_block_stream(torch.zeros(3 * C, C), None, proj_w, None, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden).to(torch.float32).reshape(48, 12, 64, 8)
+    assert torch.equal(stl[6:], full[24:])  # the MLP slots are the block kernel's (fc1 / fc2 with their biases on the constant-one channels)
+    scale = hd ** -0.5
+
+    def frag(st, slot, f, i, k):
+        return float(st[slot, f, 16 * (k // 8) + i, k % 8])
+
+    rng = torch.Generator().manual_seed(6)
+    for _ in range(400):
+        p, c, w, i, k = (int(torch.randint(0, n, (1,), generator=rng)) for n in (3, 6, 4, 16, 32))
+        hh, half = w >> 1, w & 1
+        head, d, ch = 2 * p + hh, 16 * half + i, 32 * c + k
+        for t in range(3):  # q, k, v tiles: all three biases ride on channels C, C + 1; the scale (no log2 e) is in the q rows
+            sc = scale if t == 0 else 1.0
+            if d < hd and ch < C:
+                want = float(bf(qkv_w[t * C + head * hd + d, ch] * sc))
+            elif d < hd and ch in (C, C + 1):
+                b = qkv_b[t * C + head * hd + d] * sc
+                want = float(bf(b)) if ch == C else float(bf(b - bf(b)))
+            else:
+                want = 0.0
+            assert frag(sq, 6 * p + c, 3 * w + t, i, k) == want, (p, c, w, t, i, k)
+        # projection slot c = head c of the attention output: fragment 3 w + n = output channels 48 w + 16 n + i, k = feature d of that head
+        n = p
+        row, dd = 48 * w + 16 * n + i, k
+        want = float(bf(proj_w[row, c * hd + dd])) if (row < C and dd < hd) else 0.0
+        assert frag(stl, c, 3 * w + n, i, k) == want, (c, w, n, i, k)
+
