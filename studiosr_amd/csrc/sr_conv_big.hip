@@ -22,6 +22,13 @@
 
 namespace {
 
+#ifdef SR_STAMPS
+__device__ unsigned long long sr_dbg_convbig[8];
+#define BSTAMP(i) SR_STAMP(sr_dbg_convbig, i)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+
 constexpr int BT = 16;                  // tile width (pixels) = one MFMA row tile
 constexpr int BH = BT + 2;              // halo width
 
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     constexpr int KCT = 9 * KC;
     const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
     const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+    BSTAMP(0);
 
     // plain residual convs: the skip tile is the initial accumulator (fetched now, in the accumulator layout: its latency hides under
     // the staging; in the epilogue a residual read sits on the critical path of every row-tile group: 37 -> 47 us on the RSTB conv)
@@ -133,6 +141,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
 
     for (int ph = 0; ph < PH; ++ph) {
         if constexpr (!PIPE) {
+        if (ph == 0) BSTAMP(1);
         if (ph > 0) __syncthreads();  // every wave is done reading the previous phase's tile
         // ---- stage channels [ph * KGP * 8, +KGP * 8) of the halo tile: 8 pixels x 8 K-groups per wave instruction
         {
@@ -165,6 +174,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             }
         }
         __syncthreads();
+        if (ph == 0) BSTAMP(2);
         }
 
         // ---- 9 taps x KCP chunks of this phase; weight chunk index in the packed order = tap * KC + ph * KCP + kc
@@ -258,6 +268,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         }
     }
 
+    BSTAMP(3);
     // ---- epilogue (the coalesced form of sr_conv_impl.h, same op order: (acc + bias) -> activation -> scale -> + skip -> round):
     //      each wave transposes two row tiles at a time through a private fp32 LDS tile [pixel][its NW * 16 channels] and stores / reads
     //      the residual in 16-byte pieces with adjacent lanes on adjacent addresses of one pixel
@@ -331,6 +342,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         else
             run(IntC<0>{});
     });
+    BSTAMP(4);
 }
 
 template <typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
@@ -369,6 +381,12 @@ int dispatch_big(const SrConv3x3& c, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SR_STAMPS
+extern "C" int sr_debug_convbig_stamps(unsigned long long* host8) {
+    return hipMemcpyFromSymbol(host8, HIP_SYMBOL(sr_dbg_convbig), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // true if sr_conv3x3_big covers this conv (bf16 compute, NHWC or PixelShuffle output, no pooling side output)
 bool sr_conv3x3_big_supported(const SrConv3x3& c) {
