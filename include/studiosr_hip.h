@@ -154,6 +154,7 @@ typedef struct SrSwinQkv {
     float eps;
     int y_mode;            /* SR_Y_* */
     int compute_dtype;     /* SR_BF16 */
+    int frag_order;        /* 1: q, k, vt in the fragment order of SrWindowAttn.qkv_frag (oca_pad == 0, ws 16 only) */
     int oca_pad;           /* 0: k / vt in window order (above).  > 0 (HAT OCAB, hat.py:247-264; as sr_gemm's SR_EPI_QKV_OCA): k -> zero-bordered image order
                             * [B][H+2p][W+2p][heads][hd_p], vt -> transposed zero-bordered planes [B][heads][hd_p][(H+2p)(W+2p)], p = oca_pad (multiple of 4), shift 0 */
 } SrSwinQkv;
@@ -197,6 +198,7 @@ typedef struct SrSwinTail {
      * the next block (48 slots in all).  Layouts as SrSwinQkv; y_mode must be SR_Y_ROLL; both shifts multiples of 4. */
     void* q2; void* k2; void* vt2;
     int shift2;
+    int frag_order;        /* as SrSwinQkv.frag_order, for q2 / k2 / vt2 */
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);
@@ -309,6 +311,9 @@ typedef struct SrWindowAttn {
     int y_mode;           /* SR_Y_* */
     const float* bias_frag; /* optional: the same bias in accumulator-fragment order [heads][qt][kt][lane][4]
                              * (element = bias[h][16 qt + (lane & 15)][16 kt + 4 (lane >> 4) + r]); selects the flash-form kernel */
+    int qkv_frag;           /* 1 (ABI v6; bf16, ntok 256, hd_p 32): q, k, vt are in FRAGMENT order as written by sr_swin_qkv / sr_swin_tail with frag_order = 1
+                             * (q, k: [tile of 16 tokens][lane = 16 g + i][8] = token 16 tile + i, features 8 g ..; vt: [64-key block][d tile][32-key step][lane][8]
+                             * = d 16 dt + i, keys 64 kb + 32 ks + 16 (e >> 2) + 4 g + (e & 3)): every operand fragment is one coalesced 1-KiB load */
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
 

@@ -71,7 +71,7 @@ class SrSwinQkv(C.Structure):
     _fields_ = [
         ("x", _vp), ("q", _vp), ("k", _vp), ("vt", _vp), ("wstream", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
-        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i), ("oca_pad", _i),
+        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i), ("frag_order", _i), ("oca_pad", _i),
     ]
 
 
@@ -82,7 +82,7 @@ class SrSwinTail(C.Structure):
         ("shift", _i), ("Hp", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
         ("n1", _vp), ("n1_gamma", _vp), ("n1_beta", _vp), ("ldn", _i),
         ("pool_partial", _vp), ("ca_w1", _vp), ("ca_b1", _vp), ("ca_w2", _vp), ("ca_b2", _vp), ("ca_Cr", _i), ("ca_n_tiles", _i), ("y_scale", _f),
-        ("q2", _vp), ("k2", _vp), ("vt2", _vp), ("shift2", _i),
+        ("q2", _vp), ("k2", _vp), ("vt2", _vp), ("shift2", _i), ("frag_order", _i),
     ]
 
 
@@ -117,7 +117,7 @@ class SrWindowAttn(C.Structure):
     _fields_ = [
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
         ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
-        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i), ("y_mode", _i), ("bias_frag", _vp),
+        ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i), ("y_mode", _i), ("bias_frag", _vp), ("qkv_frag", _i),
     ]
 
 

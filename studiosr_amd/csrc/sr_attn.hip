@@ -194,8 +194,13 @@ __global__ __launch_bounds__(256) void sr_window_attn_kernel(SrWindowAttn a) {
 #ifndef SR_ATTN_FLASH_WGS
 #define SR_ATTN_FLASH_WGS 2
 #endif
-template <typename TC, int KT, int QT, int DC>
+// FR (SrWindowAttn.qkv_frag, hd_p == 32): q, k and v^T arrive in FRAGMENT order -- q / k as [tile of 16 tokens][lane][8], v^T as [64-key block][d tile][32-key
+// step][lane][8] (written so by sr_swin_qkv / sr_swin_tail) -- so that every operand fragment is ONE fully coalesced 1-KiB load (lane * 16 B).  In the
+// row-major layouts adjacent lanes sit on different rows (64 B / 512 B apart): four cache lines per quad of lanes, ~125 cycles of issue per load, 14 loads
+// per key block (profiles/r03_window_attention_ablation.txt).
+template <typename TC, int KT, int QT, int DC, bool FR = false>
 __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_kernel(SrWindowAttn a) {
+    static_assert(!FR || DC == 1, "fragment order: head_dim 32");
     static_assert(KT % 4 == 0 && KT % QT == 0, "key blocks of 64");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,7 +225,12 @@ __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_k
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int c = 0; c < DC; ++c) qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
+        for (int c = 0; c < DC; ++c) {
+            if constexpr (FR)
+                qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 64 + lane) * 8);
+            else
+                qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
+        }
 
     // shift mask (common.py:250-274): label(q) != label(k)  <=>  the row halves differ (last window row only) or the column
     // halves differ (last window column only).  ws % 4 == 0, so the 4 keys of a lane group share a window row.
@@ -261,7 +271,12 @@ __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_k
 #pragma unroll
             for (int t = 0; t < QT; ++t) b[j][t] = bfrag[((size_t)t * KT + kb * 4 + j) * 64];
 #pragma unroll
-            for (int c = 0; c < DC; ++c) kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
+            for (int c = 0; c < DC; ++c) {
+                if constexpr (FR)
+                    kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 64 + lane) * 8);
+                else
+                    kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
+            }
         }
     };
     if constexpr (PF) fetch(0, bb[0], kk[0]);
@@ -274,7 +289,12 @@ __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_k
             for (int dt = 0; dt < 2 * DC; ++dt) {
                 const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+                for (int ks = 0; ks < 2; ++ks) {
+                    if constexpr (FR)
+                        vf[dt][ks] = *reinterpret_cast<const Frag<TC>*>(vt + (size_t)(((kb * 2 + dt) * 2 + ks) * 64 + lane) * 8);
+                    else
+                        vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+                }
             }
             if (kb + 1 < KT / 4) fetch(kb + 1, bb[(kb + 1) & 1], kk[(kb + 1) & 1]);
         } else {
@@ -369,10 +389,10 @@ __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_k
     }
 }
 
-template <typename TC, int KT, int QT, int DC>
+template <typename TC, int KT, int QT, int DC, bool FR = false>
 int launch_flash(const SrWindowAttn& a, hipStream_t st) {
     const int items = a.n_bwin * a.heads * (KT / QT);
-    hipLaunchKernelGGL((sr_window_attn_flash_kernel<TC, KT, QT, DC>), dim3((items + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_window_attn_flash_kernel<TC, KT, QT, DC, FR>), dim3((items + 3) / 4), dim3(256), 0, st, a);
     SR_CHECK_LAUNCH("sr_window_attention");
     return SR_OK;
 }
@@ -388,7 +408,12 @@ int launch_attn(const SrWindowAttn& a, hipStream_t st) {
 template <typename TC>
 int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
     if (a.bias_frag && a.ws % 4 == 0) {  // fragment-ordered bias available: flash form
-        if (a.ntok == 256 && a.hd_p == 32) return launch_flash<TC, 16, 2, 1>(a, st);  // 2 query tiles per wave: ~120 VGPRs, 4 waves per SIMD hide the per-block load latency
+        if (a.ntok == 256 && a.hd_p == 32) {
+            if constexpr (sizeof(TC) == 2) {
+                if (a.qkv_frag) return launch_flash<TC, 16, 2, 1, true>(a, st);
+            }
+            return launch_flash<TC, 16, 2, 1>(a, st);  // 2 query tiles per wave, two workgroups per CU
+        }
         if (a.ntok == 64 && a.hd_p == 32) return launch_flash<TC, 4, 4, 1>(a, st);
         if (a.ntok == 256 && a.hd_p == 64) return launch_flash<TC, 16, 2, 2>(a, st);
         if (a.ntok == 64 && a.hd_p == 64) return launch_flash<TC, 4, 4, 2>(a, st);
@@ -409,6 +434,7 @@ extern "C" int sr_window_attention(const SrWindowAttn* p, void* stream) {
     SR_REQUIRE(a.ws > 0 && a.ntok == a.ws * a.ws && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws,
                "sr_window_attention: bad geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_window_attention: n_bwin");
+    SR_REQUIRE(!a.qkv_frag || (a.dtype == SR_BF16 && a.ntok == 256 && a.hd_p == 32 && a.bias_frag && a.ws % 4 == 0), "sr_window_attention: qkv_frag needs bf16, 16 x 16 windows, hd_p 32 and bias_frag");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return a.dtype == SR_BF16 ? dispatch_attn<bf16>(a, st) : dispatch_attn<float>(a, st);
 }

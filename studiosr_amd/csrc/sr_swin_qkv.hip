@@ -148,6 +148,22 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
         });
         const int head = 2 * p + hh;
         const size_t bh = bwin * a.heads + head;
+        if (a.frag_order) {
+            // fragment order (SrWindowAttn.qkv_frag): q / k cell [tile = token >> 4][g = feature >> 3][i = token & 15][8]; v^T cell
+            // [64-key block][d tile][32-key step][g = (key >> 2) & 3][i = d & 15][8] with element (key >> 4 & 1) * 4 + (key & 3)
+            const size_t base = (bh << ntok_log2) * a.hd_p;
+            bf16* qd = reinterpret_cast<bf16*>(a.q) + base + (size_t)(((part * 4) * 4 + 2 * half + (ag >> 1)) * 16 + ar) * 8 + 4 * (ag & 1);
+            bf16* kd = reinterpret_cast<bf16*>(a.k) + base + (size_t)(((part * 4) * 4 + 2 * half + (ag >> 1)) * 16 + ar) * 8 + 4 * (ag & 1);
+            bf16* vd = reinterpret_cast<bf16*>(a.vt) + base + (size_t)(((part * 2 + half) * 2) * 64 + ag * 16 + ar) * 8;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *reinterpret_cast<bf16x4*>(qd + m * 4 * 16 * 8) = cvt4(acc[m][0]);
+                *reinterpret_cast<bf16x4*>(kd + m * 4 * 16 * 8) = cvt4(acc[m][1]);
+                *reinterpret_cast<bf16x4*>(vd + (m >> 1) * 64 * 8 + (m & 1) * 4) = cvt4(acc[m][2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
         bf16* qd = reinterpret_cast<bf16*>(a.q) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
 #pragma unroll
         for (int m = 0; m < 4; ++m) *reinterpret_cast<bf16x4*>(qd + m * 16 * a.hd_p) = cvt4(acc[m][0]);
@@ -197,6 +213,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_qkv: bad geometry");
+    SR_REQUIRE(!a.frag_order || (a.ws == 16 && a.oca_pad == 0 && a.hd_p == 32), "sr_swin_qkv: frag_order needs 16 x 16 windows and oca_pad == 0");
     SR_REQUIRE(a.oca_pad == 0 || (a.oca_pad > 0 && a.oca_pad % 4 == 0 && a.shift == 0 && a.y_mode == SR_Y_ROLL), "sr_swin_qkv: OCA layouts need shift 0 and a border that is a multiple of 4");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");
     SwinQkvDev dv;

@@ -410,10 +410,18 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
             const int head = 2 * p + hh;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const size_t qo = ((((size_t)(qbw[m] + head)) << ntok_log2) + qtok[m]) * a.hd_p + 16 * half + 4 * ag;
+                size_t qo, vo;
+                if (a.frag_order) {  // fragment order of SrWindowAttn.qkv_frag (see sr_swin_qkv.hip); token = qtok / vtok of the next block's window
+                    qo = (((size_t)(qbw[m] + head)) << ntok_log2) * a.hd_p + (size_t)(((qtok[m] >> 4) * 4 + 2 * half + (ag >> 1)) * 16 + (qtok[m] & 15)) * 8 + 4 * (ag & 1);
+                    const int t6 = vtok[m] & 63;
+                    vo = (((size_t)(vbw[m] + head)) << ntok_log2) * a.hd_p +
+                         (size_t)((((vtok[m] >> 6) * 2 + half) * 2 + (t6 >> 5)) * 64 + ((t6 >> 2) & 3) * 16 + ar) * 8 + ((t6 >> 4) & 1) * 4;
+                } else {
+                    qo = ((((size_t)(qbw[m] + head)) << ntok_log2) + qtok[m]) * a.hd_p + 16 * half + 4 * ag;
+                    vo = (((size_t)(vbw[m] + head) * a.hd_p + 16 * half + ar) << ntok_log2) + vtok[m];
+                }
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.q2) + qo) = cvt4(acc[m][0]);
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k2) + qo) = cvt4(acc[m][1]);
-                const size_t vo = (((size_t)(vbw[m] + head) * a.hd_p + 16 * half + ar) << ntok_log2) + vtok[m];
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt2) + vo) = cvt4(acc[m][2]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -449,6 +457,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0), "sr_swin_tail: the LayerNorm side output needs n1_gamma, n1_beta, ldn");
     SR_REQUIRE(!a.q2 || (a.k2 && a.vt2 && a.shift2 >= 0 && a.shift2 < a.ws && a.shift2 % 4 == 0 && a.shift % 4 == 0 && a.y_mode == SR_Y_ROLL),
                "sr_swin_tail: the fused next-block QKV needs q2 / k2 / vt2, shifts that are multiples of 4 and y_mode SR_Y_ROLL");
+    SR_REQUIRE(!a.frag_order || (a.q2 && a.ws == 16), "sr_swin_tail: frag_order is a layout of q2 / k2 / vt2 for 16 x 16 windows");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;
     dv.a = a;

@@ -41,6 +41,7 @@ from .swinir import (
     pack_mlp,
     pack_qkv_stream,
     pack_tail_stream,
+    qkv_frag_order,
     run_mlp,
     run_swin_tail,
     run_window_msa,
@@ -350,7 +351,8 @@ class HAT(Model):
             if fuse_next_qkv:
                 nb_ = B * H * W // geo.ntok
                 d.update(qkv_next=dict(q=ws_.get("hab.q", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt), k=ws_.get("hab.k", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt),
-                                       vt=ws_.get("hab.vt", (nb_, geo.heads, geo.hd_p, geo.ntok), cdt), shift=next_bp["shift"]))
+                                       vt=ws_.get("hab.vt", (nb_, geo.heads, geo.hd_p, geo.ntok), cdt), shift=next_bp["shift"],
+                                       frag=qkv_frag_order(next_bp, geo, Cp, cdt)))
             if gate_in_tail:
                 d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
                                  ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))

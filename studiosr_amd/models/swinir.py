@@ -183,6 +183,12 @@ def swin_qkv_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bo
             and ops.swin_qkv_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, L.SR_BF16))
 
 
+def qkv_frag_order(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
+    """q / k / v^T between sr_swin_qkv (or sr_swin_tail's fused QKV stage) and sr_window_attention in FRAGMENT order (every operand fragment of the attention
+    kernel = one coalesced 1-KiB load): 16 x 16 windows, bf16, stream-form producer.  SR_QKV_FRAG=0 keeps the row-major layouts."""
+    return geo.ntok == 256 and geo.hd_p == 32 and swin_qkv_usable(p, geo, Cp, cdt) and os.environ.get("SR_QKV_FRAG", "1") != "0"
+
+
 def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_TAIL=0 keeps the projection GEMM + MLP kernel (A/B switch, read per call)."""
     return ("tail_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_TAIL", "1") != "0"
@@ -201,7 +207,8 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     wstream = p["tail_stream"]
     if qkv_next is not None:
         wstream = p["tail_qkv_stream"]
-        kw.update(q2=qkv_next["q"].data_ptr(), k2=qkv_next["k"].data_ptr(), vt2=qkv_next["vt"].data_ptr(), shift2=int(qkv_next["shift"]))
+        kw.update(q2=qkv_next["q"].data_ptr(), k2=qkv_next["k"].data_ptr(), vt2=qkv_next["vt"].data_ptr(), shift2=int(qkv_next["shift"]),
+                  frag_order=int(bool(qkv_next.get("frag"))))
     if n1 is not None:
         assert n1.dtype == torch.bfloat16 and n1.shape == skip.shape
         kw.update(n1=n1.data_ptr(), n1_gamma=n1_ln[0].data_ptr(), n1_beta=n1_ln[1].data_ptr(), ldn=Cp)
@@ -271,11 +278,13 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
+    frag = qkv_frag_order(p, geo, Cp, cdt)  # (a qkv_ready producer decides with the same predicate)
     if qkv_ready:
         pass
     elif swin_qkv_usable(p, geo, Cp, cdt):
         ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
-                     Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=L.SR_BF16)
+                     Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=L.SR_BF16,
+                     frag_order=int(frag))
     else:
         ops.gemm(
             A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
@@ -286,6 +295,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     ops.window_attention(
         q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
         hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
+        qkv_frag=int(frag),
     )
     extra = before_proj() if before_proj is not None else {}
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
