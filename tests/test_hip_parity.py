@@ -670,6 +670,56 @@ def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
             assert torch.equal(got, ref), f"{name}: shift {cur['shift']} -> {nxt['shift']}, max diff {float((got.float() - ref.float()).abs().max()):.3e}"
 
 
+def test_swin_qkv_fragment_order_is_a_permutation_of_the_row_major_layouts():
+    """frag_order = 1 of sr_swin_qkv and of sr_swin_tail's fused QKV stage (what sr_window_attention reads with qkv_frag = 1): q / k as
+    [16-token tile][g][i][8] = token 16 tile + i, features 8 g ..; v^T as [64-key block][d tile][32-key step][g][i][8] = d 16 dt + i, key 64 kb + 32 ks +
+    16 (e >> 2) + 4 g + (e & 3) -- exactly the row-major tensors, permuted; and both producers agree bit for bit."""
+    ws = 16
+    torch.manual_seed(37)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=37).to(DEV).eval().set_precision("bf16")
+    cdt = torch.bfloat16
+    lp = m._get_packed(cdt)["layers"][0]
+    geo = lp["geo"]
+    b0, b1 = lp["blocks"]
+    B, H, W = 2, 2 * ws, 3 * ws
+    M = B * H * W
+    nb = M // geo.ntok
+    t = torch.randn(B, H, W, geo.Cp, device=DEV)
+    t[..., geo.C:] = 0
+
+    def qkv(bp, frag):
+        q = torch.full((nb, geo.heads, geo.ntok, geo.hd_p), float("nan"), device=DEV).to(cdt)
+        k, vt = torch.full_like(q, float("nan")), torch.full((nb, geo.heads, geo.hd_p, geo.ntok), float("nan"), device=DEV).to(cdt)
+        ops.swin_qkv(x=t.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=bp["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=geo.Cp,
+                     ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=bp["shift"], eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, frag_order=frag)
+        torch.cuda.synchronize()
+        return q, k, vt
+
+    for bp in (b0, b1):
+        q0, k0, v0 = qkv(bp, 0)
+        q1, k1, v1 = qkv(bp, 1)
+        for row, frag in ((q0, q1), (k0, k1)):
+            want = row.view(nb, geo.heads, 16, 16, 4, 8).permute(0, 1, 2, 4, 3, 5)  # [tile][i][g][e] -> [tile][g][i][e]
+            assert torch.equal(frag.view(nb, geo.heads, 16, 4, 16, 8), want)
+        want = v0.view(nb, geo.heads, 2, 16, 4, 2, 2, 4, 4).permute(0, 1, 4, 2, 5, 7, 3, 6, 8)  # [dt][i][kb][ks][hi][g][lo] -> [kb][dt][ks][g][i][hi][lo]
+        assert torch.equal(v1.view(nb, geo.heads, 4, 2, 2, 4, 16, 2, 4), want)
+    # the fused stage of sr_swin_tail writes the same fragment-order tensors as sr_swin_qkv on its output
+    skip = torch.randn(B, H, W, geo.Cp, device=DEV)
+    skip[..., geo.C:] = 0
+    o = (torch.randn(M, geo.HP, device=DEV) * 0.5).to(cdt)
+    o.view(M, geo.heads, geo.hd_p)[..., geo.hd:] = 0
+    out = torch.empty_like(skip)
+    q2 = torch.full((nb, geo.heads, geo.ntok, geo.hd_p), float("nan"), device=DEV).to(cdt)
+    k2, vt2 = torch.full_like(q2, float("nan")), torch.full((nb, geo.heads, geo.hd_p, geo.ntok), float("nan"), device=DEV).to(cdt)
+    stream = torch.cat([b0["tail_stream"], b1["qkv_stream"]]).contiguous()
+    ops.swin_tail(x=skip.data_ptr(), out=out.data_ptr(), o=o.data_ptr(), wstream=stream.data_ptr(), bproj=b0["proj_b"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=geo.Cp,
+                  ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=b0["shift"], Hp=geo.hid_p, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16,
+                  q2=q2.data_ptr(), k2=k2.data_ptr(), vt2=vt2.data_ptr(), shift2=b1["shift"], frag_order=1)
+    t = out
+    qw, kw, vw = qkv(b1, 1)
+    assert torch.equal(q2, qw) and torch.equal(k2, kw) and torch.equal(vt2, vw)
+
+
 @pytest.mark.parametrize("ws", [8, 16])
 def test_swin_qkv_overlapping_cross_attention_layouts_against_the_gemm_epilogue(ws):
     """sr_swin_qkv with oca_pad > 0 (hat.py:247-264: k in zero-bordered image order, v^T in zero-bordered planes, q in window order) against
