@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 6
+#define SR_ABI_VERSION 7
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -463,6 +463,116 @@ int sr_pack_matrix(const float* w, long long ld, const int* row_idx, const int* 
 int sr_pack_conv3x3(const float* w, const int* row_idx, void* out, int out_dtype, int N_p, int Cout, int Cin, int cin_p, void* stream);
 int sr_pack_vector(const float* b, const int* idx, const float* scale, float* out, int n_p, int n, void* stream);
 int sr_pack_bias_fragments(const float* table, const long long* rpi, float* out, int T, int heads, int Nq, int Nk, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fast training path (ABI v7): the fused forward + backward of a training step under torch.autocast(bfloat16)
+ * (studiosr/engine/trainer.py:97-109: autocast forward, L1 loss, loss.backward(), Adam) for the default HAT / SwinIR
+ * block geometry (C 180, 6 heads, hidden 360, windows 8 / 16).  Activations between kernels are bf16 (what autocast
+ * stores), the residual stream / LayerNorm statistics / accumulators / parameters / gradients are fp32.  The host side
+ * is studiosr_amd/fasttrain.py; every other geometry and the exact-fp32 path stay on the generic engine above.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Packed operand arena <- flat fp32 parameter buffer through host-built index maps (per optimizer step, ONE launch):
+ *   v = scl[i] * (idx[i] >= 0 ? P[idx[i]] : 1) * (idx2 && idx2[i] >= 0 ? P[idx2[i]] : 1);
+ *   mode[i] == 1: v = bf16(v) (leading part of a bias carried as hi + lo on the two constant-one channels), == 2: v - bf16(v);
+ *   out[i] = (out_dtype) v.  Replaces studiosr_amd/packing.py's per-tensor torch ops in the training loop. */
+int sr_tr_gather(const float* P, const int* idx, const int* idx2, const float* scl, const unsigned char* mode, void* out, int out_dtype, long long n, void* stream);
+/* The adjoint: grad[i] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]]  (src[i] < 0: grad[i] = 0); sums in slice order. */
+int sr_tr_finalize(const float* arena, const long long* src, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream);
+
+typedef struct SrTrWgradJob {
+    /* dW[slice][tap][n][k] = sum over the slice's tokens t of A[t][n] * B[t'][k]: the weight gradient of nn.Linear (taps 1, t' = t;
+     * swinir.py:69-71, common.py:184-195) or of a 3x3 nn.Conv2d (taps 9: t' = the pixel at offset (tap / 3 - 1, tap % 3 - 1) of t in its
+     * H x W image, zero outside; A = dy, B = x, NHWC; common.py:104-105).  A, B: bf16 token-major [T, lda / ldb].  ones_col >= 0: column
+     * ones_col of B reads as 1 (bias gradient as one more column).  out: fp32 [ks][taps][Np][Kp] partial sums (ks token slices). */
+    const void* A; const void* B; float* out;
+    int lda, ldb, Np, Kp, T, taps, H, W, ones_col, ks;
+} SrTrWgradJob;
+int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream); /* jobs: HOST array, at most 8 per launch */
+long long sr_tr_wgrad_out_floats(const SrTrWgradJob* j);
+
+typedef struct SrTrAttnBwd {
+    /* Backward of softmax(q k^T + bias + shift mask) v per (window, head), flash form (swinir.py:83-102, hat.py:90-107, 266-283): P is
+     * recomputed from q, k, bias.  bf16 operands; q is pre-scaled.  Layouts: q, k, v, dq, dk, dv [bwin][head][N][32]; qT, kT, dOT
+     * [bwin][head][32][N]; o, dO rows [bwin * Nq + tok][ldo] with head h at column 32 h; bias [heads][Nq][Nk], biasT [heads][Nk][Nq] fp32;
+     * lse, delta [bwin][head][Nq] fp32 (written, then read by the second pass); dbias_part [groups][heads][Nq][Nk] fp32 = sum of dS over the
+     * windows of each group (deterministic, no atomics). */
+    const void* q; const void* qT; const void* k; const void* kT; const void* v;
+    const void* o; const void* dO; const void* dOT;
+    const float* bias; const float* biasT;
+    void* dq; void* dk; void* dv;
+    float* lse; float* delta; float* dbias_part;
+    int n_bwin, heads, hd_p, Nq, Nk, ldo, groups;
+    int H, W, ws, shift;   /* mask geometry (shift == 0: no mask) */
+} SrTrAttnBwd;
+int sr_tr_attn_bwd(const SrTrAttnBwd* a, void* stream);
+/* relative_position_bias_table gradient: dtable[rpi[ij] (negative wraps)][h] += sum_g dbias_part[g][h][ij]  (dtable zeroed by the caller). */
+int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream);
+
+int sr_tr_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp);
+
+typedef struct SrTrQkvFwd {
+    /* n1 = LayerNorm1(x) * gamma + beta (bf16, image order, channels 180 / 181 = 1; optional) and q, k, v = qkv(n1) for the window
+     * attention kernels, each in both orientations (hat.py:164-176; swinir.py:146-160).  wstream: packing of sr_swin_qkv (18 slots) with
+     * the UNFOLDED weights. */
+    const float* x; const float* gamma; const float* beta; const void* wstream;
+    void* q; void* qT; void* k; void* kT; void* v; void* vT; void* n1;
+    int B, H, W, C, Cp, ldx, ldn, heads, hd_p, ws, shift;
+    float eps;
+} SrTrQkvFwd;
+int sr_tr_qkv_fwd(const SrTrQkvFwd* a, void* stream);
+
+typedef struct SrTrTailFwd {
+    /* x1 = x + s_a[b] (proj(O) + bproj) + y * gate[b];  out = x1 + s_m[b] (fc2(GELU(fc1(LayerNorm2(x1)))) + b2)   (hat.py:172-194, 286-293;
+     * swinir.py:169-174; s_a / s_m = DropPath's per-image scale or NULL).  x1 is stored for the backward; the gate is recomputed from the
+     * CAB's pool partials (as sr_swin_tail) and optionally written to gate_out [B][Cp].  wstream: sr_swin_tail's 30 slots, unfolded weights,
+     * hidden pad columns written as s_m by the kernel. */
+    const float* x; float* out; float* x1; const void* o; const void* wstream; const float* bproj; const float* gamma; const float* beta;
+    const void* y; const float* pool_partial; const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2; float* gate_out;
+    const float* s_a; const float* s_m;
+    int B, H, W, C, Cp, ldx, ldy, heads, hd_p, ws, shift, Hp, ca_Cr, ca_n_tiles;
+    float eps, y_scale;
+} SrTrTailFwd;
+int sr_tr_tail_fwd(const SrTrTailFwd* a, void* stream);
+
+typedef struct SrTrTailBwd {
+    /* Adjoint of sr_tr_tail_fwd.  In: dout (gradient of out), x1, y, gate [B][Cp].  Out: dx1 (fp32, image order); bf16 token-major operands of
+     * the weight-gradient GEMMs in WINDOW order: n2w [T][Cp] (LayerNorm2 output, ones in 180 / 181), doutw [T][Cp], gw [T][Hp] (s_m GELU(h),
+     * s_m in columns 360 / 361), dhw [T][Hp], dx1sw [T][Cp] (s_a dx1); dOw [T][Cp] and dOT [bwin][head][32][ntok] = gradient of the attention
+     * output; dyc (bf16, image order, ldy) = dx1 * gate; dgate_part [T / 64][Cp] = per-workgroup sums of dx1 * y; ln_part [T / 64][2][Cp] =
+     * per-workgroup LayerNorm2 dgamma | dbeta.  wstream: 42 slots (fasttrain.py pack_tail_bwd). */
+    const float* dout; const float* x1; const void* y; const float* gate; const float* gamma; const float* beta; const void* wstream;
+    const float* s_a; const float* s_m;
+    float* dx1; void* n2w; void* doutw; void* gw; void* dhw; void* dOw; void* dOT; void* dx1sw; void* dyc; float* dgate_part; float* ln_part;
+    int B, H, W, C, Cp, ldx, ldy, heads, hd_p, ws, shift, Hp;
+    float eps;
+} SrTrTailBwd;
+int sr_tr_tail_bwd(const SrTrTailBwd* a, void* stream);
+
+typedef struct SrTrQkvBwd {
+    /* Adjoint of sr_tr_qkv_fwd: dn1 = [dq | dk | dv] Wqkv (+ dn1c, the CAB branch's gradient w.r.t. n1, bf16 image order), LayerNorm1
+     * backward, dx = dx1 + ...  Also writes n1w [T][Cp] (LayerNorm1 output in window order) and dqkvw [T][3 * heads * 32] (the same gradients
+     * token-major): the operands of the qkv weight gradient, and ln_part [T / 64][2][Cp].  wstream: 18 slots (fasttrain.py pack_qkv_bwd). */
+    const float* dx1; const float* x; const void* dq; const void* dk; const void* dv; const void* dn1c; const float* gamma; const float* beta; const void* wstream;
+    float* dx; void* n1w; void* dqkvw; float* ln_part;
+    int B, H, W, C, Cp, ldx, ldn, heads, hd_p, ws, shift;
+    float eps;
+} SrTrQkvBwd;
+int sr_tr_qkv_bwd(const SrTrQkvBwd* a, void* stream);
+
+typedef struct SrTrCaBwd {
+    /* ChannelAttention backward of HAT's CAB (hat.py:25-38): from dgate_part (sr_tr_tail_bwd) the squeeze MLP's parameter gradients
+     * (dparam_part [B][dparam_stride]: dw1 [Cr*C] | db1 [Cr] | dw2 [C*Cr] | db2 [C], one partial per image) and
+     * dy[b][px][c] += dmean[b][c] / (H W) in place (dy = dyc of sr_tr_tail_bwd, bf16 image order). */
+    const float* dgate_part; const float* pool_partial; const float* w1; const float* b1; const float* w2; const float* b2;
+    void* dy; float* dparam_part;
+    int B, H, W, C, Cp, Cr, n_tiles, parts, ld, dparam_stride;
+    float y_scale;
+} SrTrCaBwd;
+int sr_tr_ca_bwd(const SrTrCaBwd* a, void* stream);
+
+/* g = GELU(x) and / or dx = dg * GELU'(x), bf16 (the nn.GELU between the CAB's convolutions, hat.py:43); n elements, n % 8 == 0. */
+int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long long n, void* stream);
 
 #ifdef __cplusplus
 }

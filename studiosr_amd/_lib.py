@@ -24,7 +24,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -151,6 +151,60 @@ class SrBgemm(C.Structure):
     ]
 
 
+
+# ---- fast training path (ABI v7)
+class SrTrWgradJob(C.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("lda", _i), ("ldb", _i), ("Np", _i), ("Kp", _i), ("T", _i), ("taps", _i), ("H", _i), ("W", _i),
+                ("ones_col", _i), ("ks", _i)]
+
+
+class SrTrAttnBwd(C.Structure):
+    _fields_ = [
+        ("q", _vp), ("qT", _vp), ("k", _vp), ("kT", _vp), ("v", _vp), ("o", _vp), ("dO", _vp), ("dOT", _vp), ("bias", _vp), ("biasT", _vp),
+        ("dq", _vp), ("dk", _vp), ("dv", _vp), ("lse", _vp), ("delta", _vp), ("dbias_part", _vp),
+        ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i), ("groups", _i), ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
+    ]
+
+
+class SrTrQkvFwd(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("gamma", _vp), ("beta", _vp), ("wstream", _vp), ("q", _vp), ("qT", _vp), ("k", _vp), ("kT", _vp), ("v", _vp), ("vT", _vp), ("n1", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldn", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("eps", _f),
+    ]
+
+
+class SrTrTailFwd(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("out", _vp), ("x1", _vp), ("o", _vp), ("wstream", _vp), ("bproj", _vp), ("gamma", _vp), ("beta", _vp),
+        ("y", _vp), ("pool_partial", _vp), ("ca_w1", _vp), ("ca_b1", _vp), ("ca_w2", _vp), ("ca_b2", _vp), ("gate_out", _vp), ("s_a", _vp), ("s_m", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldy", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("Hp", _i),
+        ("ca_Cr", _i), ("ca_n_tiles", _i), ("eps", _f), ("y_scale", _f),
+    ]
+
+
+class SrTrTailBwd(C.Structure):
+    _fields_ = [
+        ("dout", _vp), ("x1", _vp), ("y", _vp), ("gate", _vp), ("gamma", _vp), ("beta", _vp), ("wstream", _vp), ("s_a", _vp), ("s_m", _vp),
+        ("dx1", _vp), ("n2w", _vp), ("doutw", _vp), ("gw", _vp), ("dhw", _vp), ("dOw", _vp), ("dOT", _vp), ("dx1sw", _vp), ("dyc", _vp), ("dgate_part", _vp), ("ln_part", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldy", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("Hp", _i), ("eps", _f),
+    ]
+
+
+class SrTrQkvBwd(C.Structure):
+    _fields_ = [
+        ("dx1", _vp), ("x", _vp), ("dq", _vp), ("dk", _vp), ("dv", _vp), ("dn1c", _vp), ("gamma", _vp), ("beta", _vp), ("wstream", _vp),
+        ("dx", _vp), ("n1w", _vp), ("dqkvw", _vp), ("ln_part", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldn", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("eps", _f),
+    ]
+
+
+class SrTrCaBwd(C.Structure):
+    _fields_ = [
+        ("dgate_part", _vp), ("pool_partial", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("dy", _vp), ("dparam_part", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("Cr", _i), ("n_tiles", _i), ("parts", _i), ("ld", _i), ("dparam_stride", _i), ("y_scale", _f),
+    ]
+
+
 EW_GELU_FWD, EW_GELU_BWD, EW_RELU_FWD, EW_RELU_BWD, EW_LRELU_FWD, EW_LRELU_BWD, EW_AXPBY, EW_MUL = range(8)
 EW_SIGMOID_FWD, EW_SIGMOID_BWD, EW_SCALE_SAMPLE, EW_MUL_BC, EW_BCAST_BC, EW_AFFINE_C = range(8, 14)
 
@@ -211,6 +265,20 @@ SYMBOLS = {
     "sr_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sr_pack_vector": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sr_pack_bias_fragments": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    # fast training path (ABI v7)
+    "sr_tr_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
+    "sr_tr_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "sr_tr_wgrad": (_i, [C.POINTER(SrTrWgradJob), _i, _vp]),
+    "sr_tr_wgrad_out_floats": (_ll, [C.POINTER(SrTrWgradJob)]),
+    "sr_tr_attn_bwd": (_i, [C.POINTER(SrTrAttnBwd), _vp]),
+    "sr_tr_dbias": (_i, [_vp, _i, _vp, _vp, _i, _i, _ll, _vp]),
+    "sr_tr_block_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sr_tr_qkv_fwd": (_i, [C.POINTER(SrTrQkvFwd), _vp]),
+    "sr_tr_tail_fwd": (_i, [C.POINTER(SrTrTailFwd), _vp]),
+    "sr_tr_tail_bwd": (_i, [C.POINTER(SrTrTailBwd), _vp]),
+    "sr_tr_qkv_bwd": (_i, [C.POINTER(SrTrQkvBwd), _vp]),
+    "sr_tr_ca_bwd": (_i, [C.POINTER(SrTrCaBwd), _vp]),
+    "sr_tr_gelu": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,286 @@
+// Fast training path (C ABI v7): backward of (shifted-)window attention and of HAT's overlapping cross attention, flash form
+// (swinir.py:83-102, hat.py:90-107, 266-283 under loss.backward(), trainer.py:104).  Nothing of the N x N logits is stored by the forward:
+// both passes recompute P = softmax(q k^T + bias + mask) from q, k and the bias table, in registers, exactly like the forward kernel
+// sr_window_attn_kernel (sr_attn.hip) -- one wave per item, operands straight from the [.., tok, 32] buffers, no LDS:
+//   pass Q  (item = window group x head x 16 queries; the wave walks the windows of its group)
+//           S^T = K Q^T + bias + mask -> softmax -> (lse);  dP^T = V dO^T;  delta = rowsum(dO o O);  dS = P (dP - delta);
+//           dQ = dS K (the dS accumulator is the MFMA operand, K^T comes from the transposed copy);  the bias gradient
+//           sum_windows dS stays in registers across the walk and leaves as ONE partial per group (no atomics, deterministic)
+//   pass KV (item = window x head x 16 keys)   S = Q K^T (key on the lane) + bias^T + mask, P = exp(S - lse), dP = dO V^T, dS = P (dP - delta);
+//           dV = P^T dO, dK = dS^T Q with the P / dS accumulators as operands and dO^T / Q^T from the transposed copies.
+// q is pre-scaled by hd^-0.5 (the scale lives in the packed Wq), so no scale appears here.  Layouts (bf16 unless noted):
+//   q, k, v, dq, dk, dv [bwin][head][N][32];  qT, kT, dOT [bwin][head][32][N];  o, dO rows [bwin*Nq + tok][ldo], head at column 32*head;
+//   bias [heads][Nq][Nk] fp32, biasT [heads][Nk][Nq] fp32;  lse, delta [bwin][head][Nq] fp32;  dbias partial [groups][heads][Nq][Nk] fp32.
+#include "sr_common.h"
+#include "sr_host.h"
+
+namespace {
+
+SR_DEV int region(int v, int size, int ws, int shift) { return v < size - ws ? 0 : (v < size - shift ? 1 : 2); }
+
+SR_DEV Frag<bf16> load_2x4(const bf16* p0, const bf16* p1) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
+    bf16x4 b = *reinterpret_cast<const bf16x4*>(p1);
+    Frag<bf16> f;
+    f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return f;
+}
+SR_DEV Frag<bf16> pack_p(const f32x4& a, const f32x4& b) {
+    Frag<bf16> f;
+    f.v[0] = (bf16)a[0]; f.v[1] = (bf16)a[1]; f.v[2] = (bf16)a[2]; f.v[3] = (bf16)a[3];
+    f.v[4] = (bf16)b[0]; f.v[5] = (bf16)b[1]; f.v[6] = (bf16)b[2]; f.v[7] = (bf16)b[3];
+    return f;
+}
+SR_DEV f32x4 mma_z(const Frag<bf16>& x, const Frag<bf16>& y) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, (f32x4)(0.0f), 0, 0, 0); }
+
+struct Geo {
+    int nwx, nwy, win_per_img;
+};
+
+// ---- pass Q.  KT = key tiles; Nq = 16 * QT_ALL query rows per (window, head)
+template <int KT>
+__global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(SrTrAttnBwd a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NK = KT * 16;
+    const int qtiles = a.Nq >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    const int n_items = a.groups * a.heads * qtiles;
+    if (item >= n_items) return;  // wave-uniform; no barriers
+    const int qt = item % qtiles;
+    const int gh = item / qtiles;
+    const int head = gh % a.heads, grp = gh / a.heads;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wpg = (a.n_bwin + a.groups - 1) / a.groups;
+    const int qi = qt * 16 + lr;
+
+    const float* bias = a.bias + ((size_t)head * a.Nq + qi) * NK;
+    f32x4 dbacc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) dbacc[kt] = (f32x4)(0.0f);
+
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+    for (int wi = 0; wi < wpg; ++wi) {
+        const int bwin = grp * wpg + wi;
+        if (bwin >= a.n_bwin) break;
+        const size_t bh = (size_t)bwin * a.heads + head;
+        const bf16* q = reinterpret_cast<const bf16*>(a.q) + bh * a.Nq * 32;
+        const bf16* k = reinterpret_cast<const bf16*>(a.k) + bh * NK * 32;
+        const bf16* kT = reinterpret_cast<const bf16*>(a.kT) + bh * NK * 32;
+        const bf16* v = reinterpret_cast<const bf16*>(a.v) + bh * NK * 32;
+        const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(q + (size_t)qi * 32 + lg * 8);
+        const size_t orow = ((size_t)bwin * a.Nq + qi) * a.ldo + head * 32 + lg * 8;
+        const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
+        const Frag<bf16> of = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.o) + orow);
+
+        f32x4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+            s[kt] = mma_z(kf, qf);  // S^T[key 16 kt + 4 lg + r][query lr]
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps hipcc from hoisting every operand load of the pass at once (spills)
+        }
+        // + bias (+ shift mask: 16 x 16 windows, so key 16 kt + 4 lg + r sits at window row kt, column 4 lg + r)
+        const int win = bwin % (nwx * nwy);
+        const int wy = win / nwx, wx = win - wy * nwx;
+        const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+        const int qrow = region(wy * 16 + (qi >> 4), a.H, 16, a.shift), qcol = region(wx * 16 + (qi & 15), a.W, 16, a.shift);
+        bool cdiff[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != qcol;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt] += *reinterpret_cast<const f32x4*>(bias + kt * 16 + lg * 4);
+            if (masked) {
+                const bool rdiff = region(wy * 16 + kt, a.H, 16, a.shift) != qrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rdiff || cdiff[r]) s[kt][r] += -100.0f;
+            }
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = wave_max_xor(mx, 16);
+        mx = wave_max_xor(mx, 32);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] = __expf(s[kt][r] - mx);
+                sum += s[kt][r];
+            }
+        sum = wave_sum_xor(sum, 16);
+        sum = wave_sum_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // delta = sum_d dO[q][d] O[q][d]
+        float dl = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dl += (float)dof.v[jj] * (float)of.v[jj];
+        dl = wave_sum_xor(dl, 16);
+        dl = wave_sum_xor(dl, 32);
+        if (lg == 0) {
+            a.lse[bh * a.Nq + qi] = mx + __logf(sum);
+            a.delta[bh * a.Nq + qi] = dl;
+        }
+        // dS^T = P o (V dO^T - delta)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const Frag<bf16> vf = *reinterpret_cast<const Frag<bf16>*>(v + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+            const f32x4 dp = mma_z(vf, dof);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * (dp[r] - dl);
+            dbacc[kt] += s[kt];
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // dQ[q][d] = sum_key dS[q][key] K[key][d]: operand = the dS accumulators (keys 32 ks + 4 lg + r | 32 ks + 16 + 4 lg + r per lane group)
+        f32x4 dq[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+#pragma unroll
+        for (int ks = 0; ks < KT / 2; ++ks) {
+            const Frag<bf16> pf = pack_p(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16* kp = kT + (size_t)(dt * 16 + lr) * NK + ks * 32 + lg * 4;
+                mma(load_2x4(kp, kp + 16), pf, dq[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
+            }
+            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        bf16* dqp = reinterpret_cast<bf16*>(a.dq) + (bh * a.Nq + qi) * 32 + lg * 4;
+        store4(dqp, dq[0]);
+        store4(dqp + 16, dq[1]);
+    }
+    float* dbp = a.dbias_part + (((size_t)grp * a.heads + head) * a.Nq + qi) * NK;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f32x4*>(dbp + kt * 16 + lg * 4) = dbacc[kt];
+}
+
+// ---- pass KV.  QT = query tiles (Nq / 16, even)
+template <int QT>
+__global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NQ = QT * 16;
+    const int ktiles = a.Nk >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    const int n_items = a.n_bwin * a.heads * ktiles;
+    if (item >= n_items) return;
+    const int kt = item % ktiles;
+    const size_t bh = item / ktiles;
+    const int head = (int)(bh % a.heads), bwin = (int)(bh / a.heads);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int ki = kt * 16 + lr;
+
+    const bf16* q = reinterpret_cast<const bf16*>(a.q) + bh * NQ * 32;
+    const bf16* qT = reinterpret_cast<const bf16*>(a.qT) + bh * NQ * 32;
+    const bf16* dOT = reinterpret_cast<const bf16*>(a.dOT) + bh * NQ * 32;
+    const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.k) + (bh * a.Nk + ki) * 32 + lg * 8);
+    const Frag<bf16> vf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.v) + (bh * a.Nk + ki) * 32 + lg * 8);
+    const float* biasT = a.biasT + ((size_t)head * a.Nk + ki) * NQ;
+    const float* lse = a.lse + bh * NQ;
+    const float* delta = a.delta + bh * NQ;
+
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+    const int win = bwin % (nwx * nwy);
+    const int wy = win / nwx, wx = win - wy * nwx;
+    const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+    const int krow = region(wy * 16 + (ki >> 4), a.H, 16, a.shift), kcol = region(wx * 16 + (ki & 15), a.W, 16, a.shift);
+    bool cdiff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != kcol;
+
+    f32x4 dk[2] = {(f32x4)(0.0f), (f32x4)(0.0f)}, dv[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+#pragma unroll 2
+    for (int qs = 0; qs < QT / 2; ++qs) {
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int qt = 2 * qs + h;
+            const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(q + (size_t)(qt * 16 + lr) * 32 + lg * 8);
+            const size_t orow = ((size_t)bwin * NQ + qt * 16 + lr) * a.ldo + head * 32 + lg * 8;
+            const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
+            f32x4 s = mma_z(qf, kf);        // S[query 16 qt + 4 lg + r][key lr]
+            const f32x4 dp = mma_z(dof, vf);  // dP, same layout
+            const int q0 = qt * 16 + lg * 4;
+            s += *reinterpret_cast<const f32x4*>(biasT + q0);
+            if (masked) {
+                const bool rdiff = region(wy * 16 + qt, a.H, 16, a.shift) != krow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rdiff || cdiff[r]) s[r] += -100.0f;
+            }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + q0), d4 = *reinterpret_cast<const f32x4*>(delta + q0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[h][r] = __expf(s[r] - l4[r]);
+                ds[h][r] = p[h][r] * (dp[r] - d4[r]);
+            }
+        }
+        const Frag<bf16> pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);  // row = key lr, k = queries 32 qs + 4 lg + r | + 16
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const size_t off = (size_t)(dt * 16 + lr) * NQ + qs * 32 + lg * 4;
+            mma(load_2x4(dOT + off, dOT + off + 16), pf, dv[dt]);  // C[d = 16 dt + 4 lg + r][key lr]
+            mma(load_2x4(qT + off, qT + off + 16), dsf, dk[dt]);
+        }
+    }
+    bf16* dkp = reinterpret_cast<bf16*>(a.dk) + (bh * a.Nk + ki) * 32 + lg * 4;
+    bf16* dvp = reinterpret_cast<bf16*>(a.dv) + (bh * a.Nk + ki) * 32 + lg * 4;
+    store4(dkp, dk[0]);
+    store4(dkp + 16, dk[1]);
+    store4(dvp, dv[0]);
+    store4(dvp + 16, dv[1]);
+}
+
+__global__ __launch_bounds__(256) void sr_tr_dbias_kernel(const float* __restrict__ part, int groups, const long long* __restrict__ rpi, float* __restrict__ dtable, int T, int heads,
+                                                         long long NN) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NN * heads) return;
+    const int h = (int)(idx / NN);
+    const long long ij = idx - (long long)h * NN;
+    float v = 0.f;
+    for (int g = 0; g < groups; ++g) v += part[(long long)g * heads * NN + idx];
+    long long t = rpi[ij];
+    if (t < 0) t += T;
+    atomicAdd(dtable + t * heads + h, v);
+}
+
+}  // namespace
+
+extern "C" int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream) {
+    SR_REQUIRE(dbias_part && rpi && dtable && groups > 0 && T > 0 && heads > 0 && NN > 0, "sr_tr_dbias: bad arguments");
+    hipLaunchKernelGGL(sr_tr_dbias_kernel, dim3((unsigned)((NN * heads + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dbias_part, groups, rpi, dtable, T, heads, NN);
+    SR_CHECK_LAUNCH("sr_tr_dbias");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
+    SR_REQUIRE(p && p->q && p->qT && p->k && p->kT && p->v && p->o && p->dO && p->dOT && p->bias && p->biasT && p->dq && p->dk && p->dv && p->lse && p->delta &&
+                   p->dbias_part,
+               "sr_tr_attn_bwd: null pointer");
+    const SrTrAttnBwd& a = *p;
+    SR_REQUIRE(a.hd_p == 32 && a.Nq == 256 && (a.Nk == 256 || a.Nk == 576) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 && a.groups <= a.n_bwin && a.ldo >= a.heads * 32 &&
+                   a.ldo % 8 == 0,
+               "sr_tr_attn_bwd: unsupported geometry (hd_p 32, Nq 256, Nk 256 / 576)");
+    SR_REQUIRE(a.shift == 0 || (a.Nk == a.Nq && a.ws == 16 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0),
+               "sr_tr_attn_bwd: the shift mask needs the window geometry");
+    SR_REQUIRE(a.shift == 0 || (a.ws > 0 && a.H > 0 && a.W > 0), "sr_tr_attn_bwd: geometry");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SrTrAttnBwd b = a;
+    if (b.shift == 0) {  // the kernels divide by the window geometry even when no mask applies
+        b.ws = 16;
+        b.H = b.W = 16;
+    }
+    const int items_q = a.groups * a.heads * (a.Nq / 16), items_kv = a.n_bwin * a.heads * (a.Nk / 16);
+    if (a.Nk == 256)
+        hipLaunchKernelGGL(sr_tr_attn_bwd_q_kernel<16>, dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    else
+        hipLaunchKernelGGL(sr_tr_attn_bwd_q_kernel<36>, dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    SR_CHECK_LAUNCH("sr_tr_attn_bwd (q)");
+    hipLaunchKernelGGL(sr_tr_attn_bwd_kv_kernel<16>, dim3((items_kv + 3) / 4), dim3(256), 0, st, b);
+    SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv)");
+    return SR_OK;
+}

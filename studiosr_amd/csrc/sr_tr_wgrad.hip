@@ -1,0 +1,236 @@
+// Fast training path (C ABI v7), parameter side: everything between the reference's parameter tensors and the kernels' operand layouts.
+//   sr_tr_gather    packed operand arena  <- flat fp32 parameters through host-built index maps (replaces packing.py per optimizer step)
+//   sr_tr_wgrad     weight gradients dW[n][k] = sum_t A[t][n] B[t'(t)][k] of nn.Linear / 3x3 nn.Conv2d (trainer.py:104 loss.backward():
+//                   the contraction runs over TOKENS) on the bf16 matrix cores from token-major bf16 operands, split over token slices
+//   sr_tr_finalize  flat fp32 gradient     <- the slices' partial sums through host-built index maps (the adjoint of sr_tr_gather)
+// The token-major operands ([t][n], what every producer kernel writes with coalesced rows) are the WRONG way round for an MFMA whose
+// contraction index must be contiguous per lane: the tiles are staged row-major in LDS and read back TRANSPOSED with
+// ds_read_b64_tr_b16 (a 4-row x 16-column block per 16 lanes, delivered column-major).  The contraction order inside a 32-token step
+// is permuted identically on both operands (k-group g = tokens 4g..4g+3 and 16+4g..16+4g+3): with a 160-byte row stride the eight
+// rows a 32-lane half touches per read fall into eight different 8-bank groups, so every transposed read is conflict-free.
+#include "sr_common.h"
+#include "sr_host.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ----------------------------------------------------------------------------- gather pack
+__global__ __launch_bounds__(256) void sr_tr_gather_kernel(const float* __restrict__ P, const int* __restrict__ idx, const int* __restrict__ idx2,
+                                                          const float* __restrict__ scl, const unsigned char* __restrict__ mode, void* out, int out_dtype,
+                                                          long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int a = idx[i];
+    float v = scl[i];
+    if (a >= 0) v *= P[a];
+    if (idx2) {
+        const int b = idx2[i];
+        if (b >= 0) v *= P[b];
+    }
+    const int m = mode ? mode[i] : 0;
+    if (m == 1) v = (float)(bf16)v;                       // leading bf16 of a value carried as hi + lo on two constant-one channels
+    else if (m == 2) v = v - (float)(bf16)v;              // its remainder
+    if (out_dtype == SR_BF16) reinterpret_cast<bf16*>(out)[i] = (bf16)v;
+    else reinterpret_cast<float*>(out)[i] = v;
+}
+
+// ----------------------------------------------------------------------------- finalize (adjoint of the gather)
+__global__ __launch_bounds__(256) void sr_tr_finalize_kernel(const float* __restrict__ arena, const long long* __restrict__ src, const int* __restrict__ stride,
+                                                            const int* __restrict__ ns, const float* __restrict__ scale, float* __restrict__ grad, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long s0 = src[i];
+    if (s0 < 0) {
+        grad[i] = 0.0f;
+        return;
+    }
+    const int st = stride[i], cnt = ns[i];
+    const float* p = arena + s0;
+    float acc = 0.0f;
+    int s = 0;
+    for (; s + 4 <= cnt; s += 4) {  // four partials in flight, added in slice order (deterministic)
+        const float v0 = p[(long long)s * st], v1 = p[(long long)(s + 1) * st], v2 = p[(long long)(s + 2) * st], v3 = p[(long long)(s + 3) * st];
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+    }
+    for (; s < cnt; ++s) acc += p[(long long)s * st];
+    grad[i] = acc * scale[i];
+}
+
+// ----------------------------------------------------------------------------- wgrad
+constexpr int WG_TN = 64, WG_TK = 64, WG_STEP = 32;
+constexpr int WG_LD = 160;                       // bytes per LDS tile row (64 bf16 + 32 B): see the header comment
+constexpr int WG_TILE = WG_STEP * WG_LD;         // one operand tile
+constexpr int WG_MAXJOBS = 8;
+
+struct WgradJobs {
+    SrTrWgradJob j[WG_MAXJOBS];
+    int wg0[WG_MAXJOBS + 1];  // first workgroup of each job
+    int tiles_n[WG_MAXJOBS], tiles_k[WG_MAXJOBS];
+    int n;
+};
+
+// 8 bytes of a transposed fragment: for 16-lane group g, block rows r0 .. r0+3, columns c0 .. c0+15 of a row-major bf16 tile -> lane i gets column c0 + i
+SR_DEV s16x4 tr_read(const char* tile, int r0, int c0, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    auto* ptr = (__attribute__((address_space(3))) s16x4*)(tile + (r0 + q) * WG_LD + (c0 + 4 * p) * 2);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(ptr);
+}
+
+__global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * WG_TILE];  // [buffer][operand]
+    int jb = 0;
+#pragma unroll
+    for (int i = 1; i < WG_MAXJOBS; ++i)
+        if (i < J.n && (int)blockIdx.x >= J.wg0[i]) jb = i;
+    const SrTrWgradJob& j = J.j[jb];
+    int rem = blockIdx.x - J.wg0[jb];
+    const int tk = rem % J.tiles_k[jb];
+    rem /= J.tiles_k[jb];
+    const int tn = rem % J.tiles_n[jb];
+    rem /= J.tiles_n[jb];
+    const int tap = rem % j.taps;
+    const int slice = rem / j.taps;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w >> 1, wk = w & 1;  // wave tile: 32 n x 32 k
+    const int lg = lane >> 4;
+    const int chunk = ((j.T + j.ks - 1) / j.ks + WG_STEP - 1) / WG_STEP * WG_STEP;
+    const int t_beg = slice * chunk, t_end = min(j.T, t_beg + chunk);
+    const int n0 = tn * WG_TN, k0 = tk * WG_TK;
+
+    // staging: thread -> (row = tid >> 3, 16-byte column piece = tid & 7) of both tiles
+    const int srow = tid >> 3, spc = tid & 7;
+    const bf16* A = reinterpret_cast<const bf16*>(j.A);
+    const bf16* Bm = reinterpret_cast<const bf16*>(j.B);
+    const int dy = j.taps == 9 ? tap / 3 - 1 : 0, dx = j.taps == 9 ? tap % 3 - 1 : 0;
+    const int hw = j.H * j.W;
+    const bool a_col_ok = n0 + spc * 8 < j.Np, b_col_ok = k0 + spc * 8 < j.Kp;
+    const int ones_piece = (j.ones_col >= k0 && j.ones_col < k0 + WG_TK) ? (j.ones_col - k0) >> 3 : -1;
+    const int ones_elem = (j.ones_col - k0) & 7;
+
+    bf16x8 ra, rb;
+    auto fetch = [&](int t0) {
+        const int t = t0 + srow;
+        ra = (bf16x8)(0.0f);
+        rb = (bf16x8)(0.0f);
+        if (t < t_end) {
+            if (a_col_ok) ra = *reinterpret_cast<const bf16x8*>(A + (size_t)t * j.lda + n0 + spc * 8);
+            int ts = t;
+            bool ok = true;
+            if (j.taps == 9) {
+                const int b = t / hw, p = t - b * hw, y = p / j.W, x = p - y * j.W;
+                const int ys = y + dy, xs = x + dx;
+                ok = ys >= 0 && ys < j.H && xs >= 0 && xs < j.W;
+                ts = b * hw + ys * j.W + xs;
+            }
+            if (ok) {
+                if (b_col_ok) rb = *reinterpret_cast<const bf16x8*>(Bm + (size_t)ts * j.ldb + k0 + spc * 8);
+                if (spc == ones_piece) rb[ones_elem] = (bf16)1.0f;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<bf16x8*>(smem + (2 * buf) * WG_TILE + srow * WG_LD + spc * 16) = ra;
+        *reinterpret_cast<bf16x8*>(smem + (2 * buf + 1) * WG_TILE + srow * WG_LD + spc * 16) = rb;
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4)(0.0f);
+
+    fetch(t_beg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = t_beg; t0 < t_end; t0 += WG_STEP) {
+        const bool more = t0 + WG_STEP < t_end;
+        if (more) fetch(t0 + WG_STEP);
+        const char* ta = smem + (2 * buf) * WG_TILE;
+        const char* tb = ta + WG_TILE;
+        Frag<bf16> xa[2], yb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const s16x4 a0 = tr_read(ta, 4 * lg, wn * 32 + 16 * i, lane), a1 = tr_read(ta, 16 + 4 * lg, wn * 32 + 16 * i, lane);
+            const s16x4 b0 = tr_read(tb, 4 * lg, wk * 32 + 16 * i, lane), b1 = tr_read(tb, 16 + 4 * lg, wk * 32 + 16 * i, lane);
+            xa[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            yb[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) mma(xa[a], yb[b], acc[a][b]);
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // acc[a][b]: n = n0 + 32 wn + 16 a + 4 lg + r, k = k0 + 32 wk + 16 b + (lane & 15)
+    float* out = j.out + ((size_t)(slice * j.taps + tap) * j.Np) * j.Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int k = k0 + wk * 32 + 16 * b + (lane & 15);
+            if (k >= j.Kp) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + 16 * a + 4 * lg + r;
+                if (n < j.Np) out[(size_t)n * j.Kp + k] = acc[a][b][r];
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int sr_tr_gather(const float* P, const int* idx, const int* idx2, const float* scl, const unsigned char* mode, void* out, int out_dtype, long long n,
+                            void* stream) {
+    SR_REQUIRE(P && idx && scl && out && n >= 0 && (out_dtype == SR_BF16 || out_dtype == SR_F32), "sr_tr_gather: bad arguments");
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(sr_tr_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P, idx, idx2, scl, mode, out, out_dtype, n);
+    SR_CHECK_LAUNCH("sr_tr_gather");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_finalize(const float* arena, const long long* src, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream) {
+    SR_REQUIRE(arena && src && stride && ns && scale && grad && n >= 0, "sr_tr_finalize: bad arguments");
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(sr_tr_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), arena, src, stride, ns, scale, grad, n);
+    SR_CHECK_LAUNCH("sr_tr_finalize");
+    return SR_OK;
+}
+
+extern "C" long long sr_tr_wgrad_out_floats(const SrTrWgradJob* j) { return j ? (long long)j->ks * j->taps * j->Np * j->Kp : 0; }
+
+extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
+    SR_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAXJOBS, "sr_tr_wgrad: 1..%d jobs per launch", WG_MAXJOBS);
+    WgradJobs J;
+    J.n = njobs;
+    int wg = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SrTrWgradJob& j = jobs[i];
+        SR_REQUIRE(j.A && j.B && j.out && j.T > 0 && j.Np > 0 && j.Kp > 0 && j.Np % 8 == 0 && j.Kp % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.lda >= j.Np &&
+                       j.ldb >= j.Kp && j.ks > 0 && (j.taps == 1 || j.taps == 9) && j.ones_col < j.Kp,
+                   "sr_tr_wgrad: bad job %d", i);
+        SR_REQUIRE(j.taps == 1 || (j.H > 0 && j.W > 0 && j.T % (j.H * j.W) == 0), "sr_tr_wgrad: a 3x3 job needs H, W with T = B*H*W");
+        SR_REQUIRE((((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0, "sr_tr_wgrad: operands must be 16-byte aligned");
+        J.j[i] = j;
+        J.tiles_n[i] = (j.Np + WG_TN - 1) / WG_TN;
+        J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
+        J.wg0[i] = wg;
+        wg += J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
+    }
+    J.wg0[njobs] = wg;
+    for (int i = njobs; i < WG_MAXJOBS; ++i) {
+        J.j[i] = J.j[0];
+        J.tiles_n[i] = J.tiles_k[i] = 1;
+        J.wg0[i + 1 <= WG_MAXJOBS ? i + 1 : i] = wg;
+    }
+    hipLaunchKernelGGL(sr_tr_wgrad_kernel, dim3(wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), J);
+    SR_CHECK_LAUNCH("sr_tr_wgrad");
+    return SR_OK;
+}
