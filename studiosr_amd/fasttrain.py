@@ -1,0 +1,649 @@
+"""Fast training path (C ABI v7): the training step of the reference Trainer (studiosr/engine/trainer.py:97-109: autocast(bfloat16) forward,
+L1 loss, loss.backward(), Adam) for HAT's default block geometry as fused HIP launches instead of the generic one-kernel-per-op engine
+(studiosr_amd/autograd.py).  What runs per HAB (hat.py:153-195):
+
+    forward   sr_tr_qkv_fwd -> sr_window_attention || sr_cab_fused -> sr_tr_tail_fwd                                   (4 launches)
+    backward  sr_tr_tail_bwd -> sr_tr_attn_bwd (2) + sr_tr_dbias -> CAB: conv1 recompute, sr_tr_ca_bwd, conv2 dgrad, sr_tr_gelu,
+              conv1 dgrad (the dgrads are sr_conv3x3 with flipped / transposed packed weights) -> sr_tr_qkv_bwd -> sr_tr_wgrad (6 jobs)
+
+Host-side design:
+  * FlatParams: every parameter becomes a view of ONE fp32 buffer P, its gradient a view of ONE buffer G (torch.optim / DDP see ordinary
+    tensors).
+  * Arena: the kernels' packed operands (weight streams, packed convolutions, padded vectors, gathered relative-position bias) are
+    produced from P by ONE sr_tr_gather launch per arena and optimizer step through index maps built once on the host; the maps are written
+    as the same reshape / transpose chains as studiosr_amd/packing.py, applied to parameter INDICES instead of values.
+  * The adjoint, sr_tr_finalize, turns the weight-gradient GEMMs' partial sums (and the LayerNorm / channel-attention / bias-table
+    partials) into G through index maps of the same kind: one launch per stage.
+Activations kept for the backward live in per-block static buffers (one forward in flight per model, checked).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+Tensor = torch.Tensor
+CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
+C_REAL, HID = 180, 360
+WG_KS = 8  # token slices of the weight-gradient GEMMs
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- flat parameters
+class FlatParams:
+    """All parameters of a model as views of one fp32 buffer (P) and their gradients as views of another (G)."""
+
+    def __init__(self, model: torch.nn.Module) -> None:
+        self.params = [p for p in model.parameters()]
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            assert p.dtype == torch.float32
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4  # 16-byte aligned
+        self.P = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._off: Dict[int, int] = {}
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                view = self.P[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                self._off[id(p)] = o
+        self.n = n
+
+    def off(self, p: Tensor) -> int:
+        return self._off[id(p)]
+
+    def intact(self) -> bool:
+        base = self.P.data_ptr()
+        return all(p.data_ptr() == base + 4 * self._off[id(p)] and p.device == self.P.device for p in self.params)
+
+    def grad_view(self, p: Tensor) -> Tensor:
+        o = self._off[id(p)]
+        return self.G[o:o + p.numel()].view_as(p)
+
+    def pidx(self, p: Tensor) -> np.ndarray:
+        return (self._off[id(p)] + np.arange(p.numel(), dtype=np.int64)).reshape(tuple(p.shape))
+
+
+# --------------------------------------------------------------------------- index-form matrices
+class IM:
+    """A padded operand matrix in index form: idx (flat parameter index, -1 = constant), scl (multiplier, or the constant), mode (0 value,
+    1 leading bf16, 2 remainder)."""
+
+    def __init__(self, shape) -> None:
+        self.idx = np.full(shape, -1, dtype=np.int64)
+        self.scl = np.zeros(shape, dtype=np.float32)
+        self.mode = np.zeros(shape, dtype=np.uint8)
+
+    def put(self, sl, pidx: np.ndarray, scale=1.0, mode: int = 0) -> None:
+        self.idx[sl] = pidx
+        self.scl[sl] = scale
+        self.mode[sl] = mode
+
+    def const(self, sl, value: float) -> None:
+        self.idx[sl] = -1
+        self.scl[sl] = value
+        self.mode[sl] = 0
+
+    def map(self, f) -> "IM":
+        out = IM.__new__(IM)
+        out.idx, out.scl, out.mode = f(self.idx), f(self.scl), f(self.mode)
+        return out
+
+    @staticmethod
+    def cat(ms: List["IM"]) -> "IM":
+        out = IM.__new__(IM)
+        out.idx = np.concatenate([m.idx.reshape(-1) for m in ms])
+        out.scl = np.concatenate([m.scl.reshape(-1) for m in ms])
+        out.mode = np.concatenate([m.mode.reshape(-1) for m in ms])
+        return out
+
+
+def _slots(m: IM) -> IM:
+    """[192 rows, 32 * ns] -> weight-stream slots [ns][12 fragments = 3 w + n][64 lanes = 16 g + i][8]: element (row 48 w + 16 n + i, k = 32 c + 8 g + j)
+    (the layout of packing.pack_swin_tail_stream's projection part)."""
+    ns = m.idx.shape[1] // 32
+    return m.map(lambda a: a.reshape(4, 3, 16, ns, 4, 8).transpose(3, 0, 1, 4, 2, 5).reshape(-1))
+
+
+def _fragments(m: IM) -> IM:
+    """packing.to_fragments: [N_p, K_p] -> [n_tile][k_chunk][lane][8]."""
+    n_p, k_p = m.idx.shape
+    return m.map(lambda a: a.reshape(n_p // 16, 16, k_p // 32, 4, 8).transpose(0, 2, 3, 1, 4).reshape(-1))
+
+
+class Arena:
+    """One packed operand buffer (bf16 or fp32) + its gather maps."""
+
+    def __init__(self, dtype: torch.dtype) -> None:
+        self.dtype = dtype
+        self.parts: List[IM] = []
+        self.n = 0
+        self.buf: Optional[Tensor] = None
+
+    def add(self, m: IM) -> int:
+        off = self.n
+        cnt = m.idx.size
+        pad = (-cnt) % 64
+        if pad:
+            z = IM((pad,))
+            m = IM.cat([m, z])
+        self.parts.append(m)
+        self.n += cnt + pad
+        return off
+
+    def finish(self, device) -> None:
+        if not self.parts:
+            self.parts.append(IM((64,)))
+            self.n = 64
+        m = IM.cat(self.parts)
+        self.parts = []
+        self.idx = torch.from_numpy(m.idx.astype(np.int32)).to(device)
+        self.scl = torch.from_numpy(m.scl).to(device)
+        self.mode = torch.from_numpy(m.mode).to(device)
+        self.buf = torch.zeros(self.n, dtype=self.dtype, device=device)
+
+    def view(self, off: int, n: int) -> Tensor:
+        return self.buf[off:off + n]
+
+    def gather(self, P: Tensor) -> None:
+        L.check(L.lib().sr_tr_gather(P.data_ptr(), self.idx.data_ptr(), None, self.scl.data_ptr(), self.mode.data_ptr(), self.buf.data_ptr(),
+                                     L.SR_BF16 if self.dtype == torch.bfloat16 else L.SR_F32, self.n, _st()), "sr_tr_gather")
+
+
+class FinalMap:
+    """Gradient side: for the parameters [p0, p1) of the flat buffer, grad[p] = scale[p] * sum_s part[src[p] + s * stride[p]]."""
+
+    def __init__(self, fp: FlatParams, p0: int, p1: int) -> None:
+        self.p0, self.p1 = p0, p1
+        n = p1 - p0
+        self.src = np.full(n, -1, dtype=np.int64)
+        self.stride = np.zeros(n, dtype=np.int32)
+        self.ns = np.ones(n, dtype=np.int32)
+        self.scale = np.ones(n, dtype=np.float32)
+        self.size = 0  # floats of the partial arena
+
+    def alloc(self, n: int) -> int:
+        off = self.size
+        self.size += (n + 63) // 64 * 64
+        return off
+
+    def put(self, pidx: np.ndarray, src: np.ndarray, stride: int, ns: int, scale=1.0) -> None:
+        i = (pidx - self.p0).reshape(-1)
+        self.src[i] = np.asarray(src, dtype=np.int64).reshape(-1)
+        self.stride[i] = stride
+        self.ns[i] = ns
+        self.scale[i] = np.asarray(scale, dtype=np.float32).reshape(-1) if np.ndim(scale) else scale
+
+    def finish(self, device) -> None:
+        self.d_src = torch.from_numpy(self.src).to(device)
+        self.d_stride = torch.from_numpy(self.stride).to(device)
+        self.d_ns = torch.from_numpy(self.ns).to(device)
+        self.d_scale = torch.from_numpy(self.scale).to(device)
+        self.part = torch.zeros(max(self.size, 64), dtype=torch.float32, device=device)
+
+    def run(self, G: Tensor) -> None:
+        n = self.p1 - self.p0
+        L.check(L.lib().sr_tr_finalize(self.part.data_ptr(), self.d_src.data_ptr(), self.d_stride.data_ptr(), self.d_ns.data_ptr(), self.d_scale.data_ptr(),
+                                       G.data_ptr() + 4 * self.p0, n, _st()), "sr_tr_finalize")
+
+
+# --------------------------------------------------------------------------- index-form packers (cf. studiosr_amd/packing.py)
+def pack_qkv_fwd(fp: FlatParams, qkv_w: Tensor, qkv_b: Tensor) -> IM:
+    """packing.pack_swin_qkv_stream in index form (unfolded weights)."""
+    m = IM((3, HEADS, HDP, CP))
+    sc = np.ones((3, 1, 1, 1), dtype=np.float32)
+    sc[0] = HD ** -0.5
+    m.put((slice(None), slice(None), slice(0, HD), slice(0, C_REAL)), fp.pidx(qkv_w).reshape(3, HEADS, HD, C_REAL), np.broadcast_to(sc, (3, HEADS, HD, C_REAL)))
+    b = fp.pidx(qkv_b).reshape(3, HEADS, HD)
+    bs = np.broadcast_to(sc[:, :, :, 0], (3, HEADS, HD))
+    m.put((slice(None), slice(None), slice(0, HD), C_REAL), b, bs, 1)
+    m.put((slice(None), slice(None), slice(0, HD), C_REAL + 1), b, bs, 2)
+    return m.map(lambda a: a.reshape(3, 3, 2, 2, 16, 6, 4, 8).transpose(1, 5, 2, 3, 0, 6, 4, 7).reshape(-1))
+
+
+def _m_proj(fp: FlatParams, proj_w: Tensor) -> IM:
+    m = IM((CP, HEADS, HDP))
+    m.put((slice(0, C_REAL), slice(None), slice(0, HD)), fp.pidx(proj_w).reshape(C_REAL, HEADS, HD))
+    return m.map(lambda a: a.reshape(CP, HEADS * HDP))
+
+
+def _m_fc1(fp: FlatParams, w: Tensor, b: Tensor) -> IM:
+    m = IM((HP, CP))
+    m.put((slice(0, HID), slice(0, C_REAL)), fp.pidx(w))
+    m.put((slice(0, HID), C_REAL), fp.pidx(b), 1.0, 1)
+    m.put((slice(0, HID), C_REAL + 1), fp.pidx(b), 1.0, 2)
+    return m
+
+
+def _m_fc2(fp: FlatParams, w: Tensor, b: Tensor) -> IM:
+    m = IM((CP, HP))
+    m.put((slice(0, C_REAL), slice(0, HID)), fp.pidx(w))
+    m.put((slice(0, C_REAL), HID), fp.pidx(b), 1.0, 1)
+    m.put((slice(0, C_REAL), HID + 1), fp.pidx(b), 1.0, 2)
+    return m
+
+
+def _sub(m: IM, rows: slice, cols: slice) -> IM:
+    return m.map(lambda a: a[rows, cols])
+
+
+def _tr(m: IM) -> IM:
+    return m.map(lambda a: np.ascontiguousarray(a.T))
+
+
+def pack_tail_fwd(fp: FlatParams, proj_w, fc1_w, fc1_b, fc2_w, fc2_b) -> IM:
+    """sr_tr_tail_fwd's 30 slots: 6 projection, then per hidden half 6 fc1 + 6 fc2 (biases on the constant-one channels / hidden columns)."""
+    fc1, fc2 = _m_fc1(fp, fc1_w, fc1_b), _m_fc2(fp, fc2_w, fc2_b)
+    parts = [_slots(_m_proj(fp, proj_w))]
+    for hf in range(2):
+        parts.append(_slots(_sub(fc1, slice(192 * hf, 192 * hf + 192), slice(None))))
+        parts.append(_slots(_sub(fc2, slice(None), slice(192 * hf, 192 * hf + 192))))
+    return IM.cat(parts)
+
+
+def _weights_only(m: IM, rows: int, cols: int) -> IM:
+    """the matrix with everything outside [0, rows) x [0, cols) (bias columns, pads) zero"""
+    out = IM(m.idx.shape)
+    out.idx[:rows, :cols] = m.idx[:rows, :cols]
+    out.scl[:rows, :cols] = m.scl[:rows, :cols]
+    out.mode[:rows, :cols] = m.mode[:rows, :cols]
+    return out
+
+
+def pack_tail_bwd(fp: FlatParams, proj_w, fc1_w, fc1_b, fc2_w, fc2_b) -> IM:
+    """sr_tr_tail_bwd's 42 slots: per hidden half 6 fc1 (forward, with bias), 6 W2^T (rows = hidden columns, K = channels), 6 W1^T (rows =
+    channels, K = hidden columns); then 6 Wproj^T (rows = (head, feature), K = channels).  The transposed matrices carry weights only."""
+    fc1, fc2 = _m_fc1(fp, fc1_w, fc1_b), _m_fc2(fp, fc2_w, fc2_b)
+    w1, w2 = _weights_only(fc1, HID, C_REAL), _weights_only(fc2, C_REAL, HID)
+    parts = []
+    for hf in range(2):
+        hs = slice(192 * hf, 192 * hf + 192)
+        parts.append(_slots(_sub(fc1, hs, slice(None))))
+        parts.append(_slots(_tr(_sub(w2, slice(None), hs))))  # [hidden col][channel]
+        parts.append(_slots(_tr(_sub(w1, hs, slice(None)))))  # [channel][hidden col]
+    parts.append(_slots(_tr(_m_proj(fp, proj_w))))            # [(head, feature)][channel]
+    return IM.cat(parts)
+
+
+def pack_qkv_bwd(fp: FlatParams, qkv_w: Tensor) -> IM:
+    """sr_tr_qkv_bwd's 18 slots: W^T [channel][(part, head, feature)], q part scaled by hd^-0.5."""
+    m = IM((3, HEADS, HDP, CP))
+    sc = np.ones((3, 1, 1, 1), dtype=np.float32)
+    sc[0] = HD ** -0.5
+    m.put((slice(None), slice(None), slice(0, HD), slice(0, C_REAL)), fp.pidx(qkv_w).reshape(3, HEADS, HD, C_REAL), np.broadcast_to(sc, (3, HEADS, HD, C_REAL)))
+    return _slots(_tr(m.map(lambda a: a.reshape(3 * HEADS * HDP, CP))))
+
+
+def pack_conv(fp: FlatParams, w: Tensor, cin_p: int, cout_p: int, transpose: bool = False) -> IM:
+    """packing.pack_conv3x3 in index form: [cout_p, 9 * cin_p] with k = tap * cin_p + c.  transpose = True: the data-gradient convolution
+    (input = the forward's output channels, taps flipped): W'[ci][tap'][co] = W[co][ci][8 - tap']."""
+    cout, cin = w.shape[:2]
+    pi = fp.pidx(w).reshape(cout, cin, 9)
+    if transpose:
+        m = IM((cout_p, 9, cin_p))  # here cout_p / cin_p are the DGRAD's output / input widths: rows = forward ci, columns = forward co
+        m.put((slice(0, cin), slice(None), slice(0, cout)), pi[:, :, ::-1].transpose(1, 2, 0))
+    else:
+        m = IM((cout_p, 9, cin_p))
+        m.put((slice(0, cout), slice(None), slice(0, cin)), pi.transpose(0, 2, 1))
+    return _fragments(m.map(lambda a: a.reshape(a.shape[0], -1)))
+
+
+def pack_vec(fp: FlatParams, v: Tensor, n_p: int) -> IM:
+    m = IM((n_p,))
+    m.put(slice(0, v.numel()), fp.pidx(v).reshape(-1))
+    return m
+
+
+def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) -> Tuple[IM, IM, IM]:
+    """relative-position bias gathered through rpi (negative indices wrap): [heads][nq][nk], its transpose [heads][nk][nq], and the
+    accumulator-fragment order of packing.bias_fragments."""
+    T = table.shape[0]
+    r = np.asarray(rpi, dtype=np.int64).reshape(nq, nk)
+    r = np.where(r < 0, r + T, r)
+    pi = fp.pidx(table)  # [T, heads]
+    b = IM((HEADS, nq, nk))
+    b.put(slice(None), pi[r].transpose(2, 0, 1))
+    bt = b.map(lambda a: np.ascontiguousarray(a.transpose(0, 2, 1)))
+    bf = b.map(lambda a: a.reshape(HEADS, nq // 16, 16, nk // 16, 4, 4).transpose(0, 1, 3, 4, 2, 5).reshape(-1))
+    return b, bt, bf
+
+
+# --------------------------------------------------------------------------- one HAB
+class HabPlan:
+    """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195)."""
+
+    def __init__(self, fp: FlatParams, blk, rpi_sa: np.ndarray, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: FinalMap) -> None:
+        self.shift, self.conv_scale = shift, float(conv_scale)
+        self.fp = fp
+        at, mlp = blk.attn, blk.mlp
+        cab = blk.conv_block.cab
+        ca = cab[3].attention
+        self.blk = blk
+        # ---- packed operands
+        self.o_qkvf = wa.add(pack_qkv_fwd(fp, at.qkv.weight, at.qkv.bias))
+        self.o_tailf = wa.add(pack_tail_fwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
+        self.o_tailb = wa.add(pack_tail_bwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
+        self.o_qkvb = wa.add(pack_qkv_bwd(fp, at.qkv.weight))
+        self.o_c1 = wa.add(pack_conv(fp, cab[0].weight, CP, 64))
+        self.o_c2 = wa.add(pack_conv(fp, cab[2].weight, 64, CP))
+        self.o_c1t = wa.add(pack_conv(fp, cab[0].weight, 64, CP, transpose=True))   # dmid [64] -> dn1 [192]
+        self.o_c2t = wa.add(pack_conv(fp, cab[2].weight, CP, 64, transpose=True))   # dy [192] -> dmid [64]
+        self.o_g1, self.o_b1 = fa.add(pack_vec(fp, blk.norm1.weight, CP)), fa.add(pack_vec(fp, blk.norm1.bias, CP))
+        self.o_g2, self.o_b2 = fa.add(pack_vec(fp, blk.norm2.weight, CP)), fa.add(pack_vec(fp, blk.norm2.bias, CP))
+        self.o_bp = fa.add(pack_vec(fp, at.proj.bias, CP))
+        self.o_bc1, self.o_bc2 = fa.add(pack_vec(fp, cab[0].bias, 64)), fa.add(pack_vec(fp, cab[2].bias, CP))
+        b, bt, bf = pack_bias(fp, at.relative_position_bias_table, rpi_sa, 256, 256)
+        self.o_bias, self.o_biasT, self.o_biasF = fa.add(b), fa.add(bt), fa.add(bf)
+        self.ca = (ca[1].weight, ca[1].bias, ca[3].weight, ca[3].bias)
+        self.table = at.relative_position_bias_table
+        self.fm = fm
+        self._final_maps(fp, fm, at, mlp, cab, ca)
+
+    def _final_maps(self, fp, fm, at, mlp, cab, ca) -> None:
+        ks = WG_KS
+        # -- qkv: out [ks][576][192]; n = part * 192 + head * 32 + d
+        n_qkv = 3 * HEADS * HDP
+        self.f_qkv = fm.alloc(ks * n_qkv * CP)
+        nn = (np.arange(3)[:, None, None] * 192 + np.arange(HEADS)[None, :, None] * 32 + np.arange(HD)[None, None, :]).reshape(-1)  # [540] -> padded row
+        sc = np.ones(3 * HEADS * HD, dtype=np.float32)
+        sc[: HEADS * HD] = HD ** -0.5
+        fm.put(fp.pidx(at.qkv.weight), self.f_qkv + nn[:, None] * CP + np.arange(C_REAL)[None, :], n_qkv * CP, ks, np.broadcast_to(sc[:, None], (540, C_REAL)))
+        fm.put(fp.pidx(at.qkv.bias), self.f_qkv + nn * CP + C_REAL, n_qkv * CP, ks, sc)
+        # -- proj: out [ks][192 c][192 (head, d)]; bias = column 30 (a pad feature of O, read as one)
+        self.f_proj = fm.alloc(ks * CP * CP)
+        kk = (np.arange(HEADS)[:, None] * 32 + np.arange(HD)[None, :]).reshape(-1)
+        fm.put(fp.pidx(at.proj.weight), self.f_proj + np.arange(C_REAL)[:, None] * CP + kk[None, :], CP * CP, ks)
+        fm.put(fp.pidx(at.proj.bias), self.f_proj + np.arange(C_REAL) * CP + HD, CP * CP, ks)
+        # -- fc1: out [ks][384][192]; fc2: out [ks][192][384]
+        self.f_fc1 = fm.alloc(ks * HP * CP)
+        fm.put(fp.pidx(mlp.fc1.weight), self.f_fc1 + np.arange(HID)[:, None] * CP + np.arange(C_REAL)[None, :], HP * CP, ks)
+        fm.put(fp.pidx(mlp.fc1.bias), self.f_fc1 + np.arange(HID) * CP + C_REAL, HP * CP, ks)
+        self.f_fc2 = fm.alloc(ks * CP * HP)
+        fm.put(fp.pidx(mlp.fc2.weight), self.f_fc2 + np.arange(C_REAL)[:, None] * HP + np.arange(HID)[None, :], CP * HP, ks)
+        fm.put(fp.pidx(mlp.fc2.bias), self.f_fc2 + np.arange(C_REAL) * HP + HID, CP * HP, ks)
+        # -- CAB convs: out [ks][9][Np][Kp]
+        c3 = cab[0].weight.shape[0]
+        self.f_c1 = fm.alloc(ks * 9 * 64 * CP)
+        co, ci, tp = np.arange(c3)[:, None, None], np.arange(C_REAL)[None, :, None], np.arange(9)[None, None, :]
+        fm.put(fp.pidx(cab[0].weight).reshape(c3, C_REAL, 9), self.f_c1 + (tp * 64 + co) * CP + ci, 9 * 64 * CP, ks)
+        fm.put(fp.pidx(cab[0].bias), self.f_c1 + (4 * 64 + np.arange(c3)) * CP + C_REAL, 9 * 64 * CP, ks)  # centre tap, the ones channel of n1
+        self.f_c2 = fm.alloc(ks * 9 * CP * 64)
+        co, ci = np.arange(C_REAL)[:, None, None], np.arange(c3)[None, :, None]
+        fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
+        fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
+        # -- the remaining partial buffers are sized per geometry (prepare): LayerNorm partials, channel-attention partials, bias table
+        self._final_late = (at, mlp, cab, ca)
+
+    def prepare(self, B: int, H: int, W: int, dev) -> None:
+        """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images."""
+        fp, fm = self.fp, self.fm
+        at, mlp, cab, ca = self._final_late
+        nwg = B * H * W // 64
+        self.f_ln1, self.f_ln2 = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
+        for f, norm in ((self.f_ln1, self.blk.norm1), (self.f_ln2, self.blk.norm2)):
+            fm.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
+            fm.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
+        cr = ca[1].weight.shape[0]
+        self.ca_stride = (2 * cr * C_REAL + cr + C_REAL + 63) // 64 * 64
+        self.f_ca = fm.alloc(B * self.ca_stride)
+        o = self.f_ca
+        fm.put(fp.pidx(ca[1].weight), o + np.arange(cr * C_REAL), self.ca_stride, B)
+        fm.put(fp.pidx(ca[1].bias), o + cr * C_REAL + np.arange(cr), self.ca_stride, B)
+        fm.put(fp.pidx(ca[3].weight), o + cr * C_REAL + cr + np.arange(C_REAL * cr), self.ca_stride, B)
+        fm.put(fp.pidx(ca[3].bias), o + cr * C_REAL + cr + C_REAL * cr + np.arange(C_REAL), self.ca_stride, B)
+        tb = self.table
+        self.f_tab = fm.alloc(tb.numel())
+        fm.put(fp.pidx(tb), self.f_tab + np.arange(tb.numel()), 0, 1)
+        # static activations kept from forward to backward
+        T = B * H * W
+        bf, f32 = torch.bfloat16, torch.float32
+        e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        self.x1 = e(T, CP, dt=f32)
+        self.q, self.qT, self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(6))
+        self.o, self.n1, self.y = e(T, CP), e(T, CP), e(T, CP)
+        self.n_tiles = ops.cab_pool_tiles(H, W)
+        self.pool = e(B, self.n_tiles, CP, dt=f32)
+        self.gate = e(B, CP, dt=f32)
+
+
+class Scratch:
+    """Backward scratch shared by all blocks of a model (one block's backward at a time)."""
+
+    def __init__(self, B: int, H: int, W: int, dev, groups: int) -> None:
+        T = B * H * W
+        bf, f32 = torch.bfloat16, torch.float32
+        e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        self.dx1 = e(T, CP, dt=f32)
+        self.n2w, self.doutw, self.dOw, self.dx1sw, self.dyc, self.n1w, self.dn1c = (e(T, CP) for _ in range(7))
+        self.gw, self.dhw = e(T, HP), e(T, HP)
+        self.dOT, self.dq, self.dk, self.dv = (e(T * CP) for _ in range(4))
+        self.dqkvw = e(T, 3 * CP)
+        self.dgate_part = e(T // 64, CP, dt=f32)
+        self.lse, self.delta = e(T // 256 * HEADS * 256, dt=f32), e(T // 256 * HEADS * 256, dt=f32)
+        self.groups = groups
+        self.dbias_part = e(groups, HEADS, 256, 256, dt=f32)
+        self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))
+
+
+def _conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, B: int, H: int, W: int, cin_p: int, cout_p: int) -> None:
+    ops.conv3x3(x=x.data_ptr(), Wp=wp.data_ptr(), bias=None if bias is None else bias.data_ptr(), out=out.data_ptr(), skip=None, pool_partial=None,
+                B=B, H=H, W=W, Cin_p=cin_p, Cout_p=cout_p, x_dtype=L.SR_BF16, out_dtype=L.SR_BF16, skip_dtype=0, compute_dtype=L.SR_BF16, act=L.ACT_NONE,
+                out_scale=1.0, out_mode=L.OUT_NHWC, ps_r=0, cps_p=0, act_slope=0.0, tile_rows=0)
+
+
+def _wgrad(jobs: List[dict]) -> None:
+    arr = (L.SrTrWgradJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for k, v in j.items():
+            setattr(a, k, v)
+    L.check(L.lib().sr_tr_wgrad(arr, len(jobs), _st()), "sr_tr_wgrad")
+
+
+def _call(fn, struct, what: str, **kw) -> None:
+    a = struct()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(fn(C.byref(a), _st()), what)
+
+
+class Stage:
+    """A run of consecutive HABs (one RHAG's blocks) with its arenas; forward / backward as launch sequences."""
+
+    def __init__(self, fp: FlatParams, blocks, rpi_sa: Tensor, conv_scale: float, wa: Arena, fa: Arena) -> None:
+        self.fp, self.wa, self.fa = fp, wa, fa
+        params = [p for b in blocks for p in b.parameters()]
+        p0 = min(fp.off(p) for p in params)
+        p1 = max(fp.off(p) + (p.numel() + 3) // 4 * 4 for p in params)
+        self.params = params
+        self.fm = FinalMap(fp, p0, p1)
+        rpi = rpi_sa.detach().cpu().numpy()
+        self.rpi_dev = rpi_sa.detach().to(torch.int64).contiguous()
+        self.habs = [HabPlan(fp, b, rpi, conv_scale, b.shift_size, wa, fa, self.fm) for b in blocks]
+        self.geo = None
+        self.gen = 0
+
+    def prepare(self, B: int, H: int, W: int, dev, scratch: Scratch) -> None:
+        if self.geo == (B, H, W):
+            return
+        assert self.geo is None, "one geometry per fast-training plan (rebuild the plan for another batch / patch size)"
+        for h in self.habs:
+            h.prepare(B, H, W, dev)
+        self.fm.finish(dev)
+        self.geo = (B, H, W)
+        self.sc = scratch
+        self.ts = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in self.habs]  # block outputs
+        self.tab_lo = min(h.f_tab for h in self.habs)
+        self.tab_hi = max(h.f_tab + h.table.numel() for h in self.habs)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor, scales: Optional[Tensor]) -> Tensor:
+        B, H, W = self.geo
+        wa, fa = self.wa.buf, self.fa.buf
+        lib = L.lib()
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
+        cur = x
+        for i, h in enumerate(self.habs):
+            out = self.ts[i]
+            _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[h.o_g1:].data_ptr(), beta=fa[h.o_b1:].data_ptr(),
+                  wstream=wa[h.o_qkvf:].data_ptr(), q=h.q.data_ptr(), qT=h.qT.data_ptr(), k=h.k.data_ptr(), kT=h.kT.data_ptr(), v=h.v.data_ptr(), vT=h.vT.data_ptr(),
+                  n1=h.n1.data_ptr(), ldn=CP, shift=h.shift, **g)
+            ops.window_attention(q=h.q.data_ptr(), k=h.k.data_ptr(), vt=h.vT.data_ptr(), bias=fa[h.o_bias:].data_ptr(), out=h.o.data_ptr(), n_bwin=B * H * W // 256,
+                                 heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=h.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
+                                 bias_frag=fa[h.o_biasF:].data_ptr(), qkv_frag=0)
+            ops.cab_fused(x=h.n1.data_ptr(), w1p=wa[h.o_c1:].data_ptr(), b1=fa[h.o_bc1:].data_ptr(), w2p=wa[h.o_c2:].data_ptr(), b2=fa[h.o_bc2:].data_ptr(),
+                          y=h.y.data_ptr(), pool_partial=h.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
+            w1, b1, w2, b2 = h.ca
+            _call(lib.sr_tr_tail_fwd, L.SrTrTailFwd, "sr_tr_tail_fwd", x=cur.data_ptr(), out=out.data_ptr(), x1=h.x1.data_ptr(), o=h.o.data_ptr(),
+                  wstream=wa[h.o_tailf:].data_ptr(), bproj=fa[h.o_bp:].data_ptr(), gamma=fa[h.o_g2:].data_ptr(), beta=fa[h.o_b2:].data_ptr(), y=h.y.data_ptr(),
+                  pool_partial=h.pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(), gate_out=h.gate.data_ptr(),
+                  s_a=None if scales is None else scales[i, 0].data_ptr(), s_m=None if scales is None else scales[i, 1].data_ptr(), ldy=CP, shift=h.shift, Hp=HP,
+                  ca_Cr=w1.shape[0], ca_n_tiles=h.n_tiles, y_scale=h.conv_scale, **g)
+            cur = out
+        return cur
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor]) -> Tensor:
+        """dout: gradient of the stage output; returns the gradient of x (a fresh tensor); fills G for the stage's parameters."""
+        B, H, W = self.geo
+        T = B * H * W
+        wa, fa, sc, fm = self.wa.buf, self.fa.buf, self.sc, self.fm
+        lib = L.lib()
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
+        part = fm.part
+        fm.part[self.tab_lo:self.tab_hi].zero_()  # the bias-table gradients are scatter-added
+        pp = lambda off: part.data_ptr() + 4 * off  # noqa: E731
+        d = dout.contiguous()
+        for i in range(len(self.habs) - 1, -1, -1):
+            h = self.habs[i]
+            xin = x if i == 0 else self.ts[i - 1]
+            dx = torch.empty(B, H, W, CP, dtype=torch.float32, device=d.device)
+            s_a = None if scales is None else scales[i, 0].data_ptr()
+            s_m = None if scales is None else scales[i, 1].data_ptr()
+            _call(lib.sr_tr_tail_bwd, L.SrTrTailBwd, "sr_tr_tail_bwd", dout=d.data_ptr(), x1=h.x1.data_ptr(), y=h.y.data_ptr(), gate=h.gate.data_ptr(),
+                  gamma=fa[h.o_g2:].data_ptr(), beta=fa[h.o_b2:].data_ptr(), wstream=wa[h.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(),
+                  n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(), dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(),
+                  dx1sw=sc.dx1sw.data_ptr(), dyc=sc.dyc.data_ptr(), dgate_part=sc.dgate_part.data_ptr(), ln_part=pp(h.f_ln2), ldy=CP, shift=h.shift, Hp=HP, **g)
+            _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=h.q.data_ptr(), qT=h.qT.data_ptr(), k=h.k.data_ptr(), kT=h.kT.data_ptr(), v=h.v.data_ptr(),
+                  o=h.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[h.o_bias:].data_ptr(), biasT=fa[h.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
+                  dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dbias_part=sc.dbias_part.data_ptr(), n_bwin=T // 256,
+                  heads=HEADS, hd_p=HDP, Nq=256, Nk=256, ldo=CP, groups=sc.groups, H=H, W=W, ws=16, shift=h.shift)
+            L.check(lib.sr_tr_dbias(sc.dbias_part.data_ptr(), sc.groups, self.rpi_dev.data_ptr(), pp(h.f_tab), h.table.shape[0], HEADS, 256 * 256, _st()), "sr_tr_dbias")
+            # ---- CAB backward (hat.py:41-52)
+            w1, b1, w2, b2 = h.ca
+            _conv(h.n1, wa[h.o_c1:], fa[h.o_bc1:], sc.mid_pre, B, H, W, CP, 64)
+            _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=h.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
+                  w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(h.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=h.n_tiles,
+                  parts=H * W // 64, ld=CP, dparam_stride=h.ca_stride, y_scale=h.conv_scale)
+            _conv(sc.dyc, wa[h.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
+            L.check(lib.sr_tr_gelu(sc.mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
+            _conv(sc.dmid, wa[h.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
+            _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
+                  dn1c=sc.dn1c.data_ptr(), gamma=fa[h.o_g1:].data_ptr(), beta=fa[h.o_b1:].data_ptr(), wstream=wa[h.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
+                  n1w=sc.n1w.data_ptr(), dqkvw=sc.dqkvw.data_ptr(), ln_part=pp(h.f_ln1), ldn=CP, shift=h.shift, **g)
+            ks = WG_KS
+            _wgrad([
+                dict(A=sc.dqkvw.data_ptr(), B=sc.n1w.data_ptr(), out=pp(h.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=sc.dx1sw.data_ptr(), B=h.o.data_ptr(), out=pp(h.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
+                dict(A=sc.dhw.data_ptr(), B=sc.n2w.data_ptr(), out=pp(h.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=sc.doutw.data_ptr(), B=sc.gw.data_ptr(), out=pp(h.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=sc.dmid.data_ptr(), B=h.n1.data_ptr(), out=pp(h.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(h.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=ks),
+            ])
+            d = dx
+        fm.run(self.fp.G)
+        return d
+
+
+class _StageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stage, scales, *params):
+        x = x.contiguous()
+        stage.gen += 1
+        ctx.stage, ctx.gen, ctx.scales = stage, stage.gen, scales
+        ctx.save_for_backward(x)
+        out = stage.forward(x, scales)
+        return out.view(out.shape)  # a fresh alias of the stage's static output buffer
+
+    @staticmethod
+    def backward(ctx, dout):
+        stage = ctx.stage
+        if stage.gen != ctx.gen:
+            raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
+        (x,) = ctx.saved_tensors
+        dx = stage.backward(x, dout, ctx.scales)
+        grads = tuple(stage.fp.grad_view(p) for p in stage.params)
+        return (dx, None, None) + grads
+
+
+def run_stage(stage: Stage, x: Tensor, scales: Optional[Tensor]) -> Tensor:
+    return _StageFn.apply(x, stage, scales, *stage.params)
+
+
+# --------------------------------------------------------------------------- whole-model plan
+class HatPlan:
+    """Fast-path plan of a HAT model: FlatParams, the two arenas, one Stage per RHAG (its six HABs)."""
+
+    def __init__(self, model) -> None:
+        self.model = model
+        self.fp = FlatParams(model)
+        dev = self.fp.P.device
+        self.wa, self.fa = Arena(torch.bfloat16), Arena(torch.float32)
+        self.stages = [Stage(self.fp, list(layer.residual_group.blocks), model.relative_position_index_SA, model.conv_scale, self.wa, self.fa) for layer in model.layers]
+        self.wa.finish(dev)
+        self.fa.finish(dev)
+        self.scratch = None
+        self.geo = None
+        self.packed_version = None
+
+    @staticmethod
+    def supported(model) -> bool:
+        try:
+            return (type(model).__name__ == "HAT" and model.embed_dim == C_REAL and model.window_size == 16 and all(h == HEADS for h in model.num_heads) and
+                    int(model.embed_dim * model.mlp_ratio) == HID and model.embed_dim // model.compress_ratio == 60 and model.embed_dim // model.squeeze_factor == CR and
+                    next(model.parameters()).is_cuda)
+        except Exception:
+            return False
+
+    def prepare(self, B: int, H: int, W: int) -> None:
+        if self.geo == (B, H, W):
+            return
+        assert self.geo is None, "one geometry per fast-training plan"
+        dev = self.fp.P.device
+        nbw = B * H * W // 256
+        groups = max(1, min(nbw, 16))
+        while nbw % groups:
+            groups -= 1
+        self.scratch = Scratch(B, H, W, dev, groups)
+        for s in self.stages:
+            s.prepare(B, H, W, dev, self.scratch)
+        self.geo = (B, H, W)
+
+    def pack(self) -> None:
+        """Packed operands <- current parameters (once per optimizer step: the parameter versions decide)."""
+        ver = tuple(p._version for p in self.fp.params)
+        if ver != self.packed_version:
+            self.wa.gather(self.fp.P)
+            self.fa.gather(self.fp.P)
+            self.packed_version = ver
+
+
+def get_plan(model) -> Optional[HatPlan]:
+    plan = getattr(model, "_fast_plan", None)
+    if plan is not None and plan.fp.intact():
+        return plan
+    if not HatPlan.supported(model):
+        return None
+    plan = HatPlan(model)
+    object.__setattr__(model, "_fast_plan", plan)
+    return plan

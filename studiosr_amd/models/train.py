@@ -145,6 +145,40 @@ def swinir_forward(model, x: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------- HAT
+def _fast_plan(model, B: int, Hp: int, Wp: int):
+    """The fused training path (studiosr_amd/fasttrain.py) when it applies: bf16 autocast (the reference Trainer's context, trainer.py:80,102),
+    the default block geometry, a padded size that is a multiple of the 16 x 16 windows.  SR_FAST_TRAIN=0 keeps the generic engine."""
+    import os
+
+    if os.environ.get("SR_FAST_TRAIN", "1") == "0" or not A.torch_autocast_bf16():
+        return None
+    from .. import fasttrain
+
+    if Hp % 16 or Wp % 16:
+        return None
+    plan = fasttrain.get_plan(model)
+    if plan is None:
+        return None
+    if plan.geo is not None and plan.geo != (B, Hp, Wp):
+        return None  # one geometry per plan: other sizes (evaluation inside a training run) take the generic engine
+    plan.prepare(B, Hp, Wp)
+    plan.pack()
+    return plan
+
+
+def _fast_habs(plan, li: int, t: Tensor, rates, training: bool) -> Tensor:
+    from .. import fasttrain
+
+    B = t.shape[0]
+    scales = None
+    if training and any(r > 0.0 for r in rates):  # DropPath: per block, per branch, per image Bernoulli(keep) / keep (hat.py:148,192-193)
+        keep = 1.0 - torch.tensor(list(rates), dtype=torch.float32, device=t.device)
+        scales = ((torch.rand(len(rates), 2, B, device=t.device) < keep[:, None, None]).to(torch.float32) / keep[:, None, None]).contiguous()
+    tp = torch.nn.functional.pad(t, (0, fasttrain.CP - t.shape[-1]))
+    out = fasttrain.run_stage(plan.stages[li], tp, scales)
+    return out[..., : t.shape[-1]].contiguous()
+
+
 def _cab(cab, x: Tensor) -> Tensor:
     seq = cab.cab
     y = _conv(A.gelu(_conv(x, seq[0])), seq[2])
@@ -164,19 +198,25 @@ def hat_forward(model, x: Tensor) -> Tensor:
     t = A.layer_norm(first, model.patch_embed.norm.weight, model.patch_embed.norm.bias)
     dpr = _drop_rates(model)
     rpi_sa, rpi_oca = model.relative_position_index_SA, model.relative_position_index_OCA
+    plan = _fast_plan(model, B, Hp, Wp)
     k = 0
     for li, layer in enumerate(model.layers):
         tin = t
         heads = model.num_heads[li]
         grp = layer.residual_group
-        for blk in grp.blocks:  # HAB (hat.py:153-195)
-            n1 = A.layer_norm(t, blk.norm1.weight, blk.norm1.bias)
-            conv_x = _cab(blk.conv_block, n1)
-            a = _window_msa(blk.attn, n1, ws, blk.shift_size, heads, rpi_sa)
-            t = A.add(A.add(t, A.drop_path(a, dpr[k], model.training)), conv_x, 1.0, blk.conv_scale)
-            m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
-            t = A.add(t, A.drop_path(m, dpr[k], model.training))
-            k += 1
+        if plan is not None:  # the six HABs as fused launches (studiosr_amd/fasttrain.py); the stream crosses in the kernels' 192-channel padding
+            nb = len(grp.blocks)
+            t = _fast_habs(plan, li, t, dpr[k:k + nb], model.training)
+            k += nb
+        else:
+            for blk in grp.blocks:  # HAB (hat.py:153-195)
+                n1 = A.layer_norm(t, blk.norm1.weight, blk.norm1.bias)
+                conv_x = _cab(blk.conv_block, n1)
+                a = _window_msa(blk.attn, n1, ws, blk.shift_size, heads, rpi_sa)
+                t = A.add(A.add(t, A.drop_path(a, dpr[k], model.training)), conv_x, 1.0, blk.conv_scale)
+                m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
+                t = A.add(t, A.drop_path(m, dpr[k], model.training))
+                k += 1
         oc = grp.overlap_attn  # OCAB (hat.py:239-293): no DropPath
         wse = oc.overlap_win_size
         qkv = A.linear(A.layer_norm(t, oc.norm1.weight, oc.norm1.bias), oc.qkv.weight, oc.qkv.bias)  # [B,H,W,3C]
