@@ -509,6 +509,24 @@ int sr_tr_attn_bwd(const SrTrAttnBwd* a, void* stream);
 /* relative_position_bias_table gradient: dtable[rpi[ij] (negative wraps)][h] += sum_g dbias_part[g][h][ij]  (dtable zeroed by the caller). */
 int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream);
 
+typedef struct SrTrAttnFwd {
+    /* Training forward of HAT's overlapping cross attention core (hat.py:266-283) on the UNFOLDED keys / values: out rows
+     * [bwin * Nq + tok][ldo] (head h at column 32 h) = softmax(q k^T + bias) v; q [bwin][head][Nq][32], k [bwin][head][Nk][32],
+     * vT [bwin][head][32][Nk] bf16, bias [heads][Nq][Nk] fp32.  Nq 256, Nk 576. */
+    const void* q; const void* k; const void* vT; const float* bias; void* out;
+    int n_bwin, heads, hd_p, Nq, Nk, ldo;
+} SrTrAttnFwd;
+int sr_tr_attn_fwd(const SrTrAttnFwd* a, void* stream);
+
+typedef struct SrTrOcaFold {
+    /* nn.Unfold(kernel wse, stride 16, padding pad) of OCAB (hat.py:217-221,255-263) between the per-window layout k, v [bwin][head][256][32]
+     * and the per-window neighbourhoods kwin, vwin [bwin][head][wse*wse][32] (+ transposes kwinT, vwinT [bwin][head][32][wse*wse]).
+     * unfold = 1: k, v -> kwin, vwin, kwinT, vwinT (zeros outside the image); unfold = 0: the adjoint, k, v <- sum of the copies in kwin, vwin. */
+    void* k; void* v; void* kwin; void* vwin; void* kwinT; void* vwinT;
+    int B, nwy, nwx, heads, wse, pad;
+} SrTrOcaFold;
+int sr_tr_oca_fold(const SrTrOcaFold* a, int unfold, void* stream);
+
 int sr_tr_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp);
 
 typedef struct SrTrQkvFwd {

@@ -166,6 +166,14 @@ class SrTrAttnBwd(C.Structure):
     ]
 
 
+class SrTrAttnFwd(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("vT", _vp), ("bias", _vp), ("out", _vp), ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i)]
+
+
+class SrTrOcaFold(C.Structure):
+    _fields_ = [("k", _vp), ("v", _vp), ("kwin", _vp), ("vwin", _vp), ("kwinT", _vp), ("vwinT", _vp), ("B", _i), ("nwy", _i), ("nwx", _i), ("heads", _i), ("wse", _i), ("pad", _i)]
+
+
 class SrTrQkvFwd(C.Structure):
     _fields_ = [
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("wstream", _vp), ("q", _vp), ("qT", _vp), ("k", _vp), ("kT", _vp), ("v", _vp), ("vT", _vp), ("n1", _vp),
@@ -272,6 +280,8 @@ SYMBOLS = {
     "sr_tr_wgrad_out_floats": (_ll, [C.POINTER(SrTrWgradJob)]),
     "sr_tr_attn_bwd": (_i, [C.POINTER(SrTrAttnBwd), _vp]),
     "sr_tr_dbias": (_i, [_vp, _i, _vp, _vp, _i, _i, _ll, _vp]),
+    "sr_tr_attn_fwd": (_i, [C.POINTER(SrTrAttnFwd), _vp]),
+    "sr_tr_oca_fold": (_i, [C.POINTER(SrTrOcaFold), _i, _vp]),
     "sr_tr_block_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sr_tr_qkv_fwd": (_i, [C.POINTER(SrTrQkvFwd), _vp]),
     "sr_tr_tail_fwd": (_i, [C.POINTER(SrTrTailFwd), _vp]),

@@ -235,6 +235,143 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
     store4(dvp + 16, dv[1]);
 }
 
+
+// ---- overlapping cross attention (hat.py:239-293), training forward: softmax(q k^T + bias) v with Nk = 16 KT keys per window from the unfolded
+//      neighbourhood (sr_tr_oca_unfold); one wave = (window, head, 16 queries), everything in registers as in pass Q
+template <int KT>
+__global__ __launch_bounds__(256, 1) void sr_tr_attn_fwd_kernel(SrTrAttnFwd a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NK = KT * 16;
+    const int qtiles = a.Nq >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n_bwin * a.heads * qtiles) return;
+    const int qt = item % qtiles;
+    const size_t bh = item / qtiles;
+    const int head = (int)(bh % a.heads), bwin = (int)(bh / a.heads);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int qi = qt * 16 + lr;
+    const bf16* k = reinterpret_cast<const bf16*>(a.k) + bh * NK * 32;
+    const bf16* vT = reinterpret_cast<const bf16*>(a.vT) + bh * NK * 32;
+    const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.q) + (bh * a.Nq + qi) * 32 + lg * 8);
+    const float* bias = a.bias + ((size_t)head * a.Nq + qi) * NK;
+    f32x4 s[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+        s[kt] = mma_z(kf, qf) + *reinterpret_cast<const f32x4*>(bias + kt * 16 + lg * 4);
+        if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = wave_max_xor(mx, 16);
+    mx = wave_max_xor(mx, 32);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[kt][r] = __expf(s[kt][r] - mx);
+            sum += s[kt][r];
+        }
+    sum = wave_sum_xor(sum, 16);
+    sum = wave_sum_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x4 o[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) {
+        const Frag<bf16> pf = pack_p(s[2 * ks] * inv, s[2 * ks + 1] * inv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bf16* vp = vT + (size_t)(dt * 16 + lr) * NK + ks * 32 + lg * 4;
+            mma(load_2x4(vp, vp + 16), pf, o[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
+        }
+        if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16* op = reinterpret_cast<bf16*>(a.out) + ((size_t)bwin * a.Nq + qi) * a.ldo + head * 32 + lg * 4;
+    store4(op, o[0]);
+    store4(op + 16, o[1]);
+}
+
+// nn.Unfold of OCAB (hat.py:217-221,255-263) on the per-window q / k / v layout: key j of window (wy, wx) is the pixel at offset
+// (j / wse - pad, j % wse - pad) of the window's corner (zeros outside the image).  unfold: kwin / vwin [bwin][head][NK][32] and their
+// transposes [bwin][head][32][NK] from k / v [bwin][head][256][32]; fold (the adjoint, a gather-sum): dk / dv <- dkwin / dvwin.
+__global__ __launch_bounds__(256) void sr_tr_oca_unfold_kernel(SrTrOcaFold a) {
+    const int NK = a.wse * a.wse;
+    const long long total = (long long)a.B * a.nwy * a.nwx * a.heads * NK * 4;  // 16-byte pieces of a key row
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int piece = (int)(i & 3);
+    long long t = i >> 2;
+    const int j = (int)(t % NK);
+    t /= NK;
+    const int head = (int)(t % a.heads);
+    const long long bwin = t / a.heads;
+    const int win = (int)(bwin % (a.nwy * a.nwx));
+    const long long b = bwin / (a.nwy * a.nwx);
+    const int wy = win / a.nwx, wx = win - wy * a.nwx;
+    const int y = wy * 16 + j / a.wse - a.pad, x = wx * 16 + j % a.wse - a.pad;
+    bf16x8 kv = (bf16x8)(0.0f), vv = (bf16x8)(0.0f);
+    if (y >= 0 && y < a.nwy * 16 && x >= 0 && x < a.nwx * 16) {
+        const long long src = (((b * a.nwy * a.nwx + (y >> 4) * a.nwx + (x >> 4)) * a.heads + head) * 256 + (y & 15) * 16 + (x & 15)) * 32 + piece * 8;
+        kv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.k) + src);
+        vv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.v) + src);
+    }
+    const long long bh = bwin * a.heads + head;
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.kwin) + (bh * NK + j) * 32 + piece * 8) = kv;
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.vwin) + (bh * NK + j) * 32 + piece * 8) = vv;
+    bf16* kT = reinterpret_cast<bf16*>(a.kwinT) + bh * 32 * NK + j;
+    bf16* vT = reinterpret_cast<bf16*>(a.vwinT) + bh * 32 * NK + j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        kT[(long long)(piece * 8 + e) * NK] = kv[e];
+        vT[(long long)(piece * 8 + e) * NK] = vv[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void sr_tr_oca_fold_kernel(SrTrOcaFold a) {
+    const int NK = a.wse * a.wse;
+    const long long total = (long long)a.B * a.nwy * a.nwx * a.heads * 256 * 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int piece = (int)(i & 3);
+    long long t = i >> 2;
+    const int tok = (int)(t & 255);
+    t >>= 8;
+    const int head = (int)(t % a.heads);
+    const long long bwin = t / a.heads;
+    const int win = (int)(bwin % (a.nwy * a.nwx));
+    const long long b = bwin / (a.nwy * a.nwx);
+    const int wy = win / a.nwx, wx = win - wy * a.nwx;
+    const int y = wy * 16 + (tok >> 4), x = wx * 16 + (tok & 15);
+    f32x4 k0 = (f32x4)(0.0f), k1 = (f32x4)(0.0f), v0 = (f32x4)(0.0f), v1 = (f32x4)(0.0f);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int wy2 = wy + dy, wx2 = wx + dx;
+            if (wy2 < 0 || wy2 >= a.nwy || wx2 < 0 || wx2 >= a.nwx) continue;
+            const int jy = y - wy2 * 16 + a.pad, jx = x - wx2 * 16 + a.pad;
+            if (jy < 0 || jy >= a.wse || jx < 0 || jx >= a.wse) continue;
+            const long long src = ((((b * a.nwy + wy2) * a.nwx + wx2) * a.heads + head) * NK + jy * a.wse + jx) * 32 + piece * 8;
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.kwin) + src);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.vwin) + src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                k0[e] += (float)kv[e];
+                k1[e] += (float)kv[4 + e];
+                v0[e] += (float)vv[e];
+                v1[e] += (float)vv[4 + e];
+            }
+        }
+    const long long dst = ((bwin * a.heads + head) * 256 + tok) * 32 + piece * 8;
+    store4(reinterpret_cast<bf16*>(a.k) + dst, k0);
+    store4(reinterpret_cast<bf16*>(a.k) + dst + 4, k1);
+    store4(reinterpret_cast<bf16*>(a.v) + dst, v0);
+    store4(reinterpret_cast<bf16*>(a.v) + dst + 4, v1);
+}
+
 __global__ __launch_bounds__(256) void sr_tr_dbias_kernel(const float* __restrict__ part, int groups, const long long* __restrict__ rpi, float* __restrict__ dtable, int T, int heads,
                                                          long long NN) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -249,6 +386,30 @@ __global__ __launch_bounds__(256) void sr_tr_dbias_kernel(const float* __restric
 }
 
 }  // namespace
+
+
+extern "C" int sr_tr_attn_fwd(const SrTrAttnFwd* p, void* stream) {
+    SR_REQUIRE(p && p->q && p->k && p->vT && p->bias && p->out, "sr_tr_attn_fwd: null pointer");
+    const SrTrAttnFwd& a = *p;
+    SR_REQUIRE(a.hd_p == 32 && a.Nq == 256 && a.Nk == 576 && a.heads > 0 && a.n_bwin > 0 && a.ldo >= a.heads * 32 && a.ldo % 4 == 0, "sr_tr_attn_fwd: unsupported geometry (Nq 256, Nk 576)");
+    const int items = a.n_bwin * a.heads * (a.Nq / 16);
+    hipLaunchKernelGGL(sr_tr_attn_fwd_kernel<36>, dim3((items + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    SR_CHECK_LAUNCH("sr_tr_attn_fwd");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_oca_fold(const SrTrOcaFold* p, int unfold, void* stream) {
+    SR_REQUIRE(p && p->k && p->v && p->kwin && p->vwin && (!unfold || (p->kwinT && p->vwinT)), "sr_tr_oca_fold: null pointer");
+    const SrTrOcaFold& a = *p;
+    SR_REQUIRE(a.B > 0 && a.nwy > 0 && a.nwx > 0 && a.heads > 0 && a.wse > 16 && a.pad * 2 + 16 == a.wse, "sr_tr_oca_fold: bad geometry (16 x 16 windows, wse = 16 + 2 pad)");
+    const long long total = (long long)a.B * a.nwy * a.nwx * a.heads * (unfold ? a.wse * a.wse : 256) * 4;
+    if (unfold)
+        hipLaunchKernelGGL(sr_tr_oca_unfold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(sr_tr_oca_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    SR_CHECK_LAUNCH("sr_tr_oca_fold");
+    return SR_OK;
+}
 
 extern "C" int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream) {
     SR_REQUIRE(dbias_part && rpi && dtable && groups > 0 && T > 0 && heads > 0 && NN > 0, "sr_tr_dbias: bad arguments");

@@ -19,6 +19,7 @@ Activations kept for the backward live in per-block static buffers (one forward 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -319,39 +320,44 @@ def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) 
     return b, bt, bf
 
 
-# --------------------------------------------------------------------------- one HAB
-class HabPlan:
-    """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195)."""
+# --------------------------------------------------------------------------- one block (HAB or OCAB)
+class BlockPlan:
+    """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195) or OCAB (hat.py:107-118,239-293; oca = True: no CAB, no shift,
+    no DropPath, keys / values from the unfolded 24 x 24 neighbourhood)."""
 
-    def __init__(self, fp: FlatParams, blk, rpi_sa: np.ndarray, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: FinalMap) -> None:
-        self.shift, self.conv_scale = shift, float(conv_scale)
-        self.fp = fp
-        at, mlp = blk.attn, blk.mlp
-        cab = blk.conv_block.cab
-        ca = cab[3].attention
-        self.blk = blk
-        # ---- packed operands
+    def __init__(self, fp: FlatParams, blk, rpi: np.ndarray, rpi_dev: Tensor, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: "FinalMap", oca: bool = False) -> None:
+        self.shift, self.conv_scale, self.oca = shift, float(conv_scale), oca
+        self.fp, self.blk, self.fm, self.rpi_dev = fp, blk, fm, rpi_dev
+        at = blk if oca else blk.attn  # OCAB holds qkv / proj / table itself
+        mlp = blk.mlp
+        self.at, self.mlp = at, mlp
+        self.nk = 576 if oca else 256
         self.o_qkvf = wa.add(pack_qkv_fwd(fp, at.qkv.weight, at.qkv.bias))
         self.o_tailf = wa.add(pack_tail_fwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
         self.o_tailb = wa.add(pack_tail_bwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
         self.o_qkvb = wa.add(pack_qkv_bwd(fp, at.qkv.weight))
-        self.o_c1 = wa.add(pack_conv(fp, cab[0].weight, CP, 64))
-        self.o_c2 = wa.add(pack_conv(fp, cab[2].weight, 64, CP))
-        self.o_c1t = wa.add(pack_conv(fp, cab[0].weight, 64, CP, transpose=True))   # dmid [64] -> dn1 [192]
-        self.o_c2t = wa.add(pack_conv(fp, cab[2].weight, CP, 64, transpose=True))   # dy [192] -> dmid [64]
         self.o_g1, self.o_b1 = fa.add(pack_vec(fp, blk.norm1.weight, CP)), fa.add(pack_vec(fp, blk.norm1.bias, CP))
         self.o_g2, self.o_b2 = fa.add(pack_vec(fp, blk.norm2.weight, CP)), fa.add(pack_vec(fp, blk.norm2.bias, CP))
         self.o_bp = fa.add(pack_vec(fp, at.proj.bias, CP))
-        self.o_bc1, self.o_bc2 = fa.add(pack_vec(fp, cab[0].bias, 64)), fa.add(pack_vec(fp, cab[2].bias, CP))
-        b, bt, bf = pack_bias(fp, at.relative_position_bias_table, rpi_sa, 256, 256)
-        self.o_bias, self.o_biasT, self.o_biasF = fa.add(b), fa.add(bt), fa.add(bf)
-        self.ca = (ca[1].weight, ca[1].bias, ca[3].weight, ca[3].bias)
         self.table = at.relative_position_bias_table
-        self.fm = fm
-        self._final_maps(fp, fm, at, mlp, cab, ca)
+        b, bt, bf = pack_bias(fp, self.table, rpi, 256, self.nk)
+        self.o_bias, self.o_biasT = fa.add(b), fa.add(bt)
+        self.o_biasF = None if oca else fa.add(bf)
+        self.cab = None
+        if not oca:
+            cab = blk.conv_block.cab
+            ca = cab[3].attention
+            self.cab, self.ca_mod = cab, ca
+            self.o_c1 = wa.add(pack_conv(fp, cab[0].weight, CP, 64))
+            self.o_c2 = wa.add(pack_conv(fp, cab[2].weight, 64, CP))
+            self.o_c1t = wa.add(pack_conv(fp, cab[0].weight, 64, CP, transpose=True))   # dmid [64] -> dn1 [192]
+            self.o_c2t = wa.add(pack_conv(fp, cab[2].weight, CP, 64, transpose=True))   # dy [192] -> dmid [64]
+            self.o_bc1, self.o_bc2 = fa.add(pack_vec(fp, cab[0].bias, 64)), fa.add(pack_vec(fp, cab[2].bias, CP))
+            self.ca = (ca[1].weight, ca[1].bias, ca[3].weight, ca[3].bias)
+        self._final_maps()
 
-    def _final_maps(self, fp, fm, at, mlp, cab, ca) -> None:
-        ks = WG_KS
+    def _final_maps(self) -> None:
+        fp, fm, at, mlp, ks = self.fp, self.fm, self.at, self.mlp, WG_KS
         # -- qkv: out [ks][576][192]; n = part * 192 + head * 32 + d
         n_qkv = 3 * HEADS * HDP
         self.f_qkv = fm.alloc(ks * n_qkv * CP)
@@ -372,49 +378,141 @@ class HabPlan:
         self.f_fc2 = fm.alloc(ks * CP * HP)
         fm.put(fp.pidx(mlp.fc2.weight), self.f_fc2 + np.arange(C_REAL)[:, None] * HP + np.arange(HID)[None, :], CP * HP, ks)
         fm.put(fp.pidx(mlp.fc2.bias), self.f_fc2 + np.arange(C_REAL) * HP + HID, CP * HP, ks)
-        # -- CAB convs: out [ks][9][Np][Kp]
-        c3 = cab[0].weight.shape[0]
-        self.f_c1 = fm.alloc(ks * 9 * 64 * CP)
-        co, ci, tp = np.arange(c3)[:, None, None], np.arange(C_REAL)[None, :, None], np.arange(9)[None, None, :]
-        fm.put(fp.pidx(cab[0].weight).reshape(c3, C_REAL, 9), self.f_c1 + (tp * 64 + co) * CP + ci, 9 * 64 * CP, ks)
-        fm.put(fp.pidx(cab[0].bias), self.f_c1 + (4 * 64 + np.arange(c3)) * CP + C_REAL, 9 * 64 * CP, ks)  # centre tap, the ones channel of n1
-        self.f_c2 = fm.alloc(ks * 9 * CP * 64)
-        co, ci = np.arange(C_REAL)[:, None, None], np.arange(c3)[None, :, None]
-        fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
-        fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
-        # -- the remaining partial buffers are sized per geometry (prepare): LayerNorm partials, channel-attention partials, bias table
-        self._final_late = (at, mlp, cab, ca)
+        if self.cab is not None:  # CAB convs: out [ks][9][Np][Kp]
+            cab = self.cab
+            c3 = cab[0].weight.shape[0]
+            self.f_c1 = fm.alloc(ks * 9 * 64 * CP)
+            co, ci, tp = np.arange(c3)[:, None, None], np.arange(C_REAL)[None, :, None], np.arange(9)[None, None, :]
+            fm.put(fp.pidx(cab[0].weight).reshape(c3, C_REAL, 9), self.f_c1 + (tp * 64 + co) * CP + ci, 9 * 64 * CP, ks)
+            fm.put(fp.pidx(cab[0].bias), self.f_c1 + (4 * 64 + np.arange(c3)) * CP + C_REAL, 9 * 64 * CP, ks)  # centre tap, the ones channel of n1
+            self.f_c2 = fm.alloc(ks * 9 * CP * 64)
+            co, ci = np.arange(C_REAL)[:, None, None], np.arange(c3)[None, :, None]
+            fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
+            fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
 
     def prepare(self, B: int, H: int, W: int, dev) -> None:
-        """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images."""
+        """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images; static activations."""
         fp, fm = self.fp, self.fm
-        at, mlp, cab, ca = self._final_late
         nwg = B * H * W // 64
         self.f_ln1, self.f_ln2 = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
         for f, norm in ((self.f_ln1, self.blk.norm1), (self.f_ln2, self.blk.norm2)):
             fm.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
             fm.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
-        cr = ca[1].weight.shape[0]
-        self.ca_stride = (2 * cr * C_REAL + cr + C_REAL + 63) // 64 * 64
-        self.f_ca = fm.alloc(B * self.ca_stride)
-        o = self.f_ca
-        fm.put(fp.pidx(ca[1].weight), o + np.arange(cr * C_REAL), self.ca_stride, B)
-        fm.put(fp.pidx(ca[1].bias), o + cr * C_REAL + np.arange(cr), self.ca_stride, B)
-        fm.put(fp.pidx(ca[3].weight), o + cr * C_REAL + cr + np.arange(C_REAL * cr), self.ca_stride, B)
-        fm.put(fp.pidx(ca[3].bias), o + cr * C_REAL + cr + C_REAL * cr + np.arange(C_REAL), self.ca_stride, B)
+        if self.cab is not None:
+            ca = self.ca_mod
+            cr = ca[1].weight.shape[0]
+            self.ca_stride = (2 * cr * C_REAL + cr + C_REAL + 63) // 64 * 64
+            self.f_ca = fm.alloc(B * self.ca_stride)
+            o = self.f_ca
+            fm.put(fp.pidx(ca[1].weight), o + np.arange(cr * C_REAL), self.ca_stride, B)
+            fm.put(fp.pidx(ca[1].bias), o + cr * C_REAL + np.arange(cr), self.ca_stride, B)
+            fm.put(fp.pidx(ca[3].weight), o + cr * C_REAL + cr + np.arange(C_REAL * cr), self.ca_stride, B)
+            fm.put(fp.pidx(ca[3].bias), o + cr * C_REAL + cr + C_REAL * cr + np.arange(C_REAL), self.ca_stride, B)
         tb = self.table
         self.f_tab = fm.alloc(tb.numel())
         fm.put(fp.pidx(tb), self.f_tab + np.arange(tb.numel()), 0, 1)
-        # static activations kept from forward to backward
         T = B * H * W
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
         self.x1 = e(T, CP, dt=f32)
-        self.q, self.qT, self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(6))
-        self.o, self.n1, self.y = e(T, CP), e(T, CP), e(T, CP)
-        self.n_tiles = ops.cab_pool_tiles(H, W)
-        self.pool = e(B, self.n_tiles, CP, dt=f32)
-        self.gate = e(B, CP, dt=f32)
+        self.q, self.qT, self.o = e(T * CP), e(T * CP), e(T, CP)
+        if self.oca:
+            n = T // 256 * HEADS * 576 * 32
+            self.k, self.kT, self.v = e(n), e(n), e(n)  # the unfolded neighbourhoods
+        else:
+            self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(4))
+            self.n1, self.y = e(T, CP), e(T, CP)
+            self.n_tiles = ops.cab_pool_tiles(H, W)
+            self.pool = e(B, self.n_tiles, CP, dt=f32)
+            self.gate = e(B, CP, dt=f32)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, st: "Stage", cur: Tensor, out: Tensor, sc_i: Optional[Tensor]) -> None:
+        B, H, W = st.geo
+        wa, fa, sc = st.wa.buf, st.fa.buf, st.sc
+        lib = L.lib()
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
+        nbw = B * H * W // 256
+        if self.oca:
+            _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
+                  wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=sc.dk.data_ptr(), kT=sc.dq.data_ptr(), v=sc.dv.data_ptr(),
+                  vT=sc.dOT.data_ptr(), n1=None, ldn=CP, shift=0, **g)  # k / v in scratch (dk, dv; the transposes are not needed): only their unfolded copies are kept
+            a = L.SrTrOcaFold()
+            a.k, a.v, a.kwin, a.vwin, a.kwinT, a.vwinT = sc.dk.data_ptr(), sc.dv.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), self.kT.data_ptr(), sc.vwinT.data_ptr()
+            a.B, a.nwy, a.nwx, a.heads, a.wse, a.pad = B, H // 16, W // 16, HEADS, 24, 4
+            L.check(lib.sr_tr_oca_fold(C.byref(a), 1, _st()), "sr_tr_oca_fold")
+            _call(lib.sr_tr_attn_fwd, L.SrTrAttnFwd, "sr_tr_attn_fwd", q=self.q.data_ptr(), k=self.k.data_ptr(), vT=sc.vwinT.data_ptr(), bias=fa[self.o_bias:].data_ptr(),
+                  out=self.o.data_ptr(), n_bwin=nbw, heads=HEADS, hd_p=HDP, Nq=256, Nk=576, ldo=CP)
+        else:
+            _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
+                  wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
+                  vT=self.vT.data_ptr(), n1=self.n1.data_ptr(), ldn=CP, shift=self.shift, **g)
+            ops.window_attention(q=self.q.data_ptr(), k=self.k.data_ptr(), vt=self.vT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), out=self.o.data_ptr(), n_bwin=nbw,
+                                 heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
+                                 bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0)
+            ops.cab_fused(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
+                          y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
+        kw = {}
+        if self.cab is not None:
+            w1, b1, w2, b2 = self.ca
+            kw = dict(y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
+                      gate_out=self.gate.data_ptr(), ca_Cr=w1.shape[0], ca_n_tiles=self.n_tiles, y_scale=self.conv_scale)
+        _call(lib.sr_tr_tail_fwd, L.SrTrTailFwd, "sr_tr_tail_fwd", x=cur.data_ptr(), out=out.data_ptr(), x1=self.x1.data_ptr(), o=self.o.data_ptr(),
+              wstream=wa[self.o_tailf:].data_ptr(), bproj=fa[self.o_bp:].data_ptr(), gamma=fa[self.o_g2:].data_ptr(), beta=fa[self.o_b2:].data_ptr(),
+              s_a=None if sc_i is None else sc_i[0].data_ptr(), s_m=None if sc_i is None else sc_i[1].data_ptr(), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, st: "Stage", xin: Tensor, d: Tensor, dx: Tensor, sc_i: Optional[Tensor]) -> None:
+        B, H, W = st.geo
+        T = B * H * W
+        wa, fa, sc, fm = st.wa.buf, st.fa.buf, st.sc, st.fm
+        lib = L.lib()
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
+        pp = lambda off: fm.part.data_ptr() + 4 * off  # noqa: E731
+        s_a = None if sc_i is None else sc_i[0].data_ptr()
+        s_m = None if sc_i is None else sc_i[1].data_ptr()
+        kw = {}
+        if self.cab is not None:
+            kw = dict(y=self.y.data_ptr(), gate=self.gate.data_ptr(), dyc=sc.dyc.data_ptr(), dgate_part=sc.dgate_part.data_ptr())
+        _call(lib.sr_tr_tail_bwd, L.SrTrTailBwd, "sr_tr_tail_bwd", dout=d.data_ptr(), x1=self.x1.data_ptr(), gamma=fa[self.o_g2:].data_ptr(), beta=fa[self.o_b2:].data_ptr(),
+              wstream=wa[self.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(), n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(),
+              dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=sc.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
+        dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
+        dbp = sc.dbias_oca if self.oca else sc.dbias_part
+        _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
+              o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
+              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dbias_part=dbp.data_ptr(), n_bwin=T // 256,
+              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=sc.groups, H=H, W=W, ws=16, shift=self.shift)
+        L.check(lib.sr_tr_dbias(dbp.data_ptr(), sc.groups, self.rpi_dev.data_ptr(), pp(self.f_tab), self.table.shape[0], HEADS, 256 * self.nk, _st()), "sr_tr_dbias")
+        jobs = []
+        ks = WG_KS
+        if self.oca:
+            a = L.SrTrOcaFold()
+            a.k, a.v, a.kwin, a.vwin = sc.dk.data_ptr(), sc.dv.data_ptr(), sc.dkwin.data_ptr(), sc.dvwin.data_ptr()
+            a.B, a.nwy, a.nwx, a.heads, a.wse, a.pad = B, H // 16, W // 16, HEADS, 24, 4
+            L.check(lib.sr_tr_oca_fold(C.byref(a), 0, _st()), "sr_tr_oca_fold")
+        else:  # ---- CAB backward (hat.py:41-52)
+            w1, b1, w2, b2 = self.ca
+            _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], sc.mid_pre, B, H, W, CP, 64)
+            _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
+                  w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
+                  parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
+            _conv(sc.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
+            L.check(lib.sr_tr_gelu(sc.mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
+            _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
+            jobs += [
+                dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=ks),
+            ]
+        _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
+              dn1c=None if self.oca else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
+              n1w=sc.n1w.data_ptr(), dqkvw=sc.dqkvw.data_ptr(), ln_part=pp(self.f_ln1), ldn=CP, shift=self.shift, **g)
+        _wgrad([
+            dict(A=sc.dqkvw.data_ptr(), B=sc.n1w.data_ptr(), out=pp(self.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            dict(A=sc.dx1sw.data_ptr(), B=self.o.data_ptr(), out=pp(self.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
+            dict(A=sc.dhw.data_ptr(), B=sc.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            dict(A=sc.doutw.data_ptr(), B=sc.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+        ] + jobs)
 
 
 class Scratch:
@@ -434,6 +532,9 @@ class Scratch:
         self.groups = groups
         self.dbias_part = e(groups, HEADS, 256, 256, dt=f32)
         self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))
+        n = T // 256 * HEADS * 576 * 32  # OCAB: unfolded neighbourhoods
+        self.vwinT, self.dkwin, self.dvwin = e(n), e(n), e(n)
+        self.dbias_oca = e(groups, HEADS, 256, 576, dt=f32)
 
 
 def _conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, B: int, H: int, W: int, cin_p: int, cout_p: int) -> None:
@@ -458,18 +559,21 @@ def _call(fn, struct, what: str, **kw) -> None:
 
 
 class Stage:
-    """A run of consecutive HABs (one RHAG's blocks) with its arenas; forward / backward as launch sequences."""
+    """The blocks of one RHAG (six HABs, then the OCAB) with their gradient map; forward / backward as launch sequences."""
 
-    def __init__(self, fp: FlatParams, blocks, rpi_sa: Tensor, conv_scale: float, wa: Arena, fa: Arena) -> None:
+    def __init__(self, fp: FlatParams, habs, ocab, rpi_sa: Tensor, rpi_oca: Tensor, conv_scale: float, wa: Arena, fa: Arena) -> None:
         self.fp, self.wa, self.fa = fp, wa, fa
-        params = [p for b in blocks for p in b.parameters()]
+        mods = list(habs) + ([ocab] if ocab is not None else [])
+        params = [p for b in mods for p in b.parameters()]
         p0 = min(fp.off(p) for p in params)
         p1 = max(fp.off(p) + (p.numel() + 3) // 4 * 4 for p in params)
         self.params = params
         self.fm = FinalMap(fp, p0, p1)
-        rpi = rpi_sa.detach().cpu().numpy()
-        self.rpi_dev = rpi_sa.detach().to(torch.int64).contiguous()
-        self.habs = [HabPlan(fp, b, rpi, conv_scale, b.shift_size, wa, fa, self.fm) for b in blocks]
+        sa_dev, oca_dev = rpi_sa.detach().to(torch.int64).contiguous(), rpi_oca.detach().to(torch.int64).contiguous()
+        self.blocks = [BlockPlan(fp, b, rpi_sa.detach().cpu().numpy(), sa_dev, conv_scale, b.shift_size, wa, fa, self.fm) for b in habs]
+        if ocab is not None:
+            self.blocks.append(BlockPlan(fp, ocab, rpi_oca.detach().cpu().numpy(), oca_dev, 0.0, 0, wa, fa, self.fm, oca=True))
+        self.n_habs = len(habs)
         self.geo = None
         self.gen = 0
 
@@ -477,91 +581,33 @@ class Stage:
         if self.geo == (B, H, W):
             return
         assert self.geo is None, "one geometry per fast-training plan (rebuild the plan for another batch / patch size)"
-        for h in self.habs:
+        for h in self.blocks:
             h.prepare(B, H, W, dev)
         self.fm.finish(dev)
         self.geo = (B, H, W)
         self.sc = scratch
-        self.ts = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in self.habs]  # block outputs
-        self.tab_lo = min(h.f_tab for h in self.habs)
-        self.tab_hi = max(h.f_tab + h.table.numel() for h in self.habs)
+        self.ts = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in self.blocks]  # block outputs
+        self.tab_lo = min(h.f_tab for h in self.blocks)
+        self.tab_hi = max(h.f_tab + h.table.numel() for h in self.blocks)
 
-    # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, scales: Optional[Tensor]) -> Tensor:
-        B, H, W = self.geo
-        wa, fa = self.wa.buf, self.fa.buf
-        lib = L.lib()
-        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
         cur = x
-        for i, h in enumerate(self.habs):
-            out = self.ts[i]
-            _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[h.o_g1:].data_ptr(), beta=fa[h.o_b1:].data_ptr(),
-                  wstream=wa[h.o_qkvf:].data_ptr(), q=h.q.data_ptr(), qT=h.qT.data_ptr(), k=h.k.data_ptr(), kT=h.kT.data_ptr(), v=h.v.data_ptr(), vT=h.vT.data_ptr(),
-                  n1=h.n1.data_ptr(), ldn=CP, shift=h.shift, **g)
-            ops.window_attention(q=h.q.data_ptr(), k=h.k.data_ptr(), vt=h.vT.data_ptr(), bias=fa[h.o_bias:].data_ptr(), out=h.o.data_ptr(), n_bwin=B * H * W // 256,
-                                 heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=h.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
-                                 bias_frag=fa[h.o_biasF:].data_ptr(), qkv_frag=0)
-            ops.cab_fused(x=h.n1.data_ptr(), w1p=wa[h.o_c1:].data_ptr(), b1=fa[h.o_bc1:].data_ptr(), w2p=wa[h.o_c2:].data_ptr(), b2=fa[h.o_bc2:].data_ptr(),
-                          y=h.y.data_ptr(), pool_partial=h.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
-            w1, b1, w2, b2 = h.ca
-            _call(lib.sr_tr_tail_fwd, L.SrTrTailFwd, "sr_tr_tail_fwd", x=cur.data_ptr(), out=out.data_ptr(), x1=h.x1.data_ptr(), o=h.o.data_ptr(),
-                  wstream=wa[h.o_tailf:].data_ptr(), bproj=fa[h.o_bp:].data_ptr(), gamma=fa[h.o_g2:].data_ptr(), beta=fa[h.o_b2:].data_ptr(), y=h.y.data_ptr(),
-                  pool_partial=h.pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(), gate_out=h.gate.data_ptr(),
-                  s_a=None if scales is None else scales[i, 0].data_ptr(), s_m=None if scales is None else scales[i, 1].data_ptr(), ldy=CP, shift=h.shift, Hp=HP,
-                  ca_Cr=w1.shape[0], ca_n_tiles=h.n_tiles, y_scale=h.conv_scale, **g)
-            cur = out
+        for i, h in enumerate(self.blocks):
+            h.forward(self, cur, self.ts[i], None if (scales is None or h.oca) else scales[i])
+            cur = self.ts[i]
         return cur
 
-    # ------------------------------------------------------------------ backward
     def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor]) -> Tensor:
         """dout: gradient of the stage output; returns the gradient of x (a fresh tensor); fills G for the stage's parameters."""
         B, H, W = self.geo
-        T = B * H * W
-        wa, fa, sc, fm = self.wa.buf, self.fa.buf, self.sc, self.fm
-        lib = L.lib()
-        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
-        part = fm.part
-        fm.part[self.tab_lo:self.tab_hi].zero_()  # the bias-table gradients are scatter-added
-        pp = lambda off: part.data_ptr() + 4 * off  # noqa: E731
+        self.fm.part[self.tab_lo:self.tab_hi].zero_()  # the bias-table gradients are scatter-added
         d = dout.contiguous()
-        for i in range(len(self.habs) - 1, -1, -1):
-            h = self.habs[i]
-            xin = x if i == 0 else self.ts[i - 1]
+        for i in range(len(self.blocks) - 1, -1, -1):
+            h = self.blocks[i]
             dx = torch.empty(B, H, W, CP, dtype=torch.float32, device=d.device)
-            s_a = None if scales is None else scales[i, 0].data_ptr()
-            s_m = None if scales is None else scales[i, 1].data_ptr()
-            _call(lib.sr_tr_tail_bwd, L.SrTrTailBwd, "sr_tr_tail_bwd", dout=d.data_ptr(), x1=h.x1.data_ptr(), y=h.y.data_ptr(), gate=h.gate.data_ptr(),
-                  gamma=fa[h.o_g2:].data_ptr(), beta=fa[h.o_b2:].data_ptr(), wstream=wa[h.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(),
-                  n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(), dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(),
-                  dx1sw=sc.dx1sw.data_ptr(), dyc=sc.dyc.data_ptr(), dgate_part=sc.dgate_part.data_ptr(), ln_part=pp(h.f_ln2), ldy=CP, shift=h.shift, Hp=HP, **g)
-            _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=h.q.data_ptr(), qT=h.qT.data_ptr(), k=h.k.data_ptr(), kT=h.kT.data_ptr(), v=h.v.data_ptr(),
-                  o=h.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[h.o_bias:].data_ptr(), biasT=fa[h.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
-                  dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dbias_part=sc.dbias_part.data_ptr(), n_bwin=T // 256,
-                  heads=HEADS, hd_p=HDP, Nq=256, Nk=256, ldo=CP, groups=sc.groups, H=H, W=W, ws=16, shift=h.shift)
-            L.check(lib.sr_tr_dbias(sc.dbias_part.data_ptr(), sc.groups, self.rpi_dev.data_ptr(), pp(h.f_tab), h.table.shape[0], HEADS, 256 * 256, _st()), "sr_tr_dbias")
-            # ---- CAB backward (hat.py:41-52)
-            w1, b1, w2, b2 = h.ca
-            _conv(h.n1, wa[h.o_c1:], fa[h.o_bc1:], sc.mid_pre, B, H, W, CP, 64)
-            _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=h.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
-                  w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(h.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=h.n_tiles,
-                  parts=H * W // 64, ld=CP, dparam_stride=h.ca_stride, y_scale=h.conv_scale)
-            _conv(sc.dyc, wa[h.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
-            L.check(lib.sr_tr_gelu(sc.mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
-            _conv(sc.dmid, wa[h.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
-            _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
-                  dn1c=sc.dn1c.data_ptr(), gamma=fa[h.o_g1:].data_ptr(), beta=fa[h.o_b1:].data_ptr(), wstream=wa[h.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
-                  n1w=sc.n1w.data_ptr(), dqkvw=sc.dqkvw.data_ptr(), ln_part=pp(h.f_ln1), ldn=CP, shift=h.shift, **g)
-            ks = WG_KS
-            _wgrad([
-                dict(A=sc.dqkvw.data_ptr(), B=sc.n1w.data_ptr(), out=pp(h.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-                dict(A=sc.dx1sw.data_ptr(), B=h.o.data_ptr(), out=pp(h.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
-                dict(A=sc.dhw.data_ptr(), B=sc.n2w.data_ptr(), out=pp(h.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-                dict(A=sc.doutw.data_ptr(), B=sc.gw.data_ptr(), out=pp(h.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-                dict(A=sc.dmid.data_ptr(), B=h.n1.data_ptr(), out=pp(h.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=ks),
-                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(h.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=ks),
-            ])
+            h.backward(self, x if i == 0 else self.ts[i - 1], d, dx, None if (scales is None or h.oca) else scales[i])
             d = dx
-        fm.run(self.fp.G)
+        self.fm.run(self.fp.G)
         return d
 
 
@@ -599,7 +645,10 @@ class HatPlan:
         self.fp = FlatParams(model)
         dev = self.fp.P.device
         self.wa, self.fa = Arena(torch.bfloat16), Arena(torch.float32)
-        self.stages = [Stage(self.fp, list(layer.residual_group.blocks), model.relative_position_index_SA, model.conv_scale, self.wa, self.fa) for layer in model.layers]
+        with_oca = os.environ.get("SR_FAST_OCAB", "1") != "0"
+        self.with_oca = with_oca
+        self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
+                             model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa) for layer in model.layers]
         self.wa.finish(dev)
         self.fa.finish(dev)
         self.scratch = None
@@ -610,7 +659,7 @@ class HatPlan:
     def supported(model) -> bool:
         try:
             return (type(model).__name__ == "HAT" and model.embed_dim == C_REAL and model.window_size == 16 and all(h == HEADS for h in model.num_heads) and
-                    int(model.embed_dim * model.mlp_ratio) == HID and model.embed_dim // model.compress_ratio == 60 and model.embed_dim // model.squeeze_factor == CR and
+                    int(model.embed_dim * model.mlp_ratio) == HID and int(model.window_size * model.overlap_ratio) == 8 and model.embed_dim // model.compress_ratio == 60 and model.embed_dim // model.squeeze_factor == CR and
                     next(model.parameters()).is_cuda)
         except Exception:
             return False

@@ -217,12 +217,13 @@ def hat_forward(model, x: Tensor) -> Tensor:
                 m = _mlp(blk.mlp, A.layer_norm(t, blk.norm2.weight, blk.norm2.bias))
                 t = A.add(t, A.drop_path(m, dpr[k], model.training))
                 k += 1
-        oc = grp.overlap_attn  # OCAB (hat.py:239-293): no DropPath
-        wse = oc.overlap_win_size
-        qkv = A.linear(A.layer_norm(t, oc.norm1.weight, oc.norm1.bias), oc.qkv.weight, oc.qkv.bias)  # [B,H,W,3C]
-        o = A.cross_window_attention(A.window_partition(qkv, ws, 0), A.oca_unfold(qkv, ws, wse), oc.relative_position_bias_table, rpi_oca, heads, ws * ws, wse * wse, Cn)
-        t = A.add(A.linear(A.window_reverse(o, ws, 0, t.shape), oc.proj.weight, oc.proj.bias), t)
-        t = A.add(t, _mlp(oc.mlp, A.layer_norm(t, oc.norm2.weight, oc.norm2.bias)))
+        if plan is None or not plan.with_oca:
+            oc = grp.overlap_attn  # OCAB (hat.py:239-293): no DropPath
+            wse = oc.overlap_win_size
+            qkv = A.linear(A.layer_norm(t, oc.norm1.weight, oc.norm1.bias), oc.qkv.weight, oc.qkv.bias)  # [B,H,W,3C]
+            o = A.cross_window_attention(A.window_partition(qkv, ws, 0), A.oca_unfold(qkv, ws, wse), oc.relative_position_bias_table, rpi_oca, heads, ws * ws, wse * wse, Cn)
+            t = A.add(A.linear(A.window_reverse(o, ws, 0, t.shape), oc.proj.weight, oc.proj.bias), t)
+            t = A.add(t, _mlp(oc.mlp, A.layer_norm(t, oc.norm2.weight, oc.norm2.bias)))
         t = A.add(_conv(t, layer.conv), tin)  # hat.py:385
     t = A.layer_norm(t, model.norm.weight, model.norm.bias)
     body = A.add(_conv(t, model.conv_after_body), first)
