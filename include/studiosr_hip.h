@@ -477,7 +477,7 @@ int sr_pack_bias_fragments(const float* table, const long long* rpi, float* out,
  *   mode[i] == 1: v = bf16(v) (leading part of a bias carried as hi + lo on the two constant-one channels), == 2: v - bf16(v);
  *   out[i] = (out_dtype) v.  Replaces studiosr_amd/packing.py's per-tensor torch ops in the training loop. */
 int sr_tr_gather(const float* P, const int* idx, const int* idx2, const float* scl, const unsigned char* mode, void* out, int out_dtype, long long n, void* stream);
-/* The adjoint: grad[i] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]]  (src[i] < 0: grad[i] = 0); sums in slice order. */
+/* The adjoint: grad[i] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]]  (src[i] == -1: grad[i] = 0; src[i] == -2: grad[i] untouched); sums in slice order. */
 int sr_tr_finalize(const float* arena, const long long* src, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream);
 
 typedef struct SrTrWgradJob {
@@ -487,6 +487,7 @@ typedef struct SrTrWgradJob {
      * ones_col of B reads as 1 (bias gradient as one more column).  out: fp32 [ks][taps][Np][Kp] partial sums (ks token slices). */
     const void* A; const void* B; float* out;
     int lda, ldb, Np, Kp, T, taps, H, W, ones_col, ks;
+    int a_f32, b_f32;   /* 1: that operand is fp32 (rounded to bf16 while it is staged), 0: bf16 */
 } SrTrWgradJob;
 int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream); /* jobs: HOST array, at most 8 per launch */
 long long sr_tr_wgrad_out_floats(const SrTrWgradJob* j);
@@ -588,6 +589,19 @@ typedef struct SrTrCaBwd {
     float y_scale;
 } SrTrCaBwd;
 int sr_tr_ca_bwd(const SrTrCaBwd* a, void* stream);
+
+typedef struct SrTrLnBwd {
+    /* nn.LayerNorm backward alone on the padded fp32 stream: dx = LN'(x)^T dy (+ dskip); ln_part [M / 64][2][Cp] dgamma | dbeta partials.
+     * dy / dskip fp32 or bf16 (flags); rows in memory order, M % 64 == 0. */
+    const float* x; const void* dy; const float* gamma; const void* dskip; float* dx; float* ln_part;
+    long long M; int C, Cp, ld, dy_bf16, dskip_bf16; float eps;
+} SrTrLnBwd;
+int sr_tr_ln_bwd(const SrTrLnBwd* a, void* stream);
+/* nn.PixelShuffle(r) backward on NHWC bf16 into the conv's packed row order n = (i r + j) cps + c; LeakyReLU backward from the output;
+ * out = a + b (b fp32 or bf16, b_dtype = SR_*). */
+int sr_tr_unshuffle(const void* src, void* dst, int B, int H, int W, int cps, int r, void* stream);
+int sr_tr_lrelu_bwd(const void* dy, const void* y, void* dx, float slope, long long n, void* stream);
+int sr_tr_add(const float* a, const void* b, int b_dtype, float* out, long long n, void* stream);
 
 /* g = GELU(x) and / or dx = dg * GELU'(x), bf16 (the nn.GELU between the CAB's convolutions, hat.py:43); n elements, n % 8 == 0. */
 int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long long n, void* stream);

@@ -155,7 +155,7 @@ class SrBgemm(C.Structure):
 # ---- fast training path (ABI v7)
 class SrTrWgradJob(C.Structure):
     _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("lda", _i), ("ldb", _i), ("Np", _i), ("Kp", _i), ("T", _i), ("taps", _i), ("H", _i), ("W", _i),
-                ("ones_col", _i), ("ks", _i)]
+                ("ones_col", _i), ("ks", _i), ("a_f32", _i), ("b_f32", _i)]
 
 
 class SrTrAttnBwd(C.Structure):
@@ -204,6 +204,11 @@ class SrTrQkvBwd(C.Structure):
         ("dx", _vp), ("n1w", _vp), ("dqkvw", _vp), ("ln_part", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("ldn", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("eps", _f),
     ]
+
+
+class SrTrLnBwd(C.Structure):
+    _fields_ = [("x", _vp), ("dy", _vp), ("gamma", _vp), ("dskip", _vp), ("dx", _vp), ("ln_part", _vp), ("M", _ll), ("C", _i), ("Cp", _i), ("ld", _i),
+                ("dy_bf16", _i), ("dskip_bf16", _i), ("eps", _f)]
 
 
 class SrTrCaBwd(C.Structure):
@@ -289,6 +294,10 @@ SYMBOLS = {
     "sr_tr_qkv_bwd": (_i, [C.POINTER(SrTrQkvBwd), _vp]),
     "sr_tr_ca_bwd": (_i, [C.POINTER(SrTrCaBwd), _vp]),
     "sr_tr_gelu": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    "sr_tr_ln_bwd": (_i, [C.POINTER(SrTrLnBwd), _vp]),
+    "sr_tr_unshuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sr_tr_lrelu_bwd": (_i, [_vp, _vp, _vp, _f, _ll, _vp]),
+    "sr_tr_add": (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
 }
 
 _lib = None

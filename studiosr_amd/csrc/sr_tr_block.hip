@@ -919,6 +919,55 @@ __global__ __launch_bounds__(256) void sr_tr_gelu_kernel(const bf16* x, const bf
     if (dx) reinterpret_cast<bf16x8*>(dx)[i] = dxv;
 }
 
+
+// ============================================================================================================ LayerNorm backward alone
+// nn.LayerNorm backward on the padded fp32 stream (swinir.py:26,313 / hat.py:460: patch_embed.norm and the final norm): rows in memory order,
+// 64 per workgroup; dx = LN'(x)^T dy (+ dskip), dgamma / dbeta partials per workgroup
+__global__ __launch_bounds__(256, 1) void sr_tr_ln_bwd_kernel(SrTrLnBwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    Pos P;
+    P.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    P.lane = threadIdx.x & 63;
+    P.ar = P.lane & 15;
+    P.ag = P.lane >> 4;
+    const int ch0 = P.w * 48 + P.ag * 4;
+    const size_t row0 = (size_t)blockIdx.x * NTOK;
+    f32x4 xh[4][3], dn[4][3], gm[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const size_t o = (row0 + m * 16 + P.ar) * a.ld + ch0 + n * 16;
+            xh[m][n] = *reinterpret_cast<const f32x4*>(a.x + o);
+            dn[m][n] = a.dy_bf16 ? widen4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.dy) + o)) : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dy) + o);
+        }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) gm[n] = *reinterpret_cast<const f32x4*>(a.gamma + ch0 + n * 16);
+    float mean[4], rstd[4];
+    ln_stats(xh, red, P, a.C, a.eps, mean, rstd);
+    const bool padl = P.w == 3 && P.ag >= 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[m][n][r] = (xh[m][n][r] - mean[m]) * rstd[m];
+            if (n == 2 && padl) xh[m][n] = (f32x4)(0.0f);
+        }
+    ln_bwd_tile(dn, xh, rstd, gm, red, P, a.C, a.ln_part + (size_t)blockIdx.x * 2 * a.Cp, a.Cp);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const size_t o = (row0 + m * 16 + P.ar) * a.ld + ch0 + n * 16;
+            f32x4 v = dn[m][n];
+            if (a.dskip) v += a.dskip_bf16 ? widen4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.dskip) + o)) : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dskip) + o);
+            if (n == 2 && padl) v = (f32x4)(0.0f);
+            *reinterpret_cast<f32x4*>(a.dx + o) = v;
+        }
+}
+
 }  // namespace
 
 static bool tr_geo_ok(int B, int H, int W, int C, int Cp, int heads, int hd_p, int ws, int shift, int ldx) {
@@ -1014,5 +1063,14 @@ extern "C" int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long
     hipLaunchKernelGGL(sr_tr_gelu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(x),
                        reinterpret_cast<const bf16*>(dg), reinterpret_cast<bf16*>(g), reinterpret_cast<bf16*>(dx), n8);
     SR_CHECK_LAUNCH("sr_tr_gelu");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_ln_bwd(const SrTrLnBwd* p, void* stream) {
+    SR_REQUIRE(p && p->x && p->dy && p->gamma && p->dx && p->ln_part, "sr_tr_ln_bwd: null pointer");
+    const SrTrLnBwd& a = *p;
+    SR_REQUIRE(a.M > 0 && a.M % 64 == 0 && a.C == 180 && a.Cp == 192 && a.ld >= a.Cp && a.ld % 4 == 0, "sr_tr_ln_bwd: rows must be a multiple of 64, C 180 / Cp 192");
+    hipLaunchKernelGGL(sr_tr_ln_bwd_kernel, dim3((unsigned)(a.M / 64)), dim3(256), LDS_RED, reinterpret_cast<hipStream_t>(stream), a);
+    SR_CHECK_LAUNCH("sr_tr_ln_bwd");
     return SR_OK;
 }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void sr_tr_finalize_kernel(const float* __rest
     if (i >= n) return;
     const long long s0 = src[i];
     if (s0 < 0) {
-        grad[i] = 0.0f;
+        if (s0 == -1) grad[i] = 0.0f;  // -2: this element belongs to another map
         return;
     }
     const int st = stride[i], cnt = ns[i];
@@ -106,6 +106,15 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
     const int srow = tid >> 3, spc = tid & 7;
     const bf16* A = reinterpret_cast<const bf16*>(j.A);
     const bf16* Bm = reinterpret_cast<const bf16*>(j.B);
+    const float* Af = reinterpret_cast<const float*>(j.A);
+    const float* Bf = reinterpret_cast<const float*>(j.B);
+    auto load8 = [](const float* p) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p), v = *reinterpret_cast<const f32x4*>(p + 4);
+        bf16x8 r;
+        r[0] = (bf16)u[0]; r[1] = (bf16)u[1]; r[2] = (bf16)u[2]; r[3] = (bf16)u[3];
+        r[4] = (bf16)v[0]; r[5] = (bf16)v[1]; r[6] = (bf16)v[2]; r[7] = (bf16)v[3];
+        return r;
+    };
     const int dy = j.taps == 9 ? tap / 3 - 1 : 0, dx = j.taps == 9 ? tap % 3 - 1 : 0;
     const int hw = j.H * j.W;
     const bool a_col_ok = n0 + spc * 8 < j.Np, b_col_ok = k0 + spc * 8 < j.Kp;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
         ra = (bf16x8)(0.0f);
         rb = (bf16x8)(0.0f);
         if (t < t_end) {
-            if (a_col_ok) ra = *reinterpret_cast<const bf16x8*>(A + (size_t)t * j.lda + n0 + spc * 8);
+            if (a_col_ok) ra = j.a_f32 ? load8(Af + (size_t)t * j.lda + n0 + spc * 8) : *reinterpret_cast<const bf16x8*>(A + (size_t)t * j.lda + n0 + spc * 8);
             int ts = t;
             bool ok = true;
             if (j.taps == 9) {
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
                 ts = b * hw + ys * j.W + xs;
             }
             if (ok) {
-                if (b_col_ok) rb = *reinterpret_cast<const bf16x8*>(Bm + (size_t)ts * j.ldb + k0 + spc * 8);
+                if (b_col_ok) rb = j.b_f32 ? load8(Bf + (size_t)ts * j.ldb + k0 + spc * 8) : *reinterpret_cast<const bf16x8*>(Bm + (size_t)ts * j.ldb + k0 + spc * 8);
                 if (spc == ones_piece) rb[ones_elem] = (bf16)1.0f;
             }
         }
@@ -185,6 +194,51 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
         }
 }
 
+
+// nn.PixelShuffle(r) backward on NHWC bf16 for a conv whose packed output rows are n = (i r + j) cps + c (common.py:124-137): the gradient of
+// the conv's packed output [B,H,W,r*r*cps] from the gradient of the shuffled tensor [B,H*r,W*r,cps]: 16-byte pieces
+__global__ __launch_bounds__(256) void sr_tr_unshuffle_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int cps, int r) {
+    const int pieces = cps >> 3;
+    const long long total = (long long)B * H * W * r * r * pieces;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int pc = (int)(i % pieces);
+    long long t = i / pieces;
+    const int ij = (int)(t % (r * r));
+    t /= r * r;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const long long b = t / H;
+    const int ii = ij / r, jj = ij - ii * r;
+    const long long s = (((b * H * r + y * r + ii) * (long long)W * r) + x * r + jj) * cps + pc * 8;
+    const long long d = (((b * H + y) * (long long)W + x) * r * r + ij) * cps + pc * 8;
+    *reinterpret_cast<bf16x8*>(dst + d) = *reinterpret_cast<const bf16x8*>(src + s);
+}
+// LeakyReLU backward from the OUTPUT (same sign as the input): dx = dy * (y > 0 ? 1 : slope)
+__global__ __launch_bounds__(256) void sr_tr_lrelu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, float slope, long long n8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dy)[i], v = reinterpret_cast<const bf16x8*>(y)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * ((float)v[e] > 0.f ? 1.0f : slope));
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+}
+// out = a + b (fp32; b fp32 or bf16): the residual joins of the backward pass
+__global__ __launch_bounds__(256) void sr_tr_add_kernel(const float* __restrict__ a, const void* __restrict__ b, int b_bf16, float* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+    if (b_bf16) {
+        const bf16x4 w = reinterpret_cast<const bf16x4*>(b)[i];
+        v[0] += (float)w[0]; v[1] += (float)w[1]; v[2] += (float)w[2]; v[3] += (float)w[3];
+    } else {
+        v += reinterpret_cast<const f32x4*>(b)[i];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
 }  // namespace
 
 extern "C" int sr_tr_gather(const float* P, const int* idx, const int* idx2, const float* scl, const unsigned char* mode, void* out, int out_dtype, long long n,
@@ -218,6 +272,7 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
                    "sr_tr_wgrad: bad job %d", i);
         SR_REQUIRE(j.taps == 1 || (j.H > 0 && j.W > 0 && j.T % (j.H * j.W) == 0), "sr_tr_wgrad: a 3x3 job needs H, W with T = B*H*W");
         SR_REQUIRE((((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0, "sr_tr_wgrad: operands must be 16-byte aligned");
+        SR_REQUIRE((j.a_f32 == 0 || j.a_f32 == 1) && (j.b_f32 == 0 || j.b_f32 == 1), "sr_tr_wgrad: a_f32 / b_f32 are flags");
         J.j[i] = j;
         J.tiles_n[i] = (j.Np + WG_TN - 1) / WG_TN;
         J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
@@ -232,5 +287,27 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
     }
     hipLaunchKernelGGL(sr_tr_wgrad_kernel, dim3(wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), J);
     SR_CHECK_LAUNCH("sr_tr_wgrad");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_unshuffle(const void* src, void* dst, int B, int H, int W, int cps, int r, void* stream) {
+    SR_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && cps > 0 && cps % 8 == 0 && r > 0, "sr_tr_unshuffle: bad arguments");
+    const long long total = (long long)B * H * W * r * r * (cps / 8);
+    hipLaunchKernelGGL(sr_tr_unshuffle_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(src),
+                       reinterpret_cast<bf16*>(dst), B, H, W, cps, r);
+    SR_CHECK_LAUNCH("sr_tr_unshuffle");
+    return SR_OK;
+}
+extern "C" int sr_tr_lrelu_bwd(const void* dy, const void* y, void* dx, float slope, long long n, void* stream) {
+    SR_REQUIRE(dy && y && dx && n > 0 && n % 8 == 0, "sr_tr_lrelu_bwd: bad arguments");
+    hipLaunchKernelGGL(sr_tr_lrelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(dy),
+                       reinterpret_cast<const bf16*>(y), reinterpret_cast<bf16*>(dx), slope, n / 8);
+    SR_CHECK_LAUNCH("sr_tr_lrelu_bwd");
+    return SR_OK;
+}
+extern "C" int sr_tr_add(const float* a, const void* b, int b_dtype, float* out, long long n, void* stream) {
+    SR_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "sr_tr_add: bad arguments");
+    hipLaunchKernelGGL(sr_tr_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, b_dtype == SR_BF16 ? 1 : 0, out, n / 4);
+    SR_CHECK_LAUNCH("sr_tr_add");
     return SR_OK;
 }

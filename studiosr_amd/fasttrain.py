@@ -286,23 +286,47 @@ def pack_qkv_bwd(fp: FlatParams, qkv_w: Tensor) -> IM:
     return _slots(_tr(m.map(lambda a: a.reshape(3 * HEADS * HDP, CP))))
 
 
-def pack_conv(fp: FlatParams, w: Tensor, cin_p: int, cout_p: int, transpose: bool = False) -> IM:
-    """packing.pack_conv3x3 in index form: [cout_p, 9 * cin_p] with k = tap * cin_p + c.  transpose = True: the data-gradient convolution
-    (input = the forward's output channels, taps flipped): W'[ci][tap'][co] = W[co][ci][8 - tap']."""
+def pack_conv(fp: FlatParams, w: Tensor, cin_p: int, cout_p: int, transpose: bool = False, rows: Optional[np.ndarray] = None) -> IM:
+    """packing.pack_conv3x3 in index form: [cout_p, 9 * cin_p] with k = tap * cin_p + c; packed row n takes output channel rows[n] (-1 = zero
+    row; None = identity -- a conv feeding nn.PixelShuffle uses packing.pixel_shuffle_rows).  transpose = True: the data-gradient convolution
+    (its input = the forward's packed output rows, taps flipped): W'[ci][tap'][n] = W[rows[n]][ci][8 - tap']; then cout_p / cin_p are the
+    DGRAD's output / input widths."""
     cout, cin = w.shape[:2]
     pi = fp.pidx(w).reshape(cout, cin, 9)
+    n_rows = cin_p if transpose else cout_p  # packed forward output rows
+    if rows is None:
+        rows = np.full(n_rows, -1, dtype=np.int64)
+        rows[:cout] = np.arange(cout)
+    rows = np.asarray(rows, dtype=np.int64)
+    assert rows.shape[0] == n_rows
+    ok = rows >= 0
+    src = pi[np.clip(rows, 0, None)]  # [n_rows, cin, 9]
     if transpose:
-        m = IM((cout_p, 9, cin_p))  # here cout_p / cin_p are the DGRAD's output / input widths: rows = forward ci, columns = forward co
-        m.put((slice(0, cin), slice(None), slice(0, cout)), pi[:, :, ::-1].transpose(1, 2, 0))
+        m = IM((cout_p, 9, cin_p))  # rows = forward ci, columns = forward packed rows
+        sub = IM((cin, 9, n_rows))
+        sub.put(slice(None), src[:, :, ::-1].transpose(1, 2, 0))
+        sub.idx[:, :, ~ok] = -1
+        sub.scl[:, :, ~ok] = 0.0
+        m.idx[:cin], m.scl[:cin], m.mode[:cin] = sub.idx, sub.scl, sub.mode
     else:
         m = IM((cout_p, 9, cin_p))
-        m.put((slice(0, cout), slice(None), slice(0, cin)), pi.transpose(0, 2, 1))
+        sub = IM((n_rows, 9, cin))
+        sub.put(slice(None), src.transpose(0, 2, 1))
+        sub.idx[~ok] = -1
+        sub.scl[~ok] = 0.0
+        m.idx[:, :, :cin], m.scl[:, :, :cin], m.mode[:, :, :cin] = sub.idx, sub.scl, sub.mode
     return _fragments(m.map(lambda a: a.reshape(a.shape[0], -1)))
 
 
-def pack_vec(fp: FlatParams, v: Tensor, n_p: int) -> IM:
+def pack_vec(fp: FlatParams, v: Tensor, n_p: int, rows: Optional[np.ndarray] = None) -> IM:
     m = IM((n_p,))
-    m.put(slice(0, v.numel()), fp.pidx(v).reshape(-1))
+    if rows is None:
+        m.put(slice(0, v.numel()), fp.pidx(v).reshape(-1))
+    else:
+        rows = np.asarray(rows, dtype=np.int64)
+        ok = rows >= 0
+        m.idx[ok] = fp.pidx(v).reshape(-1)[rows[ok]]
+        m.scl[ok] = 1.0
     return m
 
 
@@ -636,6 +660,88 @@ def run_stage(stage: Stage, x: Tensor, scales: Optional[Tensor]) -> Tensor:
     return _StageFn.apply(x, stage, scales, *stage.params)
 
 
+
+# --------------------------------------------------------------------------- 3x3 convolutions outside the blocks
+class ConvPlan:
+    """One nn.Conv2d(3x3) of the model (common.py:104-105): packed forward weights, packed data-gradient weights (flipped / transposed),
+    padded bias, and the gradient map of its weight-gradient GEMM (sr_tr_wgrad, 9 taps).  rows: packed output row -> output channel (the
+    PixelShuffle permutation of packing.pixel_shuffle_rows)."""
+
+    def __init__(self, fp: FlatParams, conv, cin_p: int, cout_p: int, wa: Arena, fa: Arena, fm: FinalMap, rows: Optional[np.ndarray] = None, dgrad: bool = True,
+                 dgrad_in_p: Optional[int] = None) -> None:
+        w, b = conv.weight, conv.bias
+        cout, cin = w.shape[:2]
+        self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
+        if rows is None:
+            rows = np.full(cout_p, -1, dtype=np.int64)
+            rows[:cout] = np.arange(cout)
+        rows = np.asarray(rows, dtype=np.int64)
+        self.o_w = wa.add(pack_conv(fp, w, cin_p, cout_p, rows=rows))
+        self.dg_in = dgrad_in_p or cout_p
+        if dgrad:
+            r2 = np.full(self.dg_in, -1, dtype=np.int64)
+            r2[:cout_p] = rows
+            self.o_wt = wa.add(pack_conv(fp, w, self.dg_in, cin_p, transpose=True, rows=r2))
+        self.o_b = fa.add(pack_vec(fp, b, cout_p, rows))
+        ks = WG_KS
+        n_of = np.zeros(cout, dtype=np.int64)
+        n_of[rows[rows >= 0]] = np.nonzero(rows >= 0)[0]
+        self.f_w = fm.alloc(ks * 9 * cout_p * cin_p)
+        tp = np.arange(9)[None, None, :]
+        fm.put(fp.pidx(w).reshape(cout, cin, 9), self.f_w + (tp * cout_p + n_of[:, None, None]) * cin_p + np.arange(cin)[None, :, None], 9 * cout_p * cin_p, ks)
+        if cin < cin_p:  # the input's first pad channel reads as one: the bias gradient is that column of the centre tap
+            self.ones_col, self.f_b = cin, None
+            fm.put(fp.pidx(b), self.f_w + (4 * cout_p + n_of) * cin_p + cin, 9 * cout_p * cin_p, ks)
+        else:            # no spare input channel: a second job against a constant-one operand
+            self.ones_col, self.f_b = -1, fm.alloc(ks * cout_p * 8)
+            fm.put(fp.pidx(b), self.f_b + n_of * 8, cout_p * 8, ks)
+
+    def fwd(self, plan, x: Tensor, out: Tensor, B: int, H: int, W: int, *, act: int = L.ACT_NONE, skip: Optional[Tensor] = None, out_mode: int = L.OUT_NHWC, ps_r: int = 0,
+            cps_p: int = 0, fin=None) -> None:
+        kw = dict(x=x.data_ptr(), Wp=plan.wa.buf[self.o_w:].data_ptr(), bias=plan.fa.buf[self.o_b:].data_ptr(), out=out.data_ptr(), skip=None if skip is None else skip.data_ptr(),
+                  pool_partial=None, B=B, H=H, W=W, Cin_p=self.cin_p, Cout_p=self.cout_p, x_dtype=ops._dt(x), out_dtype=ops._dt(out), skip_dtype=0 if skip is None else ops._dt(skip),
+                  compute_dtype=L.SR_BF16, act=act, out_scale=1.0, out_mode=out_mode, ps_r=ps_r, cps_p=cps_p, act_slope=0.0, tile_rows=0)
+        if fin is not None:
+            fs, fb, fc, fh, fw = fin
+            kw.update(fin_scale=fs.data_ptr(), fin_bias=fb.data_ptr(), fin_c=fc, fin_h=fh, fin_w=fw)
+        ops.conv3x3(**kw)
+
+    def dgrad(self, plan, dy: Tensor, dx: Tensor, B: int, H: int, W: int) -> None:
+        ops.conv3x3(x=dy.data_ptr(), Wp=plan.wa.buf[self.o_wt:].data_ptr(), bias=None, out=dx.data_ptr(), skip=None, pool_partial=None, B=B, H=H, W=W, Cin_p=self.dg_in,
+                    Cout_p=self.cin_p, x_dtype=ops._dt(dy), out_dtype=ops._dt(dx), skip_dtype=0, compute_dtype=L.SR_BF16, act=L.ACT_NONE, out_scale=1.0, out_mode=L.OUT_NHWC,
+                    ps_r=0, cps_p=0, act_slope=0.0, tile_rows=0)
+
+    def wgrad_jobs(self, plan, dy: Tensor, lda: int, x: Tensor, B: int, H: int, W: int) -> List[dict]:
+        pp = lambda off: plan.fm.part.data_ptr() + 4 * off  # noqa: E731
+        T = B * H * W
+        f32 = torch.float32
+        jobs = [dict(A=dy.data_ptr(), B=x.data_ptr(), out=pp(self.f_w), lda=lda, ldb=self.cin_p, Np=self.cout_p, Kp=self.cin_p, T=T, taps=9, H=H, W=W, ones_col=self.ones_col,
+                     ks=WG_KS, a_f32=int(dy.dtype == f32), b_f32=int(x.dtype == f32))]
+        if self.f_b is not None:
+            jobs.append(dict(A=dy.data_ptr(), B=plan.ones.data_ptr(), out=pp(self.f_b), lda=lda, ldb=8, Np=self.cout_p, Kp=8, T=T, taps=1, H=H, W=W, ones_col=-1, ks=WG_KS,
+                             a_f32=int(dy.dtype == f32), b_f32=0))
+        return jobs
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        plan.gen += 1
+        ctx.plan, ctx.gen = plan, plan.gen
+        return plan.forward_model(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        if plan.gen != ctx.gen:
+            raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
+        plan.backward_model(dout)
+        return (None, None) + tuple(plan.fp.grad_view(p) for p in plan.fp.params)
+
+
+def run_model(plan: "HatPlan", x: Tensor) -> Tensor:
+    return _ModelFn.apply(x, plan, *plan.fp.params)
+
 # --------------------------------------------------------------------------- whole-model plan
 class HatPlan:
     """Fast-path plan of a HAT model: FlatParams, the two arenas, one Stage per RHAG (its six HABs)."""
@@ -649,12 +755,36 @@ class HatPlan:
         self.with_oca = with_oca
         self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
                              model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa) for layer in model.layers]
+        self.full = with_oca and os.environ.get("SR_FAST_FULL", "1") != "0"  # the whole model as ONE autograd node (forward_model / backward_model)
+        # ---- everything outside the blocks (hat.py:519-554): conv_first, patch_embed.norm, the RHAG convs, norm, conv_after_body, the upsampling tail
+        from . import packing
+        from .models.swinir import final_affine, ingest_affine
+
+        m = model
+        self.fm = FinalMap(self.fp, 0, self.fp.n)
+        self.fm.src[:] = -2  # the stages' maps own the block parameters
+        fm = self.fm
+        self.c_first = ConvPlan(self.fp, m.conv_first, 32, CP, self.wa, self.fa, fm, dgrad=False)
+        self.c_layers = [ConvPlan(self.fp, layer.conv, CP, CP, self.wa, self.fa, fm) for layer in m.layers]
+        self.c_after = ConvPlan(self.fp, m.conv_after_body, CP, CP, self.wa, self.fa, fm)
+        self.c_before = ConvPlan(self.fp, m.conv_before_upsample[0], CP, 64, self.wa, self.fa, fm)
+        self.c_up = []
+        for idx, r, c_ps in m.upsample.stages:
+            cps_p = packing.round_up(c_ps, 32)
+            rows = packing.pixel_shuffle_rows(c_ps, cps_p, r).numpy()
+            self.c_up.append((ConvPlan(self.fp, m.upsample[idx], 64, r * r * cps_p, self.wa, self.fa, fm, rows=rows), r, cps_p))
+        self.c_last = ConvPlan(self.fp, m.conv_last, 64, 16, self.wa, self.fa, fm, dgrad_in_p=32)
+        self.o_pe = (self.fa.add(pack_vec(self.fp, m.patch_embed.norm.weight, CP)), self.fa.add(pack_vec(self.fp, m.patch_embed.norm.bias, CP)))
+        self.o_nm = (self.fa.add(pack_vec(self.fp, m.norm.weight, CP)), self.fa.add(pack_vec(self.fp, m.norm.bias, CP)))
+        self.fin = final_affine(m.img_range, m.n_colors, dev)
+        self.ing = ingest_affine(m.img_range, m.n_colors, dev)
+        self.zero3 = torch.zeros(m.n_colors, dtype=torch.float32, device=dev)
         self.wa.finish(dev)
         self.fa.finish(dev)
         self.scratch = None
         self.geo = None
         self.packed_version = None
-
+        self.gen = 0
     @staticmethod
     def supported(model) -> bool:
         try:
@@ -669,6 +799,7 @@ class HatPlan:
             return
         assert self.geo is None, "one geometry per fast-training plan"
         dev = self.fp.P.device
+        fp, fm, m = self.fp, self.fm, self.model
         nbw = B * H * W // 256
         groups = max(1, min(nbw, 16))
         while nbw % groups:
@@ -676,7 +807,124 @@ class HatPlan:
         self.scratch = Scratch(B, H, W, dev, groups)
         for s in self.stages:
             s.prepare(B, H, W, dev, self.scratch)
+        # LayerNorm partials of patch_embed.norm / norm
+        nwg = B * H * W // 64
+        self.f_pe, self.f_nm = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
+        for f, norm in ((self.f_pe, m.patch_embed.norm), (self.f_nm, m.norm)):
+            fm.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
+            fm.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
+        fm.finish(dev)
+        T = B * H * W
+        bf, f32 = torch.bfloat16, torch.float32
+        e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        self.xin = e(B, H, W, 32)
+        self.first, self.t0 = e(B, H, W, CP, dt=f32), e(B, H, W, CP, dt=f32)
+        self.tl = [e(B, H, W, CP, dt=f32) for _ in self.stages]
+        self.tn, self.body, self.feat = e(B, H, W, CP), e(B, H, W, CP), e(B, H, W, 64)
+        self.ups = []
+        h, w = H, W
+        for _, r, cps_p in self.c_up:
+            h, w = h * r, w * r
+            self.ups.append(e(B, h, w, cps_p))
+        self.hw_out = (h, w)
+        T2 = B * h * w
+        self.ones = torch.ones(T2, 8, dtype=bf, device=dev)
+        # backward scratch of the tail
+        self.dY, self.dupA, self.dupB = e(B, h, w, 32), e(T2 * 64), e(T2 * 64)
+        self.dps = e(T2 * 64)  # un-shuffled gradient: [B, h / r, w / r, r * r * 64] has the same element count as the shuffled tensor
+        self.dpre, self.dbody = e(B, H, W, 64), e(B, H, W, CP)
+        self.dtn, self.dtA, self.dtB, self.dcv = (e(B, H, W, CP, dt=f32) for _ in range(4))
         self.geo = (B, H, W)
+
+    # ------------------------------------------------------------------ whole-model launch sequences (hat.py:519-554)
+    def forward_model(self, x: Tensor) -> Tensor:
+        from .models.train import _drop_rates
+
+        m = self.model
+        B, H, W = self.geo
+        Hin, Win = x.shape[2], x.shape[3]
+        s = m.scale
+        fa = self.fa.buf
+        ops.ingest_nchw(x, self.xin, L.PAD_REFLECT if (H != Hin or W != Win) else L.PAD_NONE, *self.ing)
+        self.c_first.fwd(self, self.xin, self.first, B, H, W)
+        ops.layernorm(self.first, self.t0, fa[self.o_pe[0]:self.o_pe[0] + CP], fa[self.o_pe[1]:self.o_pe[1] + CP], C_REAL)
+        self.scales = None
+        dpr = _drop_rates(m)
+        if m.training and any(r > 0.0 for r in dpr):  # DropPath (hat.py:148,192-193): per block, per branch, per image Bernoulli(keep) / keep
+            if getattr(self, "_keep", None) is None:
+                nb = len(self.stages[0].blocks) - int(self.with_oca)
+                self._keep = (1.0 - torch.tensor(dpr, dtype=torch.float32, device=x.device)).reshape(len(self.stages), nb, 1, 1)
+            self.scales = ((torch.rand(self._keep.shape[0], self._keep.shape[1], 2, B, device=x.device) < self._keep).to(torch.float32) / self._keep).contiguous()
+        cur = self.t0
+        for li, st in enumerate(self.stages):
+            st.gen += 1
+            o = st.forward(cur, None if self.scales is None else self.scales[li])
+            self.c_layers[li].fwd(self, o, self.tl[li], B, H, W, skip=cur)
+            cur = self.tl[li]
+        ops.layernorm(cur, self.tn, fa[self.o_nm[0]:self.o_nm[0] + CP], fa[self.o_nm[1]:self.o_nm[1] + CP], C_REAL)
+        self.c_after.fwd(self, self.tn, self.body, B, H, W, skip=self.first)
+        self.c_before.fwd(self, self.body, self.feat, B, H, W, act=L.ACT_LRELU)
+        t, h, w = self.feat, H, W
+        for (cp, r, cps_p), up in zip(self.c_up, self.ups):
+            cp.fwd(self, t, up, B, h, w, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=r, cps_p=cps_p)
+            t, h, w = up, h * r, w * r
+        out = torch.empty(B, m.n_colors, Hin * s, Win * s, dtype=torch.float32, device=x.device)
+        self.c_last.fwd(self, t, out, B, h, w, out_mode=L.OUT_FINAL_NCHW, fin=(*self.fin, m.n_colors, Hin * s, Win * s))
+        return out
+
+    def backward_model(self, dout: Tensor) -> None:
+        m = self.model
+        B, H, W = self.geo
+        lib = L.lib()
+        fa = self.fa.buf
+        h, w = self.hw_out
+        T = B * H * W
+        dout = dout.contiguous().to(torch.float32)
+        # d(conv_last output) = dout * range, NHWC, zero beyond the cropped size and in the pad channels
+        ops.ingest_nchw(dout, self.dY, L.PAD_NONE, self.fin[0], self.zero3)
+        jobs = self.c_last.wgrad_jobs(self, self.dY, 32, self.ups[-1] if self.ups else self.feat, B, h, w)
+        d_cur = self.dupA[: B * h * w * 64].view(B, h, w, 64)
+        self.c_last.dgrad(self, self.dY, d_cur, B, h, w)
+        _wgrad(jobs)
+        other = self.dupB
+        for si in range(len(self.c_up) - 1, -1, -1):
+            cp, r, cps_p = self.c_up[si]
+            hi, wi = h // r, w // r
+            dps = self.dps[: B * hi * wi * r * r * cps_p].view(B, hi, wi, r * r * cps_p)
+            L.check(lib.sr_tr_unshuffle(d_cur.data_ptr(), dps.data_ptr(), B, hi, wi, cps_p, r, _st()), "sr_tr_unshuffle")
+            xin = self.ups[si - 1] if si > 0 else self.feat
+            jobs = cp.wgrad_jobs(self, dps, r * r * cps_p, xin, B, hi, wi)
+            d_prev = other[: B * hi * wi * 64].view(B, hi, wi, 64)
+            cp.dgrad(self, dps, d_prev, B, hi, wi)
+            _wgrad(jobs)
+            other = self.dupA if other is self.dupB else self.dupB
+            d_cur, h, w = d_prev, hi, wi
+        L.check(lib.sr_tr_lrelu_bwd(d_cur.data_ptr(), self.feat.data_ptr(), self.dpre.data_ptr(), 0.01, T * 64, _st()), "sr_tr_lrelu_bwd")
+        jobs = self.c_before.wgrad_jobs(self, self.dpre, 64, self.body, B, H, W)
+        self.c_before.dgrad(self, self.dpre, self.dbody, B, H, W)
+        jobs += self.c_after.wgrad_jobs(self, self.dbody, CP, self.tn, B, H, W)
+        self.c_after.dgrad(self, self.dbody, self.dtn, B, H, W)
+        _wgrad(jobs)
+        pp = lambda off: self.fm.part.data_ptr() + 4 * off  # noqa: E731
+        dt = self.dtA
+        last = self.tl[-1] if self.tl else self.t0
+        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=last.data_ptr(), dy=self.dtn.data_ptr(), gamma=fa[self.o_nm[0]:].data_ptr(), dskip=None, dx=dt.data_ptr(),
+              ln_part=pp(self.f_nm), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=0, eps=1e-5)
+        for li in range(len(self.stages) - 1, -1, -1):
+            st = self.stages[li]
+            cur_in = self.t0 if li == 0 else self.tl[li - 1]
+            jobs = self.c_layers[li].wgrad_jobs(self, dt, CP, st.ts[-1], B, H, W)
+            self.c_layers[li].dgrad(self, dt, self.dcv, B, H, W)
+            _wgrad(jobs)
+            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li])
+            nxt = self.dtB if dt is self.dtA else self.dtA
+            L.check(lib.sr_tr_add(dx.data_ptr(), dt.data_ptr(), L.SR_F32, nxt.data_ptr(), T * CP, _st()), "sr_tr_add")
+            dt = nxt
+        dfirst = self.dtn  # (free again)
+        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=self.first.data_ptr(), dy=dt.data_ptr(), gamma=fa[self.o_pe[0]:].data_ptr(), dskip=self.dbody.data_ptr(),
+              dx=dfirst.data_ptr(), ln_part=pp(self.f_pe), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=1, eps=1e-5)
+        _wgrad(self.c_first.wgrad_jobs(self, dfirst, CP, self.xin, B, H, W))
+        self.fm.run(self.fp.G)
 
     def pack(self) -> None:
         """Packed operands <- current parameters (once per optimizer step: the parameter versions decide)."""

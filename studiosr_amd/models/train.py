@@ -194,11 +194,15 @@ def hat_forward(model, x: Tensor) -> Tensor:
     if Hp - H >= H or Wp - W >= W:
         raise RuntimeError("Padding size should be less than the corresponding input dimension (reflect pad)")
     ing, fin = _affines(model.img_range, model.n_colors, x.device)
+    plan = _fast_plan(model, B, Hp, Wp)
+    if plan is not None and plan.full:  # the whole step as fused launches behind one autograd node
+        from .. import fasttrain
+
+        return fasttrain.run_model(plan, x)
     first = _conv(_ingest(x, Hp, Wp, L.PAD_REFLECT if (Hp != H or Wp != W) else L.PAD_NONE, *ing), model.conv_first, cin=model.n_colors)
     t = A.layer_norm(first, model.patch_embed.norm.weight, model.patch_embed.norm.bias)
     dpr = _drop_rates(model)
     rpi_sa, rpi_oca = model.relative_position_index_SA, model.relative_position_index_OCA
-    plan = _fast_plan(model, B, Hp, Wp)
     k = 0
     for li, layer in enumerate(model.layers):
         tin = t
