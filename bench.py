@@ -309,7 +309,7 @@ def run_train(args, device, rank, world) -> None:
     torch.manual_seed(0)
     model = S.HAT(scale=4).to(device).train()
     cfg = model.get_training_config()
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.get("learning_rate", 2e-4), betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.99)))
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.get("learning_rate", 2e-4), betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.99)), fused=True)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.get("milestones", [250000]), gamma=cfg.get("gamma", 0.5))
     net = DDP(model, device_ids=[device.index], output_device=device.index) if world > 1 else model
     per_rank = 4

@@ -496,19 +496,20 @@ typedef struct SrTrAttnBwd {
     /* Backward of softmax(q k^T + bias + shift mask) v per (window, head), flash form (swinir.py:83-102, hat.py:90-107, 266-283): P is
      * recomputed from q, k, bias.  bf16 operands; q is pre-scaled.  Layouts: q, k, v, dq, dk, dv [bwin][head][N][32]; qT, kT, dOT
      * [bwin][head][32][N]; o, dO rows [bwin * Nq + tok][ldo] with head h at column 32 h; bias [heads][Nq][Nk], biasT [heads][Nk][Nq] fp32;
-     * lse, delta [bwin][head][Nq] fp32 (written, then read by the second pass); dbias_part [groups][heads][Nq][Nk] fp32 = sum of dS over the
-     * windows of each group (deterministic, no atomics). */
+     * lse, delta [bwin][head][Nq] fp32 (written, then read by the second pass).  The relative_position_bias_table gradient leaves as
+     * dtab_part [heads * groups * Nq / 64][Tpad] fp32: workgroup (head, group, 64 queries) sums dS over the group's windows and folds it through
+     * rpi [Nq * Nk] (int32, negative entries wrap by T rows) into one table-sized partial; dtable[t][h] = sum of head h's groups * Nq / 64
+     * consecutive partials (sr_tr_finalize). */
     const void* q; const void* qT; const void* k; const void* kT; const void* v;
     const void* o; const void* dO; const void* dOT;
     const float* bias; const float* biasT;
     void* dq; void* dk; void* dv;
-    float* lse; float* delta; float* dbias_part;
-    int n_bwin, heads, hd_p, Nq, Nk, ldo, groups;
+    float* lse; float* delta; float* dtab_part; const int* rpi;
+    int n_bwin, heads, hd_p, Nq, Nk, ldo, groups, T, Tpad;
+    int toeplitz16;        /* 1: rpi is the 16 x 16 self-attention index (yq - yk + 15) * 31 + (xq - xk + 15) (hat.py:480-492): the fold runs on lane rotations */
     int H, W, ws, shift;   /* mask geometry (shift == 0: no mask) */
 } SrTrAttnBwd;
 int sr_tr_attn_bwd(const SrTrAttnBwd* a, void* stream);
-/* relative_position_bias_table gradient: dtable[rpi[ij] (negative wraps)][h] += sum_g dbias_part[g][h][ij]  (dtable zeroed by the caller). */
-int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream);
 
 typedef struct SrTrAttnFwd {
     /* Training forward of HAT's overlapping cross attention core (hat.py:266-283) on the UNFOLDED keys / values: out rows

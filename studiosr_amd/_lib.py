@@ -161,8 +161,8 @@ class SrTrWgradJob(C.Structure):
 class SrTrAttnBwd(C.Structure):
     _fields_ = [
         ("q", _vp), ("qT", _vp), ("k", _vp), ("kT", _vp), ("v", _vp), ("o", _vp), ("dO", _vp), ("dOT", _vp), ("bias", _vp), ("biasT", _vp),
-        ("dq", _vp), ("dk", _vp), ("dv", _vp), ("lse", _vp), ("delta", _vp), ("dbias_part", _vp),
-        ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i), ("groups", _i), ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
+        ("dq", _vp), ("dk", _vp), ("dv", _vp), ("lse", _vp), ("delta", _vp), ("dtab_part", _vp), ("rpi", _vp),
+        ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i), ("groups", _i), ("T", _i), ("Tpad", _i), ("toeplitz16", _i), ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
     ]
 
 
@@ -284,7 +284,6 @@ SYMBOLS = {
     "sr_tr_wgrad": (_i, [C.POINTER(SrTrWgradJob), _i, _vp]),
     "sr_tr_wgrad_out_floats": (_ll, [C.POINTER(SrTrWgradJob)]),
     "sr_tr_attn_bwd": (_i, [C.POINTER(SrTrAttnBwd), _vp]),
-    "sr_tr_dbias": (_i, [_vp, _i, _vp, _vp, _i, _i, _ll, _vp]),
     "sr_tr_attn_fwd": (_i, [C.POINTER(SrTrAttnFwd), _vp]),
     "sr_tr_oca_fold": (_i, [C.POINTER(SrTrOcaFold), _i, _vp]),
     "sr_tr_block_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -13,6 +13,7 @@
 //   bias [heads][Nq][Nk] fp32, biasT [heads][Nk][Nq] fp32;  lse, delta [bwin][head][Nq] fp32;  dbias partial [groups][heads][Nq][Nk] fp32.
 #include "sr_common.h"
 #include "sr_host.h"
+#include <cstdlib>
 
 namespace {
 
@@ -38,7 +39,7 @@ struct Geo {
 };
 
 // ---- pass Q.  KT = key tiles; Nq = 16 * QT_ALL query rows per (window, head)
-template <int KT>
+template <int KT, int VAR>
 __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(SrTrAttnBwd a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -46,10 +47,10 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
     const int qtiles = a.Nq >> 4;
     const int item = blockIdx.x * 4 + wave;
     const int n_items = a.groups * a.heads * qtiles;
-    if (item >= n_items) return;  // wave-uniform; no barriers
+    if (item >= n_items) return;  // never taken: the launcher requires Nq / 16 to be a multiple of 4 (the table reduction below has barriers)
     const int qt = item % qtiles;
     const int gh = item / qtiles;
-    const int head = gh % a.heads, grp = gh / a.heads;
+    const int grp = gh % a.groups, head = gh / a.groups;  // head-major: the 4 waves of a workgroup share (head, group); a head's workgroups are consecutive
     const int lr = lane & 15, lg = lane >> 4;
     const int wpg = (a.n_bwin + a.groups - 1) / a.groups;
     const int qi = qt * 16 + lr;
@@ -153,88 +154,152 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         store4(dqp, dq[0]);
         store4(dqp + 16, dq[1]);
     }
-    float* dbp = a.dbias_part + (((size_t)grp * a.heads + head) * a.Nq + qi) * NK;
+    // relative_position_bias_table gradient of this workgroup: dS summed over (windows of the group, its 64 queries) and folded through the
+    // position index into one table-sized partial (LDS atomics: ~2 k adds per wave, once per launch) -- no [Nq][Nk] gradient ever reaches HBM
+    __shared__ float tab[1536];
+    for (int i = threadIdx.x; i < 1536; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int* rp = a.rpi + (size_t)qi * NK;
+    if (VAR == 1) {
+        // 16 x 16 self-attention windows: table row = (yq - yk + 15) * 31 + (xq - xk + 15) (hat.py:480-492) and a 16-key tile is one window row, so the
+        // fold is a sum along the diagonals of each 16 x 16 accumulator tile: rotate every key column so that lane = (xq - xk) mod 16 (one
+        // ds_bpermute, no conflicts), split wrapped / unwrapped, reduce over the four lane groups, and add 31 DISTINCT table entries per tile
+        // (the index-map form below makes up to 4 lanes of an instruction hit one address: 37 us of a 100-us launch)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f32x4*>(dbp + kt * 16 + lg * 4) = dbacc[kt];
+        for (int kt = 0; kt < KT; ++kt) {
+            float pos = 0.f, neg = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xk = 4 * lg + r;
+                const float w = __shfl(dbacc[kt][r], (lane & 48) | ((lr + xk) & 15), 64);
+                const bool p = lr + xk <= 15;
+                pos += p ? w : 0.f;
+                neg += p ? 0.f : w;
+            }
+            pos = wave_sum_xor(pos, 16);
+            pos = wave_sum_xor(pos, 32);
+            neg = wave_sum_xor(neg, 16);
+            neg = wave_sum_xor(neg, 32);
+            if (lg == 0) {
+                const int row = (qt - kt + 15) * 31 + 15;
+                atomicAdd(&tab[row + lr], pos);
+                if (lr >= 1) atomicAdd(&tab[row + lr - 16], neg);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int4 t4 = *reinterpret_cast<const int4*>(rp + kt * 16 + lg * 4);
+            const int tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
+        }
+    }
+    __syncthreads();
+    float* dst = a.dtab_part + (size_t)blockIdx.x * a.Tpad;
+    for (int i = threadIdx.x; i < a.T; i += 256) dst[i] = tab[i];
 }
 
-// ---- pass KV.  QT = query tiles (Nq / 16, even)
-template <int QT>
+// ---- pass KV.  QT = query tiles (Nq / 16, even); every wave owns KPW consecutive key tiles, so each query-side fragment is loaded once per KPW tiles
+template <int QT, int KPW>
 __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int NQ = QT * 16;
-    const int ktiles = a.Nk >> 4;
+    const int kgroups = (a.Nk >> 4) / KPW;
     const int item = blockIdx.x * 4 + wave;
-    const int n_items = a.n_bwin * a.heads * ktiles;
+    const int n_items = a.n_bwin * a.heads * kgroups;
     if (item >= n_items) return;
-    const int kt = item % ktiles;
-    const size_t bh = item / ktiles;
+    const int kg = item % kgroups;
+    const size_t bh = item / kgroups;
     const int head = (int)(bh % a.heads), bwin = (int)(bh / a.heads);
     const int lr = lane & 15, lg = lane >> 4;
-    const int ki = kt * 16 + lr;
 
     const bf16* q = reinterpret_cast<const bf16*>(a.q) + bh * NQ * 32;
     const bf16* qT = reinterpret_cast<const bf16*>(a.qT) + bh * NQ * 32;
     const bf16* dOT = reinterpret_cast<const bf16*>(a.dOT) + bh * NQ * 32;
-    const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.k) + (bh * a.Nk + ki) * 32 + lg * 8);
-    const Frag<bf16> vf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.v) + (bh * a.Nk + ki) * 32 + lg * 8);
-    const float* biasT = a.biasT + ((size_t)head * a.Nk + ki) * NQ;
     const float* lse = a.lse + bh * NQ;
     const float* delta = a.delta + bh * NQ;
-
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
     const int win = bwin % (nwx * nwy);
     const int wy = win / nwx, wx = win - wy * nwx;
     const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
-    const int krow = region(wy * 16 + (ki >> 4), a.H, 16, a.shift), kcol = region(wx * 16 + (ki & 15), a.W, 16, a.shift);
-    bool cdiff[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != kcol;
 
-    f32x4 dk[2] = {(f32x4)(0.0f), (f32x4)(0.0f)}, dv[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+    Frag<bf16> kf[KPW], vf[KPW];
+    const float* biasT[KPW];
+    int krow[KPW];
+    bool cdiff[KPW][4];
+    f32x4 dk[KPW][2], dv[KPW][2];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) {
+        const int ki = (kg * KPW + u) * 16 + lr;
+        kf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.k) + (bh * a.Nk + ki) * 32 + lg * 8);
+        vf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.v) + (bh * a.Nk + ki) * 32 + lg * 8);
+        biasT[u] = a.biasT + ((size_t)head * a.Nk + ki) * NQ;
+        krow[u] = region(wy * 16 + (ki >> 4), a.H, 16, a.shift);
+        const int kcol = region(wx * 16 + (ki & 15), a.W, 16, a.shift);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cdiff[u][r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != kcol;
+        dk[u][0] = dk[u][1] = dv[u][0] = dv[u][1] = (f32x4)(0.0f);
+    }
 #pragma unroll 2
     for (int qs = 0; qs < QT / 2; ++qs) {
-        f32x4 p[2], ds[2];
+        f32x4 p[KPW][2], ds[KPW][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int qt = 2 * qs + h;
             const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(q + (size_t)(qt * 16 + lr) * 32 + lg * 8);
             const size_t orow = ((size_t)bwin * NQ + qt * 16 + lr) * a.ldo + head * 32 + lg * 8;
             const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
-            f32x4 s = mma_z(qf, kf);        // S[query 16 qt + 4 lg + r][key lr]
-            const f32x4 dp = mma_z(dof, vf);  // dP, same layout
             const int q0 = qt * 16 + lg * 4;
-            s += *reinterpret_cast<const f32x4*>(biasT + q0);
-            if (masked) {
-                const bool rdiff = region(wy * 16 + qt, a.H, 16, a.shift) != krow;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rdiff || cdiff[r]) s[r] += -100.0f;
-            }
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + q0), d4 = *reinterpret_cast<const f32x4*>(delta + q0);
+            const int qrow = region(wy * 16 + qt, a.H, 16, a.shift);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[h][r] = __expf(s[r] - l4[r]);
-                ds[h][r] = p[h][r] * (dp[r] - d4[r]);
+            for (int u = 0; u < KPW; ++u) {
+                f32x4 s = mma_z(qf, kf[u]);          // S[query 16 qt + 4 lg + r][key lr]
+                const f32x4 dp = mma_z(dof, vf[u]);  // dP, same layout
+                s += *reinterpret_cast<const f32x4*>(biasT[u] + q0);
+                if (masked) {
+                    const bool rdiff = qrow != krow[u];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rdiff || cdiff[u][r]) s[r] += -100.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[u][h][r] = __expf(s[r] - l4[r]);
+                    ds[u][h][r] = p[u][h][r] * (dp[r] - d4[r]);
+                }
             }
         }
-        const Frag<bf16> pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);  // row = key lr, k = queries 32 qs + 4 lg + r | + 16
+        Frag<bf16> dotf[2], qtf[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const size_t off = (size_t)(dt * 16 + lr) * NQ + qs * 32 + lg * 4;
-            mma(load_2x4(dOT + off, dOT + off + 16), pf, dv[dt]);  // C[d = 16 dt + 4 lg + r][key lr]
-            mma(load_2x4(qT + off, qT + off + 16), dsf, dk[dt]);
+            dotf[dt] = load_2x4(dOT + off, dOT + off + 16);
+            qtf[dt] = load_2x4(qT + off, qT + off + 16);
+        }
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            const Frag<bf16> pf = pack_p(p[u][0], p[u][1]), dsf = pack_p(ds[u][0], ds[u][1]);  // row = key lr, k = queries 32 qs + 4 lg + r | + 16
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                mma(dotf[dt], pf, dv[u][dt]);  // C[d = 16 dt + 4 lg + r][key lr]
+                mma(qtf[dt], dsf, dk[u][dt]);
+            }
         }
     }
-    bf16* dkp = reinterpret_cast<bf16*>(a.dk) + (bh * a.Nk + ki) * 32 + lg * 4;
-    bf16* dvp = reinterpret_cast<bf16*>(a.dv) + (bh * a.Nk + ki) * 32 + lg * 4;
-    store4(dkp, dk[0]);
-    store4(dkp + 16, dk[1]);
-    store4(dvp, dv[0]);
-    store4(dvp + 16, dv[1]);
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) {
+        const int ki = (kg * KPW + u) * 16 + lr;
+        bf16* dkp = reinterpret_cast<bf16*>(a.dk) + (bh * a.Nk + ki) * 32 + lg * 4;
+        bf16* dvp = reinterpret_cast<bf16*>(a.dv) + (bh * a.Nk + ki) * 32 + lg * 4;
+        store4(dkp, dk[u][0]);
+        store4(dkp + 16, dk[u][1]);
+        store4(dvp, dv[u][0]);
+        store4(dvp + 16, dv[u][1]);
+    }
 }
-
 
 // ---- overlapping cross attention (hat.py:239-293), training forward: softmax(q k^T + bias) v with Nk = 16 KT keys per window from the unfolded
 //      neighbourhood (sr_tr_oca_unfold); one wave = (window, head, 16 queries), everything in registers as in pass Q
@@ -372,19 +437,6 @@ __global__ __launch_bounds__(256) void sr_tr_oca_fold_kernel(SrTrOcaFold a) {
     store4(reinterpret_cast<bf16*>(a.v) + dst + 4, v1);
 }
 
-__global__ __launch_bounds__(256) void sr_tr_dbias_kernel(const float* __restrict__ part, int groups, const long long* __restrict__ rpi, float* __restrict__ dtable, int T, int heads,
-                                                         long long NN) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= NN * heads) return;
-    const int h = (int)(idx / NN);
-    const long long ij = idx - (long long)h * NN;
-    float v = 0.f;
-    for (int g = 0; g < groups; ++g) v += part[(long long)g * heads * NN + idx];
-    long long t = rpi[ij];
-    if (t < 0) t += T;
-    atomicAdd(dtable + t * heads + h, v);
-}
-
 }  // namespace
 
 
@@ -411,16 +463,9 @@ extern "C" int sr_tr_oca_fold(const SrTrOcaFold* p, int unfold, void* stream) {
     return SR_OK;
 }
 
-extern "C" int sr_tr_dbias(const float* dbias_part, int groups, const long long* rpi, float* dtable, int T, int heads, long long NN, void* stream) {
-    SR_REQUIRE(dbias_part && rpi && dtable && groups > 0 && T > 0 && heads > 0 && NN > 0, "sr_tr_dbias: bad arguments");
-    hipLaunchKernelGGL(sr_tr_dbias_kernel, dim3((unsigned)((NN * heads + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dbias_part, groups, rpi, dtable, T, heads, NN);
-    SR_CHECK_LAUNCH("sr_tr_dbias");
-    return SR_OK;
-}
-
 extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
     SR_REQUIRE(p && p->q && p->qT && p->k && p->kT && p->v && p->o && p->dO && p->dOT && p->bias && p->biasT && p->dq && p->dk && p->dv && p->lse && p->delta &&
-                   p->dbias_part,
+                   p->dtab_part && p->rpi,
                "sr_tr_attn_bwd: null pointer");
     const SrTrAttnBwd& a = *p;
     SR_REQUIRE(a.hd_p == 32 && a.Nq == 256 && (a.Nk == 256 || a.Nk == 576) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 && a.groups <= a.n_bwin && a.ldo >= a.heads * 32 &&
@@ -435,13 +480,18 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
         b.ws = 16;
         b.H = b.W = 16;
     }
-    const int items_q = a.groups * a.heads * (a.Nq / 16), items_kv = a.n_bwin * a.heads * (a.Nk / 16);
-    if (a.Nk == 256)
-        hipLaunchKernelGGL(sr_tr_attn_bwd_q_kernel<16>, dim3((items_q + 3) / 4), dim3(256), 0, st, b);
-    else
-        hipLaunchKernelGGL(sr_tr_attn_bwd_q_kernel<36>, dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    SR_REQUIRE(a.T > 0 && a.T <= 1536 && a.Tpad >= a.T, "sr_tr_attn_bwd: the bias table has at most 1536 rows");
+    const int items_q = a.groups * a.heads * (a.Nq / 16), items_kv = a.n_bwin * a.heads * (a.Nk / 32);
+    static const int var = getenv("SR_TR_QVAR") ? atoi(getenv("SR_TR_QVAR")) : 1;  // 0: the generic index-map fold (A/B knob)
+    if (a.Nk == 256) {
+        if (var == 1 && a.toeplitz16)
+            hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 1>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+        else
+            hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    } else
+        hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<36, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (q)");
-    hipLaunchKernelGGL(sr_tr_attn_bwd_kv_kernel<16>, dim3((items_kv + 3) / 4), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((sr_tr_attn_bwd_kv_kernel<16, 2>), dim3((items_kv + 3) / 4), dim3(256), 0, st, b);
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv)");
     return SR_OK;
 }

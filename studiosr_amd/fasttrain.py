@@ -3,7 +3,7 @@ L1 loss, loss.backward(), Adam) for HAT's default block geometry as fused HIP la
 (studiosr_amd/autograd.py).  What runs per HAB (hat.py:153-195):
 
     forward   sr_tr_qkv_fwd -> sr_window_attention || sr_cab_fused -> sr_tr_tail_fwd                                   (4 launches)
-    backward  sr_tr_tail_bwd -> sr_tr_attn_bwd (2) + sr_tr_dbias -> CAB: conv1 recompute, sr_tr_ca_bwd, conv2 dgrad, sr_tr_gelu,
+    backward  sr_tr_tail_bwd -> sr_tr_attn_bwd (2 passes; the bias-table gradient leaves pass Q as per-workgroup table partials) -> CAB: conv1 recompute, sr_tr_ca_bwd, conv2 dgrad, sr_tr_gelu,
               conv1 dgrad (the dgrads are sr_conv3x3 with flipped / transposed packed weights) -> sr_tr_qkv_bwd -> sr_tr_wgrad (6 jobs)
 
 Host-side design:
@@ -414,9 +414,10 @@ class BlockPlan:
             fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
             fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
 
-    def prepare(self, B: int, H: int, W: int, dev) -> None:
+    def prepare(self, B: int, H: int, W: int, dev, groups: int) -> None:
         """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images; static activations."""
         fp, fm = self.fp, self.fm
+        self.groups = groups
         nwg = B * H * W // 64
         self.f_ln1, self.f_ln2 = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
         for f, norm in ((self.f_ln1, self.blk.norm1), (self.f_ln2, self.blk.norm2)):
@@ -432,9 +433,11 @@ class BlockPlan:
             fm.put(fp.pidx(ca[1].bias), o + cr * C_REAL + np.arange(cr), self.ca_stride, B)
             fm.put(fp.pidx(ca[3].weight), o + cr * C_REAL + cr + np.arange(C_REAL * cr), self.ca_stride, B)
             fm.put(fp.pidx(ca[3].bias), o + cr * C_REAL + cr + C_REAL * cr + np.arange(C_REAL), self.ca_stride, B)
-        tb = self.table
-        self.f_tab = fm.alloc(tb.numel())
-        fm.put(fp.pidx(tb), self.f_tab + np.arange(tb.numel()), 0, 1)
+        tb = self.table  # [T, heads]: one table-sized partial per pass-Q workgroup, a head's groups * 4 workgroups consecutive (sr_tr_attn_bwd)
+        self.tpad = (tb.shape[0] + 63) // 64 * 64
+        nq_wg = self.groups * 4
+        self.f_tab = fm.alloc(HEADS * nq_wg * self.tpad)
+        fm.put(fp.pidx(tb), self.f_tab + np.arange(HEADS)[None, :] * nq_wg * self.tpad + np.arange(tb.shape[0])[:, None], self.tpad, nq_wg)
         T = B * H * W
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
@@ -502,12 +505,10 @@ class BlockPlan:
               wstream=wa[self.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(), n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(),
               dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=sc.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
         dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
-        dbp = sc.dbias_oca if self.oca else sc.dbias_part
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
-              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dbias_part=dbp.data_ptr(), n_bwin=T // 256,
-              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=sc.groups, H=H, W=W, ws=16, shift=self.shift)
-        L.check(lib.sr_tr_dbias(dbp.data_ptr(), sc.groups, self.rpi_dev.data_ptr(), pp(self.f_tab), self.table.shape[0], HEADS, 256 * self.nk, _st()), "sr_tr_dbias")
+              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // 256,
+              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=sc.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift)
         jobs = []
         ks = WG_KS
         if self.oca:
@@ -554,11 +555,9 @@ class Scratch:
         self.dgate_part = e(T // 64, CP, dt=f32)
         self.lse, self.delta = e(T // 256 * HEADS * 256, dt=f32), e(T // 256 * HEADS * 256, dt=f32)
         self.groups = groups
-        self.dbias_part = e(groups, HEADS, 256, 256, dt=f32)
         self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))
         n = T // 256 * HEADS * 576 * 32  # OCAB: unfolded neighbourhoods
         self.vwinT, self.dkwin, self.dvwin = e(n), e(n), e(n)
-        self.dbias_oca = e(groups, HEADS, 256, 576, dt=f32)
 
 
 def _conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, B: int, H: int, W: int, cin_p: int, cout_p: int) -> None:
@@ -593,7 +592,7 @@ class Stage:
         p1 = max(fp.off(p) + (p.numel() + 3) // 4 * 4 for p in params)
         self.params = params
         self.fm = FinalMap(fp, p0, p1)
-        sa_dev, oca_dev = rpi_sa.detach().to(torch.int64).contiguous(), rpi_oca.detach().to(torch.int64).contiguous()
+        sa_dev, oca_dev = rpi_sa.detach().to(torch.int32).contiguous(), rpi_oca.detach().to(torch.int32).contiguous()
         self.blocks = [BlockPlan(fp, b, rpi_sa.detach().cpu().numpy(), sa_dev, conv_scale, b.shift_size, wa, fa, self.fm) for b in habs]
         if ocab is not None:
             self.blocks.append(BlockPlan(fp, ocab, rpi_oca.detach().cpu().numpy(), oca_dev, 0.0, 0, wa, fa, self.fm, oca=True))
@@ -606,13 +605,11 @@ class Stage:
             return
         assert self.geo is None, "one geometry per fast-training plan (rebuild the plan for another batch / patch size)"
         for h in self.blocks:
-            h.prepare(B, H, W, dev)
+            h.prepare(B, H, W, dev, scratch.groups)
         self.fm.finish(dev)
         self.geo = (B, H, W)
         self.sc = scratch
         self.ts = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in self.blocks]  # block outputs
-        self.tab_lo = min(h.f_tab for h in self.blocks)
-        self.tab_hi = max(h.f_tab + h.table.numel() for h in self.blocks)
 
     def forward(self, x: Tensor, scales: Optional[Tensor]) -> Tensor:
         cur = x
@@ -624,7 +621,6 @@ class Stage:
     def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor]) -> Tensor:
         """dout: gradient of the stage output; returns the gradient of x (a fresh tensor); fills G for the stage's parameters."""
         B, H, W = self.geo
-        self.fm.part[self.tab_lo:self.tab_hi].zero_()  # the bias-table gradients are scatter-added
         d = dout.contiguous()
         for i in range(len(self.blocks) - 1, -1, -1):
             h = self.blocks[i]

@@ -159,7 +159,7 @@ class Trainer:
         return psnr, ssim
 
     def build_optimizer(self):
-        opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate, betas=self.betas, weight_decay=self.weight_decay)
+        opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate, betas=self.betas, weight_decay=self.weight_decay, fused=next(self.model.parameters()).is_cuda)
         return opt, torch.optim.lr_scheduler.MultiStepLR(opt, milestones=self.milestones, gamma=self.gamma)
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:148-187)

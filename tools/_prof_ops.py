@@ -5,7 +5,7 @@ from torch.profiler import profile, ProfilerActivity
 dev = "cuda:0"
 torch.manual_seed(0)
 m = S.HAT(scale=4).to(dev).train()
-opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.99))
+opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
 x, y = torch.rand(4, 3, 64, 64, device=dev), torch.rand(4, 3, 256, 256, device=dev)
 def step():
     with torch.autocast("cuda", dtype=torch.bfloat16):

@@ -75,7 +75,11 @@ def check_attn(shift=8):
     v = torch.randn(nb, h, N, 32, device=dev)
     for t in (q, k, v):
         t[..., 30:] = 0
-    bias = torch.randn(h, N, N, device=dev) * 0.2
+    from studiosr_amd.models.hat import rpi_sa
+
+    rpi = rpi_sa(16).to(dev)
+    table = (torch.randn(961, h, device=dev) * 0.2).requires_grad_(True)
+    bias = table[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1).contiguous().detach()
     dO = torch.randn(nb, N, h * 32, device=dev)
     qb, kb, vb, dOb = (t.to(bf) for t in (q, k, v, dO))
     mask = None
@@ -85,22 +89,56 @@ def check_attn(shift=8):
     q_, k_, v_ = (t.float().clone().requires_grad_(True) for t in (qb, kb, vb))
     o = attn_ref(q_, k_, v_, bias, mask)  # [nb, h, N, 32]
     o_rows = o.permute(0, 2, 1, 3).reshape(nb, N, h * 32)
-    bias_ = bias.clone().requires_grad_(True)
+    bias_ = table[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1)
     o2 = attn_ref(q_, k_, v_, bias_, mask).permute(0, 2, 1, 3).reshape(nb, N, h * 32)
     o2.backward(dOb.float())
     ob = o_rows.detach().to(bf).contiguous()
     groups = 4
     dq, dk, dv = (torch.zeros(nb, h, N, 32, device=dev, dtype=bf) for _ in range(3))
     lse, delta = torch.zeros(nb, h, N, device=dev), torch.zeros(nb, h, N, device=dev)
-    dbp = torch.zeros(groups, h, N, N, device=dev)
+    tpad = 1024
+    dtp = torch.zeros(h * groups * 4, tpad, device=dev)
+    rpi32 = rpi.to(torch.int32).contiguous()
     qT, kT = qb.transpose(-1, -2).contiguous(), kb.transpose(-1, -2).contiguous()
     dOT = dOb.reshape(nb, N, h, 32).permute(0, 2, 3, 1).contiguous()
     biasT = bias.transpose(1, 2).contiguous()
     F._call(L.lib().sr_tr_attn_bwd, L.SrTrAttnBwd, "attn_bwd", q=qb.data_ptr(), qT=qT.data_ptr(), k=kb.data_ptr(), kT=kT.data_ptr(), v=vb.data_ptr(), o=ob.data_ptr(),
             dO=dOb.data_ptr(), dOT=dOT.data_ptr(), bias=bias.data_ptr(), biasT=biasT.data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(), dv=dv.data_ptr(), lse=lse.data_ptr(),
-            delta=delta.data_ptr(), dbias_part=dbp.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N, ldo=h * 32, groups=groups, H=H, W=W, ws=16, shift=shift)
+            delta=delta.data_ptr(), dtab_part=dtp.data_ptr(), rpi=rpi32.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N, ldo=h * 32, groups=groups, T=961, Tpad=tpad, toeplitz16=1,
+            H=H, W=W, ws=16, shift=shift)
     torch.cuda.synchronize()
-    print(f"attn bwd shift={shift}: dq {rel(dq, q_.grad):.3e} dk {rel(dk, k_.grad):.3e} dv {rel(dv, v_.grad):.3e} dbias {rel(dbp.sum(0), bias_.grad):.3e}")
+    print(f"attn bwd shift={shift}: dq {rel(dq, q_.grad):.3e} dk {rel(dk, k_.grad):.3e} dv {rel(dv, v_.grad):.3e} dtable {rel(dtp.reshape(h, groups * 4, tpad).sum(1)[:, :961].t(), table.grad):.3e}")
+
+
+def time_attn():
+    """launch times of the two attention-backward passes at the training shape (4 x 64 x 64: 64 windows)"""
+    from studiosr_amd.models.hat import rpi_sa
+
+    torch.manual_seed(1)
+    nb, h, N = 64, 6, 256
+    mk = lambda *s: (torch.randn(*s, device=dev) * 0.3).to(bf)  # noqa: E731
+    q, k, v, qT, kT, dOT = mk(nb, h, N, 32), mk(nb, h, N, 32), mk(nb, h, N, 32), mk(nb, h, 32, N), mk(nb, h, 32, N), mk(nb, h, 32, N)
+    o, dO = mk(nb, N, 192), mk(nb, N, 192)
+    bias, biasT = torch.randn(h, N, N, device=dev), torch.randn(h, N, N, device=dev)
+    dq, dk, dv = (torch.zeros(nb, h, N, 32, device=dev, dtype=bf) for _ in range(3))
+    lse, delta = torch.zeros(nb, h, N, device=dev), torch.zeros(nb, h, N, device=dev)
+    groups = 16
+    dtp = torch.zeros(h * groups * 4, 1024, device=dev)
+    rpi32 = rpi_sa(16).to(dev).to(torch.int32).contiguous()
+    def run():
+        F._call(L.lib().sr_tr_attn_bwd, L.SrTrAttnBwd, "attn_bwd", q=q.data_ptr(), qT=qT.data_ptr(), k=k.data_ptr(), kT=kT.data_ptr(), v=v.data_ptr(), o=o.data_ptr(),
+                dO=dO.data_ptr(), dOT=dOT.data_ptr(), bias=bias.data_ptr(), biasT=biasT.data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(), dv=dv.data_ptr(), lse=lse.data_ptr(),
+                delta=delta.data_ptr(), dtab_part=dtp.data_ptr(), rpi=rpi32.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N, ldo=192, groups=groups, T=961, Tpad=1024, toeplitz16=1,
+                H=64, W=64, ws=16, shift=8)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"attn bwd (both passes) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us  QVAR={os.environ.get('SR_TR_QVAR', '0')}")
 
 
 def make_hat(depth=2):
@@ -157,6 +195,8 @@ if __name__ == "__main__":
             elif w == "attn":
                 check_attn(8)
                 check_attn(0)
+            elif w == "tattn":
+                time_attn()
             elif w == "model":
                 check_model()
         except Exception:
