@@ -191,8 +191,17 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         for (int kt = 0; kt < KT; ++kt) {
             const int4 t4 = *reinterpret_cast<const int4*>(rp + kt * 16 + lg * 4);
             const int tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            if (VAR == 2) {  // one lane group at a time: no two lanes of an instruction on one address
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
+                for (int g = 0; g < 4; ++g)
+                    if (lg == g) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
+            }
         }
     }
     __syncthreads();
@@ -486,6 +495,8 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
     if (a.Nk == 256) {
         if (var == 1 && a.toeplitz16)
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 1>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+        else if (var == 2)
+            hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 2>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
         else
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
     } else

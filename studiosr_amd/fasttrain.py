@@ -68,9 +68,19 @@ class FlatParams:
         base = self.P.data_ptr()
         return all(p.data_ptr() == base + 4 * self._off[id(p)] and p.device == self.P.device for p in self.params)
 
-    def grad_view(self, p: Tensor) -> Tensor:
+    def grad_view(self, p: Tensor, G: Optional[Tensor] = None) -> Tensor:
         o = self._off[id(p)]
-        return self.G[o:o + p.numel()].view_as(p)
+        return (self.G if G is None else G)[o:o + p.numel()].view_as(p)
+
+    def grad_target(self) -> Tensor:
+        """Where this backward writes: G itself when no parameter holds a gradient yet (autograd then adopts the views: no copy, no add);
+        a second buffer when gradients are being accumulated (`zero_grad(set_to_none=False)`, several backwards per step) -- .grad may then BE
+        a view of G, which this backward must not overwrite before autograd adds the new gradient to it."""
+        if all(p.grad is None for p in self.params):
+            return self.G
+        if getattr(self, "G2", None) is None:
+            self.G2 = torch.zeros_like(self.G)
+        return self.G2
 
     def pidx(self, p: Tensor) -> np.ndarray:
         return (self._off[id(p)] + np.arange(p.numel(), dtype=np.int64)).reshape(tuple(p.shape))
@@ -618,7 +628,7 @@ class Stage:
             cur = self.ts[i]
         return cur
 
-    def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor]) -> Tensor:
+    def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor], G: Optional[Tensor] = None) -> Tensor:
         """dout: gradient of the stage output; returns the gradient of x (a fresh tensor); fills G for the stage's parameters."""
         B, H, W = self.geo
         d = dout.contiguous()
@@ -627,7 +637,7 @@ class Stage:
             dx = torch.empty(B, H, W, CP, dtype=torch.float32, device=d.device)
             h.backward(self, x if i == 0 else self.ts[i - 1], d, dx, None if (scales is None or h.oca) else scales[i])
             d = dx
-        self.fm.run(self.fp.G)
+        self.fm.run(self.fp.G if G is None else G)
         return d
 
 
@@ -647,8 +657,9 @@ class _StageFn(torch.autograd.Function):
         if stage.gen != ctx.gen:
             raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
         (x,) = ctx.saved_tensors
-        dx = stage.backward(x, dout, ctx.scales)
-        grads = tuple(stage.fp.grad_view(p) for p in stage.params)
+        G = stage.fp.grad_target()
+        dx = stage.backward(x, dout, ctx.scales, G)
+        grads = tuple(stage.fp.grad_view(p, G) for p in stage.params)
         return (dx, None, None) + grads
 
 
@@ -731,8 +742,9 @@ class _ModelFn(torch.autograd.Function):
         plan = ctx.plan
         if plan.gen != ctx.gen:
             raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
-        plan.backward_model(dout)
-        return (None, None) + tuple(plan.fp.grad_view(p) for p in plan.fp.params)
+        G = plan.fp.grad_target()
+        plan.backward_model(dout, G)
+        return (None, None) + tuple(plan.fp.grad_view(p, G) for p in plan.fp.params)
 
 
 def run_model(plan: "HatPlan", x: Tensor) -> Tensor:
@@ -780,6 +792,7 @@ class HatPlan:
         self.scratch = None
         self.geo = None
         self.packed_version = None
+        self.scales_override = None
         self.gen = 0
     @staticmethod
     def supported(model) -> bool:
@@ -850,7 +863,10 @@ class HatPlan:
             if getattr(self, "_keep", None) is None:
                 nb = len(self.stages[0].blocks) - int(self.with_oca)
                 self._keep = (1.0 - torch.tensor(dpr, dtype=torch.float32, device=x.device)).reshape(len(self.stages), nb, 1, 1)
-            self.scales = ((torch.rand(self._keep.shape[0], self._keep.shape[1], 2, B, device=x.device) < self._keep).to(torch.float32) / self._keep).contiguous()
+            mask = (torch.rand(self._keep.shape[0], self._keep.shape[1], 2, B, device=x.device) < self._keep).to(torch.float32)
+            self.scales = (mask / self._keep.clamp_min(1e-30)).contiguous()  # keep == 0: the mask is all zero and stays unscaled, as timm's DropPath
+        if self.scales_override is not None:  # testing hook: [stages, blocks, 2, B]
+            self.scales = self.scales_override.to(torch.float32).contiguous()
         cur = self.t0
         for li, st in enumerate(self.stages):
             st.gen += 1
@@ -868,7 +884,8 @@ class HatPlan:
         self.c_last.fwd(self, t, out, B, h, w, out_mode=L.OUT_FINAL_NCHW, fin=(*self.fin, m.n_colors, Hin * s, Win * s))
         return out
 
-    def backward_model(self, dout: Tensor) -> None:
+    def backward_model(self, dout: Tensor, G: Optional[Tensor] = None) -> None:
+        G = self.fp.G if G is None else G
         m = self.model
         B, H, W = self.geo
         lib = L.lib()
@@ -876,6 +893,8 @@ class HatPlan:
         h, w = self.hw_out
         T = B * H * W
         dout = dout.contiguous().to(torch.float32)
+        if dout.shape[2] != h or dout.shape[3] != w:  # reflect-padded input (hat.py:544): the output was cropped, its gradient is zero beyond the crop
+            dout = torch.nn.functional.pad(dout, (0, w - dout.shape[3], 0, h - dout.shape[2]))
         # d(conv_last output) = dout * range, NHWC, zero beyond the cropped size and in the pad channels
         ops.ingest_nchw(dout, self.dY, L.PAD_NONE, self.fin[0], self.zero3)
         jobs = self.c_last.wgrad_jobs(self, self.dY, 32, self.ups[-1] if self.ups else self.feat, B, h, w)
@@ -912,7 +931,7 @@ class HatPlan:
             jobs = self.c_layers[li].wgrad_jobs(self, dt, CP, st.ts[-1], B, H, W)
             self.c_layers[li].dgrad(self, dt, self.dcv, B, H, W)
             _wgrad(jobs)
-            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li])
+            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li], G)
             nxt = self.dtB if dt is self.dtA else self.dtA
             L.check(lib.sr_tr_add(dx.data_ptr(), dt.data_ptr(), L.SR_F32, nxt.data_ptr(), T * CP, _st()), "sr_tr_add")
             dt = nxt
@@ -920,7 +939,7 @@ class HatPlan:
         _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=self.first.data_ptr(), dy=dt.data_ptr(), gamma=fa[self.o_pe[0]:].data_ptr(), dskip=self.dbody.data_ptr(),
               dx=dfirst.data_ptr(), ln_part=pp(self.f_pe), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=1, eps=1e-5)
         _wgrad(self.c_first.wgrad_jobs(self, dfirst, CP, self.xin, B, H, W))
-        self.fm.run(self.fp.G)
+        self.fm.run(G)
 
     def pack(self) -> None:
         """Packed operands <- current parameters (once per optimizer step: the parameter versions decide)."""

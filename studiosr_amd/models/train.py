@@ -173,7 +173,7 @@ def _fast_habs(plan, li: int, t: Tensor, rates, training: bool) -> Tensor:
     scales = None
     if training and any(r > 0.0 for r in rates):  # DropPath: per block, per branch, per image Bernoulli(keep) / keep (hat.py:148,192-193)
         keep = 1.0 - torch.tensor(list(rates), dtype=torch.float32, device=t.device)
-        scales = ((torch.rand(len(rates), 2, B, device=t.device) < keep[:, None, None]).to(torch.float32) / keep[:, None, None]).contiguous()
+        scales = ((torch.rand(len(rates), 2, B, device=t.device) < keep[:, None, None]).to(torch.float32) / keep[:, None, None].clamp_min(1e-30)).contiguous()
     tp = torch.nn.functional.pad(t, (0, fasttrain.CP - t.shape[-1]))
     out = fasttrain.run_stage(plan.stages[li], tp, scales)
     return out[..., : t.shape[-1]].contiguous()

@@ -267,3 +267,61 @@ def test_swin_qkv_and_tail_stream_packing_places_every_fragment():
         want = float(bf(proj_w[row, c * hd + dd])) if (row < C and dd < hd) else 0.0
         assert frag(stl, c, 3 * w + n, i, k) == want, (c, w, n, i, k)
 
+
+
+def test_index_form_packers_equal_the_value_packers():
+    """studiosr_amd/fasttrain.py builds the training path's packed operands as index maps (one device gather per optimizer step); evaluated on
+    the host they must reproduce studiosr_amd/packing.py element for element (where the layouts coincide)."""
+    import numpy as np
+
+    from studiosr_amd import fasttrain as F
+    from studiosr_amd.models.hat import rpi_sa
+
+    torch.manual_seed(0)
+
+    class FakeFP:
+        def __init__(self, tensors):
+            self._off, n = {}, 0
+            for p in tensors:
+                self._off[id(p)] = n
+                n += (p.numel() + 3) // 4 * 4
+            self.P = np.zeros(n, np.float32)
+            for p in tensors:
+                self.P[self._off[id(p)]:self._off[id(p)] + p.numel()] = p.numpy().reshape(-1)
+
+        def pidx(self, p):
+            return (self._off[id(p)] + np.arange(p.numel(), dtype=np.int64)).reshape(tuple(p.shape))
+
+    def emulate(fp, m, dtype=torch.bfloat16):  # what sr_tr_gather computes
+        idx, scl, mode = m.idx.reshape(-1), m.scl.reshape(-1), m.mode.reshape(-1)
+        t = torch.from_numpy(np.where(idx >= 0, fp.P[np.clip(idx, 0, None)] * scl, scl).astype(np.float32))
+        hi = t.to(torch.bfloat16).float()
+        return torch.where(torch.from_numpy(mode == 1), hi, torch.where(torch.from_numpy(mode == 2), t - hi, t)).to(dtype)
+
+    qkv_w, qkv_b, proj_w = torch.randn(540, 180) * 0.1, torch.randn(540) * 0.1, torch.randn(180, 180) * 0.1
+    fc1_w, fc1_b, fc2_w, fc2_b = torch.randn(360, 180) * 0.1, torch.randn(360) * 0.1, torch.randn(180, 360) * 0.1, torch.randn(180) * 0.1
+    fp = FakeFP([qkv_w, qkv_b, proj_w, fc1_w, fc1_b, fc2_w, fc2_b])
+    assert torch.equal(emulate(fp, F.pack_qkv_fwd(fp, qkv_w, qkv_b)), packing.pack_swin_qkv_stream(qkv_w, qkv_b, 180, 6))
+    a = emulate(fp, F.pack_tail_fwd(fp, proj_w, fc1_w, fc1_b, fc2_w, fc2_b))
+    b = packing.pack_swin_tail_stream(proj_w, fc1_w, fc1_b, fc2_w, fc2_b, 180, 6, 360)
+    # the training stream differs by design in the hidden pad columns: no gelu(1) rows in fc1 (the kernel writes the ones), fc2 bias not divided by gelu(1)
+    assert int((a != b).sum()) == 2 + 2 * 180
+    w = torch.randn(60, 180, 3, 3)
+    fp2 = FakeFP([w])
+    assert torch.equal(emulate(fp2, F.pack_conv(fp2, w, 192, 64)), packing.pack_conv3x3(w, None, 192, packing.identity_idx(60, 64), torch.bfloat16)[0])
+    wt = torch.zeros(180, 60, 3, 3)  # the data-gradient convolution's weight: transposed, taps flipped
+    for t in range(9):
+        wt[:, :, t // 3, t % 3] = w[:, :, (8 - t) // 3, (8 - t) % 3].t()
+    assert torch.equal(emulate(fp2, F.pack_conv(fp2, w, 64, 192, transpose=True)), packing.pack_conv3x3(wt, None, 64, packing.identity_idx(180, 192), torch.bfloat16)[0])
+    wu = torch.randn(256, 64, 3, 3)  # a conv feeding PixelShuffle(2): packed rows permuted
+    fp4 = FakeFP([wu])
+    rows = packing.pixel_shuffle_rows(64, 64, 2)
+    assert torch.equal(emulate(fp4, F.pack_conv(fp4, wu, 64, 256, rows=rows.numpy())), packing.pack_conv3x3(wu, None, 64, rows, torch.bfloat16)[0])
+    table = torch.randn(961, 6)
+    fp3 = FakeFP([table])
+    rpi = rpi_sa(16)
+    ref = packing.gather_bias(table, rpi, 256, 256)
+    b_, bt, bfr = F.pack_bias(fp3, table, rpi.numpy(), 256, 256)
+    assert torch.equal(emulate(fp3, b_, torch.float32).reshape(6, 256, 256), ref)
+    assert torch.equal(emulate(fp3, bt, torch.float32).reshape(6, 256, 256), ref.transpose(1, 2))
+    assert torch.equal(emulate(fp3, bfr, torch.float32), packing.bias_fragments(ref))

@@ -294,3 +294,126 @@ def test_trainer_class_runs_saves_and_resumes(tmp_path):
     assert tr2.data_handler.iterations == 3  # resumed
     sd1, sd2 = m.state_dict(), m2.state_dict()
     assert all(torch.equal(sd1[k].cpu(), sd2[k].cpu()) for k in sd1)
+
+
+# --------------------------------------------------------------------------- fused training path (studiosr_amd/fasttrain.py, C ABI v7)
+def _default_width_hat(depths=(2,), drop_path_rate=0.0, scale=2):
+    torch.manual_seed(0)
+    m = S.HAT(scale=scale, depths=list(depths), num_heads=[6] * len(depths), drop_path_rate=drop_path_rate)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.05)
+            elif n_.endswith("relative_position_bias_table"):
+                p_.add_(torch.randn_like(p_) * 0.2)
+    return m.to(DEV).train()
+
+
+def _train_step(m, x, y, autocast, fast):
+    prev = os.environ.get("SR_FAST_TRAIN")
+    os.environ["SR_FAST_TRAIN"] = "1" if fast else "0"
+    try:
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = m(x)
+            loss = F.l1_loss(out.float(), y)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        if prev is None:
+            os.environ.pop("SR_FAST_TRAIN", None)
+        else:
+            os.environ["SR_FAST_TRAIN"] = prev
+    return loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, out.detach().float()
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("size", [(32, 32), (24, 40)])
+def test_fused_training_path_matches_the_generic_engine(size):
+    """The fused HAT step (one autograd node: sr_tr_* launches, bf16 operands as under the reference Trainer's autocast, trainer.py:80,102)
+    against the generic engine whose gradients are pinned to the reference by the f15 fixtures: default block width (embed 180, 6 heads,
+    16 x 16 windows incl. a shifted block, CAB, OCAB), two images.  Yardstick as test_gradients_under_bf16_autocast: both bf16 computations
+    are compared with the exact-fp32 step; the fused one may not be noisier than the generic bf16 one (x 1.15 + 2e-3).  (24, 40): reflect
+    padding to 32 x 48 and a cropped output."""
+    m = _default_width_hat()
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, *size, device=DEV)
+    y = torch.rand(2, 3, size[0] * 2, size[1] * 2, device=DEV)
+    l32, g32, o32 = _train_step(m, x, y, False, False)
+    lac, gac, oac = _train_step(m, x, y, True, False)
+    assert getattr(m, "_fast_plan", None) is None  # SR_FAST_TRAIN=0 really is the generic engine
+    lf, gf, of = _train_step(m, x, y, True, True)
+    assert m._fast_plan is not None and m._fast_plan.full
+    assert abs(lf - l32) <= 2e-4 * max(1.0, abs(l32))
+    assert _rel(of, o32) <= 1.15 * _rel(oac, o32) + 1e-3
+    tot = lambda g: torch.cat([g[n].flatten() for n in sorted(g32)])  # noqa: E731
+    e_gen, e_fast = _rel(tot(gac), tot(g32)), _rel(tot(gf), tot(g32))
+    assert e_fast <= 1.15 * e_gen + 2e-3, (e_fast, e_gen)
+    for n in g32:  # every parameter tensor: no gradient may be missing, mis-mapped or mis-scaled
+        scale = float(g32[n].abs().max())
+        assert float((gf[n] - g32[n]).abs().max()) <= 0.08 * max(scale, 1e-9) + 3 * float((gac[n] - g32[n]).abs().max()), n
+
+
+def test_fused_training_path_drop_path_and_accumulation():
+    """DropPath in the fused path (hat.py:148,192-193: per block, per branch, per image scale in {0, 1 / keep}): with the SAME scales forced into
+    both paths the fused gradients match the generic engine's; a dropped branch (scale 0) contributes nothing; and a second backward onto
+    existing .grad tensors accumulates (the gradient buffer of the first is not overwritten)."""
+    from studiosr_amd import autograd as A
+    from studiosr_amd import fasttrain
+
+    m = _default_width_hat(drop_path_rate=0.3)
+    torch.manual_seed(5)
+    x, y = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+    scales = torch.tensor([[[[0.0, 1.25], [1.25, 1.25]], [[1.0 / 0.7, 0.0], [0.0, 1.0 / 0.7]]]], device=DEV)  # [stage 1][block 2][branch 2][image 2]
+    seq = [scales[0, b, br] for b in range(2) for br in range(2)]
+    calls = []
+
+    def forced(t, p, training):
+        s = seq[len(calls)]
+        calls.append(p)
+        return A._ScaleSample.apply(t, s.contiguous())
+
+    orig = A.drop_path
+    A.drop_path = forced
+    try:
+        lg, gg, og = _train_step(m, x, y, True, False)
+    finally:
+        A.drop_path = orig
+    assert len(calls) == 4
+    plan = fasttrain.get_plan(m)
+    plan.scales_override = scales
+    lf, gf, of = _train_step(m, x, y, True, True)
+    assert _rel(of, og) <= 5e-3 and abs(lf - lg) <= 1e-3
+    tot = lambda g: torch.cat([g[n].flatten() for n in sorted(gg)])  # noqa: E731
+    assert _rel(tot(gf), tot(gg)) <= 2e-2
+    # block 0's attention branch is dropped for image 0 and its MLP branch for ... (see scales): the proj / fc2 weight gradients see only the kept images
+    # accumulation: backward twice without clearing .grad
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        F.l1_loss(m(x).float(), y).backward()
+    for n, p in m.named_parameters():
+        assert _rel(p.grad, 2 * gf[n]) <= 1e-5, n
+    plan.scales_override = None
+
+
+def test_fused_training_path_guards():
+    """One forward in flight per model (static activation buffers): a second forward before the first backward is an error at that backward;
+    other geometries / no autocast / eval fall back to the other paths."""
+    m = _default_width_hat()
+    x, y = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l1 = F.l1_loss(m(x).float(), y)
+        l2 = F.l1_loss(m(x).float(), y)
+    l2.backward()
+    with pytest.raises(RuntimeError, match="one forward in flight"):
+        l1.backward()
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):  # another batch geometry: the generic engine (one geometry per plan)
+        out = m(torch.rand(1, 3, 48, 48, device=DEV))
+    out.float().mean().backward()
+    assert all(p.grad is not None for p in m.parameters())
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert m(x).shape == (2, 3, 64, 64)
