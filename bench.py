@@ -309,7 +309,9 @@ def run_train(args, device, rank, world) -> None:
     torch.manual_seed(0)
     model = S.HAT(scale=4).to(device).train()
     cfg = model.get_training_config()
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.get("learning_rate", 2e-4), betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.99)), fused=True)
+    from studiosr_amd.optim import Adam  # torch.optim.Adam (what studiosr_amd.Trainer builds): one flat launch on the fused path
+
+    opt = Adam(model.parameters(), model=model, lr=cfg.get("learning_rate", 2e-4), betas=(cfg.get("beta1", 0.9), cfg.get("beta2", 0.99)))
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=cfg.get("milestones", [250000]), gamma=cfg.get("gamma", 0.5))
     net = DDP(model, device_ids=[device.index], output_device=device.index) if world > 1 else model
     per_rank = 4
@@ -351,7 +353,8 @@ def run_train(args, device, rank, world) -> None:
             "metric": "training samples/sec at HAT x4, 64x64 LR patches, L1 + Adam step", "value": round(per_rank * world / dt, 3), "unit": "samples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic", "config": {"workload": "HAT x4 (embed 180, 6x(6 HAB + OCAB), ws 16) training step: forward + backward + Adam, per-rank batch 4, 64x64 LR / 256x256 HR",
-                                             "global_batch": per_rank * world, "parallelism": f"ddp{world}" if world > 1 else "single"},
+                                             "global_batch": per_rank * world, "parallelism": f"ddp{world}" if world > 1 else "single",
+                                             "path": "fused launch sequence (studiosr_amd/fasttrain.py, C ABI v7)" if getattr(model, "_fast_plan", None) is not None else "generic engine"},
             "final_loss": loss.item(),
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": round(tflops / (2500.0 * world), 4), "traffic": None,
                          "note": "bf16 operands / fp32 accumulate for the contractions (autocast), fp32 everywhere else; against the fp32 MFMA peak (157.3 TFLOP/s) the same step is "

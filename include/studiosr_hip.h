@@ -603,6 +603,9 @@ int sr_tr_ln_bwd(const SrTrLnBwd* a, void* stream);
 int sr_tr_unshuffle(const void* src, void* dst, int B, int H, int W, int cps, int r, void* stream);
 int sr_tr_lrelu_bwd(const void* dy, const void* y, void* dx, float slope, long long n, void* stream);
 int sr_tr_add(const float* a, const void* b, int b_dtype, float* out, long long n, void* stream);
+/* torch.optim.Adam's update (the reference Trainer's optimizer, trainer.py:133-139; L2 weight_decay, no amsgrad) on the flat fp32 parameter /
+ * gradient / first- / second-moment buffers in ONE launch; step = 1-based update count (bias corrections computed in double on the host). */
+int sr_tr_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream);
 
 /* g = GELU(x) and / or dx = dg * GELU'(x), bf16 (the nn.GELU between the CAB's convolutions, hat.py:43); n elements, n % 8 == 0. */
 int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long long n, void* stream);

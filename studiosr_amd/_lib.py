@@ -297,6 +297,7 @@ SYMBOLS = {
     "sr_tr_unshuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sr_tr_lrelu_bwd": (_i, [_vp, _vp, _vp, _f, _ll, _vp]),
     "sr_tr_add": (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
+    "sr_tr_adam": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _ll, _vp]),
 }
 
 _lib = None

@@ -857,11 +857,29 @@ __global__ __launch_bounds__(256) void sr_tr_ca_bwd_kernel(SrTrCaBwd a) {
     const float* mean = scratch;
     const float* hid = scratch + a.Cp;
     __shared__ float dz2[256], dz1[16], dmean[256];
-    if (tid < a.Cp) {
-        float dg = 0.f;
-        for (int p = 0; p < a.parts; ++p) dg += a.dgate_part[((size_t)b * a.parts + p) * a.Cp + tid];
-        const float s = tid < a.C ? gate[tid] / a.y_scale : 0.f;  // sigmoid
-        dz2[tid] = tid < a.C ? dg * a.y_scale * s * (1.0f - s) : 0.f;
+    {   // dgate[c] = sum over the image's tail-backward workgroups: 4 slices of parts x 48 channel quads per pass, 8 loads in flight, slice order fixed
+        float* acc = sm + 8 * 256;  // [4][Cp] (behind ca_squeeze's scratch, which is read-only from here on ... the `part` region is free)
+        const int quads = a.Cp >> 2;
+        if (tid < 4 * quads) {
+            const int sl = tid / quads, q = tid - sl * quads;
+            const float* pp = a.dgate_part + (size_t)b * a.parts * a.Cp + 4 * q;
+            f32x4 s4 = (f32x4)(0.0f);
+            for (int p0 = sl; p0 < a.parts; p0 += 32) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(p0 + 4 * k, a.parts - 1) * a.Cp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (p0 + 4 * k < a.parts) s4 += v[k];
+            }
+            *reinterpret_cast<f32x4*>(acc + sl * a.Cp + 4 * q) = s4;
+        }
+        __syncthreads();
+        if (tid < a.Cp) {
+            const float dg = (acc[tid] + acc[a.Cp + tid]) + (acc[2 * a.Cp + tid] + acc[3 * a.Cp + tid]);
+            const float s = tid < a.C ? gate[tid] / a.y_scale : 0.f;  // sigmoid
+            dz2[tid] = tid < a.C ? dg * a.y_scale * s * (1.0f - s) : 0.f;
+        }
     }
     __syncthreads();
     if (tid < a.Cr) {
@@ -1051,7 +1069,7 @@ extern "C" int sr_tr_ca_bwd(const SrTrCaBwd* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= a.Cp && a.Cp <= 256 && a.Cp % 4 == 0 && a.Cr > 0 && a.Cr <= 8 && a.n_tiles > 0 && a.parts > 0 && a.ld >= a.Cp &&
                    a.ld % 4 == 0 && a.dparam_stride >= 2 * a.Cr * a.C + a.Cr + a.C && a.y_scale != 0.f,
                "sr_tr_ca_bwd: bad geometry");
-    const int slabs = 32;
+    const int slabs = 16;
     hipLaunchKernelGGL(sr_tr_ca_bwd_kernel, dim3(slabs, a.B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_tr_ca_bwd");
     return SR_OK;

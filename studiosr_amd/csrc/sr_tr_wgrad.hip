@@ -10,6 +10,7 @@
 // rows a 32-lane half touches per read fall into eight different 8-bank groups, so every transposed read is conflict-free.
 #include "sr_common.h"
 #include "sr_host.h"
+#include <cmath>
 
 namespace {
 
@@ -225,6 +226,25 @@ __global__ __launch_bounds__(256) void sr_tr_lrelu_bwd_kernel(const bf16* __rest
     for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * ((float)v[e] > 0.f ? 1.0f : slope));
     reinterpret_cast<bf16x8*>(dx)[i] = o;
 }
+// torch.optim.Adam's update (trainer.py:133-139: lr, betas, weight_decay as L2 term; no amsgrad) on the flat parameter / gradient / moment buffers
+__global__ __launch_bounds__(256) void sr_tr_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n4, float lr,
+                                                        float b1, float b2, float eps, float wd, float bc1, float bc2_rsqrt) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    const float step = lr / bc1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gg = gv[e] + wd * pv[e];
+        mv[e] = mv[e] + (gg - mv[e]) * (1.0f - b1);          // lerp, as torch's _foreach_lerp_
+        vv[e] = vv[e] * b2 + gg * gg * (1.0f - b2);
+        const float denom = sqrtf(vv[e]) * bc2_rsqrt + eps;
+        pv[e] -= step * (mv[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+}
 // out = a + b (fp32; b fp32 or bf16): the residual joins of the backward pass
 __global__ __launch_bounds__(256) void sr_tr_add_kernel(const float* __restrict__ a, const void* __restrict__ b, int b_bf16, float* __restrict__ out, long long n4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -309,5 +329,14 @@ extern "C" int sr_tr_add(const float* a, const void* b, int b_dtype, float* out,
     SR_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "sr_tr_add: bad arguments");
     hipLaunchKernelGGL(sr_tr_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, b_dtype == SR_BF16 ? 1 : 0, out, n / 4);
     SR_CHECK_LAUNCH("sr_tr_add");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream) {
+    SR_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step > 0, "sr_tr_adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(sr_tr_adam_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)(1.0 / sqrt(bc2)));
+    SR_CHECK_LAUNCH("sr_tr_adam");
     return SR_OK;
 }

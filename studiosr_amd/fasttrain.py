@@ -944,7 +944,7 @@ class HatPlan:
     def pack(self) -> None:
         """Packed operands <- current parameters (once per optimizer step: the parameter versions decide)."""
         ver = tuple(p._version for p in self.fp.params)
-        if ver != self.packed_version:
+        if self.packed_version is None or ver != self.packed_version:
             self.wa.gather(self.fp.P)
             self.fa.gather(self.fp.P)
             self.packed_version = ver

@@ -159,7 +159,9 @@ class Trainer:
         return psnr, ssim
 
     def build_optimizer(self):
-        opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate, betas=self.betas, weight_decay=self.weight_decay, fused=next(self.model.parameters()).is_cuda)
+        from .optim import Adam  # torch.optim.Adam; one flat launch when the fused training path (fasttrain.py) owns the parameters
+
+        opt = Adam(self.model.parameters(), model=self.model, lr=self.learning_rate, betas=self.betas, weight_decay=self.weight_decay)
         return opt, torch.optim.lr_scheduler.MultiStepLR(opt, milestones=self.milestones, gamma=self.gamma)
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:148-187)

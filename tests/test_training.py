@@ -417,3 +417,40 @@ def test_fused_training_path_guards():
     m.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         assert m(x).shape == (2, 3, 64, 64)
+
+
+def test_flat_adam_equals_torch_adam_on_the_fused_path(tmp_path):
+    """studiosr_amd.optim.Adam: on the fused path one sr_tr_adam launch over the flat buffers; the parameters after three steps equal torch.optim.Adam's
+    (same gradients: the fused step is deterministic), the state_dict round-trips into torch.optim.Adam and back."""
+    from studiosr_amd.optim import Adam
+
+    x, y = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+
+    def run(make_opt, n=3, state=None):
+        m = _default_width_hat()
+        opt = make_opt(m)
+        if state is not None:
+            opt.load_state_dict(state)
+        for _ in range(n):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.l1_loss(m(x).float(), y)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return m, opt
+
+    kw = dict(lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    # ONE step: the gradients of the two runs are the same numbers (only the bias-table gradients carry LDS-atomic ordering noise, and Adam's
+    # first update is lr * g / |g|, so a table entry whose gradient is at that noise level may move by up to 2 lr)
+    m_ref, _ = run(lambda m: torch.optim.Adam(m.parameters(), **kw), n=1)
+    m_one, _ = run(lambda m: Adam(m.parameters(), model=m, **kw), n=1)
+    for (n_, a), b in zip(m_ref.named_parameters(), m_one.parameters()):
+        tol = 2.1 * kw["lr"] if n_.endswith("relative_position_bias_table") else 2e-6 + 1e-5 * float(a.detach().abs().max())
+        assert float((a.detach() - b.detach()).abs().max()) <= tol, n_
+    m_new, o_new = run(lambda m: Adam(m.parameters(), model=m, **kw))
+    assert o_new._flat is not None  # the flat path ran
+    sd = o_new.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    torch.save(sd, tmp_path / "opt.pth")
+    m3, o3 = run(lambda m: torch.optim.Adam(m.parameters(), **kw), n=0, state=torch.load(tmp_path / "opt.pth"))  # loads into torch's Adam
+    assert float(o3.state_dict()["state"][0]["step"]) == 3.0
