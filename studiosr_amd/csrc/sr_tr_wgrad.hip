@@ -122,8 +122,7 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
     const int ones_piece = (j.ones_col >= k0 && j.ones_col < k0 + WG_TK) ? (j.ones_col - k0) >> 3 : -1;
     const int ones_elem = (j.ones_col - k0) & 7;
 
-    bf16x8 ra, rb;
-    auto fetch = [&](int t0) {
+    auto fetch = [&](int t0, bf16x8& ra, bf16x8& rb) {
         const int t = t0 + srow;
         ra = (bf16x8)(0.0f);
         rb = (bf16x8)(0.0f);
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
             }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const bf16x8& ra, const bf16x8& rb) {
         *reinterpret_cast<bf16x8*>(smem + (2 * buf) * WG_TILE + srow * WG_LD + spc * 16) = ra;
         *reinterpret_cast<bf16x8*>(smem + (2 * buf + 1) * WG_TILE + srow * WG_LD + spc * 16) = rb;
     };
@@ -154,13 +153,16 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4)(0.0f);
 
-    fetch(t_beg);
-    stash(0);
+    // the launch is a chain of dependent steps per workgroup (global -> registers -> LDS -> MFMA): operands travel TWO steps ahead in registers
+    bf16x8 ra1, rb1, ra2, rb2;
+    fetch(t_beg, ra1, rb1);
+    stash(0, ra1, rb1);
+    fetch(t_beg + WG_STEP, ra1, rb1);
     __syncthreads();
     int buf = 0;
     for (int t0 = t_beg; t0 < t_end; t0 += WG_STEP) {
         const bool more = t0 + WG_STEP < t_end;
-        if (more) fetch(t0 + WG_STEP);
+        if (t0 + 2 * WG_STEP < t_end) fetch(t0 + 2 * WG_STEP, ra2, rb2);
         const char* ta = smem + (2 * buf) * WG_TILE;
         const char* tb = ta + WG_TILE;
         Frag<bf16> xa[2], yb[2];
@@ -175,7 +177,9 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) mma(xa[a], yb[b], acc[a][b]);
-        if (more) stash(buf ^ 1);
+        if (more) stash(buf ^ 1, ra1, rb1);
+        ra1 = ra2;
+        rb1 = rb2;
         __syncthreads();
         buf ^= 1;
     }

@@ -31,7 +31,7 @@ from . import ops
 Tensor = torch.Tensor
 CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
-WG_KS = 8  # token slices of the weight-gradient GEMMs
+WG_KS = int(os.environ.get("SR_WG_KS", "8"))  # token slices of the weight-gradient GEMMs (A/B knob)
 
 
 def _st():

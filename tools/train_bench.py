@@ -19,11 +19,13 @@ def main():
         b = int(b or 4)
         torch.manual_seed(0)
         m = getattr(S, kind)(scale=4).to(dev).train()
-        opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.99))
+        from studiosr_amd.optim import Adam  # what studiosr_amd.Trainer builds (torch.optim.Adam; one flat launch on the fused path)
+
+        opt = Adam(m.parameters(), model=m, lr=2e-4, betas=(0.9, 0.99))
         x, y = torch.rand(b, 3, 64, 64, device=dev), torch.rand(b, 3, 256, 256, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ac = os.environ.get("AUTOCAST", "1") != "0"  # the reference Trainer's bf16 autocast context (AUTOCAST=0: exact fp32 everywhere)
-        for it in range(4):
+        for it in range(int(os.environ.get("TRAIN_STEPS", "4"))):
             ev[0].record()
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=ac):
                 out = m(x)
