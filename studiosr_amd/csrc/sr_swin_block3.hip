@@ -26,8 +26,8 @@
 
 namespace {
 
-__device__ unsigned long long sr_dbg_sw3[64];
 #ifdef SR_STAMPS
+__device__ unsigned long long sr_dbg_sw3[64];
 #ifndef SR_STAMP_WAVE
 #define SR_STAMP_WAVE 0
 #endif
@@ -432,9 +432,11 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
 
 }  // namespace
 
+#ifdef SR_STAMPS
 extern "C" int sr_debug_sw3_stamps(unsigned long long* host64) {
     return hipMemcpyFromSymbol(host64, HIP_SYMBOL(sr_dbg_sw3), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
+#endif
 
 #ifdef SR_WGTRACE
 extern "C" int sr_debug_sw3_wgtrace(unsigned long long* host, int n) {
@@ -467,6 +469,7 @@ extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_block: bad geometry");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_block: more than 2^31 tokens");
+    SR_REQUIRE(a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "sr_swin_block: the stream rows must be 16-byte aligned (ldx a multiple of 4, x 16-byte aligned)");
     SwinBlock3Dev dv;
     dv.a = a;
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;

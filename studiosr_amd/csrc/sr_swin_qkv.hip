@@ -213,6 +213,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_qkv: bad geometry");
+    SR_REQUIRE(a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "sr_swin_qkv: the stream rows must be 16-byte aligned (ldx a multiple of 4, x 16-byte aligned)");
     SR_REQUIRE(!a.frag_order || (a.ws == 16 && a.oca_pad == 0 && a.hd_p == 32), "sr_swin_qkv: frag_order needs 16 x 16 windows and oca_pad == 0");
     SR_REQUIRE(a.oca_pad == 0 || (a.oca_pad > 0 && a.oca_pad % 4 == 0 && a.shift == 0 && a.y_mode == SR_Y_ROLL), "sr_swin_qkv: OCA layouts need shift 0 and a border that is a multiple of 4");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");

@@ -449,6 +449,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.ldx >= a.Cp &&
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_tail: bad geometry");
+    SR_REQUIRE(a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "sr_swin_tail: the stream rows must be 16-byte aligned (ldx a multiple of 4, x 16-byte aligned)");
     SR_REQUIRE(!a.y || (a.ldy >= a.Cp && a.ldy % 4 == 0), "sr_swin_tail: gated second residual needs ldy");
     SR_REQUIRE(!a.y || a.pool_partial || (a.gate && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate / ld_gate or the pool partials");
     SR_REQUIRE(!a.y || !a.pool_partial || (a.ca_w1 && a.ca_b1 && a.ca_w2 && a.ca_b2 && a.ca_Cr > 0 && a.ca_n_tiles > 0 &&

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import threading
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -18,6 +20,7 @@ from ..runtime import Workspace, compute_dtype, require_device, sr_dtype
 
 Tensor = torch.Tensor
 RGB_MEAN = (0.4488, 0.4371, 0.4040)  # common.py:112,223
+_PREC_TLS = threading.local()  # per-thread precision overrides of inference(): {id(model): precision}
 
 
 class Model(nn.Module):
@@ -136,25 +139,47 @@ class Model(nn.Module):
     def _io_scale(self) -> float:
         return 255.0 if self.img_range == 1.0 else 1.0  # common.py:39
 
-    @torch.inference_mode()
     def _inference_precision(self):
         """Context for inference() / inference_batch() / inference_with_self_ensemble(): precision "auto" outside bf16 autocast runs the
         reference-precision FAST path "fp32x3" (fp32 tensors and op order, every contraction as split-operand bf16 with fp32
         accumulation: max |error| 3e-6 against the exact-fp32 path, i.e. the metric's 1e-3 dB PSNR bar with 4 orders of margin, at 4x
-        (SwinIR) / 2.5x (EDSR) its speed).  `set_precision("fp32")` keeps the exact parity mode; forward() under "auto" is unchanged."""
+        (SwinIR) / 2.5x (EDSR) its speed).  `set_precision("fp32")` keeps the exact parity mode; forward() under "auto" is unchanged.
+        The override is per THREAD (the `precision` property reads it): the model object itself is not modified, so a forward running
+        concurrently on another thread keeps its own precision."""
         model = self
 
         class _Ctx:
             def __enter__(self_inner):
-                self_inner.prev = model.precision
-                if model.precision == "auto" and compute_dtype("auto") == torch.float32:
-                    model.precision = "fp32x3"
+                ov = getattr(_PREC_TLS, "ov", None)
+                if ov is None:
+                    ov = _PREC_TLS.ov = {}
+                self_inner.prev = ov.get(id(model))
+                if model._precision == "auto" and self_inner.prev is None and compute_dtype("auto") == torch.float32:
+                    ov[id(model)] = "fp32x3"
 
             def __exit__(self_inner, *exc):
-                model.precision = self_inner.prev
+                ov = _PREC_TLS.ov
+                if self_inner.prev is None:
+                    ov.pop(id(model), None)
+                else:
+                    ov[id(model)] = self_inner.prev
 
         return _Ctx()
 
+    @property
+    def precision(self) -> str:
+        ov = getattr(_PREC_TLS, "ov", None)
+        if ov:
+            v = ov.get(id(self))
+            if v is not None:
+                return v
+        return self._precision
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        object.__setattr__(self, "_precision", value)
+
+    @torch.inference_mode()
     def inference(self, image: np.ndarray) -> np.ndarray:
         """uint8 HWC -> uint8 HWC (studiosr/models/common.py:36-48): /scale, NCHW, forward, *scale, round-half-even, clip,
         uint8; scale = 255 iff img_range == 1.0.  The uint8 image crosses PCIe as uint8; both conversions are HIP kernels

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, packing
-from ..runtime import compute_dtype, sr_dtype
+from ..runtime import compute_dtype, knob, sr_dtype
 from .common import Model, Upsampler, conv_call, pack_upsampler, run_upsampler
 from .rcan import pack_ca, run_channel_attention
 from .swinir import (
@@ -293,7 +293,7 @@ class HAT(Model):
         # small batches: 4-row conv tiles (twice the workgroups) also for the conv with the pool side output
         th = 4 if (cdt == torch.bfloat16 and ((W + 15) // 16) * ((H + 7) // 8) * B < 256) else 0
         # conv -> GELU -> conv as ONE launch (sr_cab_fused; SR_CAB_FUSED=0: two sr_conv3x3 launches)
-        cab_fused = cdt == torch.bfloat16 and os.environ.get("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, L.SR_BF16)
+        cab_fused = cdt == torch.bfloat16 and knob("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, L.SR_BF16)
         n_tiles = ops.cab_pool_tiles(H, W) if cab_fused else ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th)
         pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
@@ -301,13 +301,13 @@ class HAT(Model):
         # branch and joins before the projection GEMM -- the first writer of t (which may be t_in) and the consumer of the conv branch.
         # Also valid under HIP-graph capture.
         main = torch.cuda.current_stream(t_in.device)
-        side = self._side_stream(t_in.device) if (self.dual_stream and os.environ.get("SR_HAT_DUAL", "1") != "0") else main
+        side = self._side_stream(t_in.device) if (self.dual_stream and knob("SR_HAT_DUAL", "1") != "0") else main
         gate = ws_.get("hab.gate", (B, Cp), f32)
         w1, b1, w2, b2 = bp["ca"]
-        gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and os.environ.get("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
+        gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and knob("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
         # the tail kernel goes on with the next block's LayerNorm1 + QKV (its attention kernel is the next launch of the chain)
         fuse_next_qkv = (unfused and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
-                         and os.environ.get("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
+                         and knob("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
 
         def conv_branch():
             with torch.cuda.stream(side):
@@ -331,7 +331,7 @@ class HAT(Model):
         # beside the attention kernel) is the longer one and is created first (default); SR_HAT_SIDE_FIRST=0 creates the attention branch first
         # and enqueues the conv branch from the projection hook.  Measured on two boxes (HAT x4 b4, ms): fused QKV + conv first 3.42 / 3.43,
         # fused + attention first 3.59 / 3.62, separate QKV + conv first 3.83 / 3.36, separate + attention first 3.85 / 3.42.
-        late = unfused and side is not main and os.environ.get("SR_HAT_SIDE_FIRST", "1") == "0"
+        late = unfused and side is not main and knob("SR_HAT_SIDE_FIRST", "1") == "0"
         fork = None
         if late:
             fork = torch.cuda.Event()

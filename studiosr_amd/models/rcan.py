@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, packing
-from ..runtime import compute_dtype, sr_dtype
+from ..runtime import capturing_or_warming_up, compute_dtype, sr_dtype
 from .common import Model, Upsampler, conv2d, conv_call, pack_upsampler, run_upsampler
 from .edsr import MeanShift, mean_shift_affine
 
@@ -165,7 +165,7 @@ class RCAN(Model):
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
         # part batches on several streams pay off only when the launches cost no CPU time, i.e. inside a HIP-graph capture: an eager forward
         # is launch-bound at 4 x 222 launches (b16 eager: 12.5 ms with four parts, 7.2 with two, 6.4 with one)
-        if self.pipeline_halves and B >= 16 and B % 2 == 0 and (torch.cuda.is_current_stream_capturing() or os.environ.get("SR_RCAN_PARTS")):
+        if self.pipeline_halves and B >= 16 and B % 2 == 0 and (capturing_or_warming_up() or os.environ.get("SR_RCAN_PARTS")):
             # Every RCAB launch is whole residency rounds whose load, MFMA and store phases run one after the other chip-wide; two half
             # batches on two streams are out of phase, so one's HBM phases run under the other's MFMAs.  Measured (tools/rcan_ab.py,
             # same box): b8 4.81 -> 5.58 ms (worse: off below 16), b16 6.43 -> 6.04 ms, b32 12.08 -> 9.13 ms.

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, packing
-from ..runtime import compute_dtype, sr_dtype
+from ..runtime import capturing_or_warming_up, compute_dtype, knob, sr_dtype
 from .common import RGB_MEAN, Model, Upsampler, conv_call, pack_upsampler, run_upsampler
 
 Tensor = torch.Tensor
@@ -179,19 +179,19 @@ def pack_qkv_stream(attn: nn.Module, norm1: nn.Module, geo: SwinGeometry, dt: to
 
 def swin_qkv_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_QKV=0 keeps the QKV GEMM (A/B switch, read per call)."""
-    return ("qkv_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_QKV", "1") != "0"
+    return ("qkv_stream" in p and cdt == torch.bfloat16 and knob("SR_SWIN_QKV", "1") != "0"
             and ops.swin_qkv_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, L.SR_BF16))
 
 
 def qkv_frag_order(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """q / k / v^T between sr_swin_qkv (or sr_swin_tail's fused QKV stage) and sr_window_attention in FRAGMENT order (every operand fragment of the attention
     kernel = one coalesced 1-KiB load): 16 x 16 windows, bf16, stream-form producer.  SR_QKV_FRAG=0 keeps the row-major layouts."""
-    return geo.ntok == 256 and geo.hd_p == 32 and swin_qkv_usable(p, geo, Cp, cdt) and os.environ.get("SR_QKV_FRAG", "1") != "0"
+    return geo.ntok == 256 and geo.hd_p == 32 and swin_qkv_usable(p, geo, Cp, cdt) and knob("SR_QKV_FRAG", "1") != "0"
 
 
 def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_TAIL=0 keeps the projection GEMM + MLP kernel (A/B switch, read per call)."""
-    return ("tail_stream" in p and cdt == torch.bfloat16 and os.environ.get("SR_SWIN_TAIL", "1") != "0"
+    return ("tail_stream" in p and cdt == torch.bfloat16 and knob("SR_SWIN_TAIL", "1") != "0"
             and ops.swin_tail_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, L.SR_BF16))
 
 
@@ -469,7 +469,7 @@ class SwinIR(Model):
         # x-fetch / store / convolution phases run under the other's MFMAs (what bench.py's two batches in flight do across steps).  Eager
         # forwards stay one launch sequence (they are launch-bound).  SR_SWIN_PARTS: 1 = off (default), 2 = two half batches.
         parts = int(os.environ.get("SR_SWIN_PARTS", "1"))
-        if parts > 1 and B % parts == 0 and B // parts >= 2 and x.is_cuda and torch.cuda.is_current_stream_capturing():
+        if parts > 1 and B % parts == 0 and B // parts >= 2 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
             main = torch.cuda.current_stream(x.device)

@@ -21,6 +21,21 @@ def require_device(x: Tensor) -> None:
     L.lib()  # raises if libstudiosr_hip.so is missing
 
 
+_KNOBS: Dict[str, str] = {}
+
+
+def knob(name: str, default: str) -> str:
+    """An A/B environment switch (SR_SWIN_QKV, SR_QKV_FRAG, SR_SWIN_TAIL, SR_TAIL_QKV, ...), read ONCE per forward: the launches of one forward must
+    agree on the layouts they hand each other (a tail kernel writes the next block's q / k / v^T in the layout that block's attention launch
+    will assume), so a variable that changes mid-forward (A/B tooling does that) must not split them.  Workspace.begin_forward() re-arms the reads."""
+    v = _KNOBS.get(name)
+    if v is None:
+        import os
+
+        v = _KNOBS[name] = os.environ.get(name, default)
+    return v
+
+
 X3_KEY = "bf16x3"  # key of the split-operand weight packing
 _x3_depth = 0      # > 0 while a forward with precision "fp32x3" is enqueueing (one forward at a time per process: SURVEY 8b)
 
@@ -96,6 +111,7 @@ class Workspace:
     def begin_forward(self) -> None:
         """Called once at the start of every forward: buffers requested from here on belong to this forward."""
         self.epoch += 1
+        _KNOBS.clear()
 
     @staticmethod
     def _nbytes(shape, dtype) -> int:
@@ -168,6 +184,16 @@ class WorkspaceView:
         return self.ws.get(self.prefix + name, shape, dtype)
 
 
+_capture_warmup = 0  # > 0 while GraphedForward runs its eager warm-up calls
+
+
+def capturing_or_warming_up() -> bool:
+    """True inside a HIP-graph capture AND inside GraphedForward's eager warm-up: a forward that takes another launch sequence under capture
+    (part batches on several streams) must take it in the warm-up too, so that its workspace buffers exist before the capture begins
+    (a buffer first requested inside a capture is a zero-fill node replayed with the graph, in the graph's private pool)."""
+    return _capture_warmup > 0 or torch.cuda.is_current_stream_capturing()
+
+
 class GraphedForward:
     """Capture `fn(static_input) -> static_output` once into a HIP graph and replay it.
 
@@ -181,9 +207,14 @@ class GraphedForward:
         self.static_in = example.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                fn(self.static_in)
+        global _capture_warmup
+        _capture_warmup += 1
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    fn(self.static_in)
+        finally:
+            _capture_warmup -= 1
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
