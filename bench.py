@@ -107,6 +107,20 @@ def profiled_clock_ghz():
     return None
 
 
+DOMINANT_KERNEL_SOURCES = ("studiosr_amd/csrc/sr_swin_block3.hip", "studiosr_amd/csrc/sr_swin_stream.h", "studiosr_amd/csrc/sr_common.h")
+
+
+def dominant_kernel_src_sha16() -> str:
+    """sha256[:16] over the sources of the dominant kernel (sr_swin_block3_kernel): a committed PMC profile is only quoted while it still
+    describes this code (tools/profile_bench.sh writes the hash into the profile's first line)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in DOMINANT_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profiled_hbm_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_bench_hbm_counters.txt,
     collected by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KiB per dispatch).  gfx950 correction
@@ -118,8 +132,11 @@ def profiled_hbm_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_hbm_counters.txt")))
     if not files:
         return None
-    vals, key = {}, None
+    vals, key, prof_sha = {}, None, None
     for line in open(files[-1]):
+        m0 = re.match(r"#\s*kernel_src_sha16\s*=\s*([0-9a-f]+)", line)
+        if m0:
+            prof_sha = m0.group(1)
         if line.startswith("("):
             key = ("swin_block3_kernel" in line or "swin_block_kernel<true>" in line) and ", 648)" in line
         elif key:
@@ -128,8 +145,10 @@ def profiled_hbm_traffic():
                 vals[m.group(1)] = float(m.group(2))
     if len(vals) != 2:
         return None
-    return dict(bytes=int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), source=os.path.relpath(files[-1], ROOT),
-                fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"])
+    cur = dominant_kernel_src_sha16()
+    stale = prof_sha != cur  # (a profile without the hash line predates round 4: stale by definition)
+    return dict(bytes=None if stale else int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), source=os.path.relpath(files[-1], ROOT),
+                fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"], profile_kernel_src_sha16=prof_sha, kernel_src_sha16=cur, stale=stale)
 
 
 def cpu_model_string() -> str:

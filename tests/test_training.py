@@ -454,3 +454,49 @@ def test_flat_adam_equals_torch_adam_on_the_fused_path(tmp_path):
     torch.save(sd, tmp_path / "opt.pth")
     m3, o3 = run(lambda m: torch.optim.Adam(m.parameters(), **kw), n=0, state=torch.load(tmp_path / "opt.pth"))  # loads into torch's Adam
     assert float(o3.state_dict()["state"][0]["step"]) == 3.0
+
+
+def test_fused_training_path_under_ddp_two_ranks_gloo(tmp_path):
+    """trainer.py:89-91 with the fused path: DistributedDataParallel around a default-width HAT under autocast, two ranks (both on this GPU, gloo).
+    The one autograd node of the fused step returns every parameter gradient as a view of the flat buffer; DDP's reducer must see all of them
+    (its hooks fire) and the averaged gradients must equal the mean of the two single-process fused gradients."""
+    script = tmp_path / "ddp_fused.py"
+    script.write_text(f"""
+import os, sys, torch, torch.distributed as dist, torch.nn.functional as F
+sys.path.insert(0, {ROOT!r})
+import studiosr_amd as S
+from torch.nn.parallel import DistributedDataParallel as DDP
+rank = int(os.environ["RANK"]); dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+torch.manual_seed(0)
+m = S.HAT(scale=2, depths=[1], num_heads=[6], drop_path_rate=0.0).to(dev).train()
+g = torch.Generator().manual_seed(5)
+x, t = torch.rand(4, 3, 32, 32, generator=g).to(dev), torch.rand(4, 3, 64, 64, generator=g).to(dev)
+def step(net, xs, ts):
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = F.l1_loss(net(xs).float(), ts)
+    loss.backward()
+single = []
+for r in range(2):
+    m.zero_grad(set_to_none=True)
+    step(m, x[2 * r: 2 * r + 2], t[2 * r: 2 * r + 2])
+    single.append([p.grad.clone() for p in m.parameters()])
+assert m._fast_plan is not None and m._fast_plan.full
+m.zero_grad(set_to_none=True)
+ddp = DDP(m, device_ids=[0])
+step(ddp, x[2 * rank: 2 * rank + 2], t[2 * rank: 2 * rank + 2])
+worst = 0.0
+for (n, p), a, b in zip(m.named_parameters(), *single):
+    ref = (a + b) / 2
+    tol = 5e-2 if n.endswith("relative_position_bias_table") else 1e-4  # (the table gradient carries LDS-atomic ordering noise)
+    e = float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-9)
+    assert e < tol, (n, e)
+    worst = max(worst, e)
+dist.barrier(); dist.destroy_process_group(); print("DDP_OK", worst)
+""")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29627", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.count("DDP_OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]

@@ -15,8 +15,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import studiosr_amd as S  # noqa: E402
 from studiosr_amd.runtime import GraphedForward  # noqa: E402
 
-GFLOP_PER_TILE = {"EDSR": 411.67, "SwinIR": 135.56, "RCAN": 130.40, "HAT": 207.76}  # BASELINE.md section 2 (64x64 LR tile, x4)
-CASES = {"EDSR": 16, "SwinIR": 8, "RCAN": 16, "HAT": 4}
+GFLOP_PER_TILE = {"EDSR": 411.67, "SwinIR": 135.56, "RCAN": 130.40, "HAT": 207.76,  # BASELINE.md section 2 (64x64 LR tile, x4)
+                  # the reference's other shipped SwinIR (from_pretrained(light=True), swinir.py:418-427: embed 60, 4 x 6 blocks, pixelshuffledirect), 72 x 72
+                  # padded tokens: per token 24 x (qkv 21,600 + attention 15,360 + proj 7,200 + mlp 28,800) + convs 379,080 = 2.13 MFLOP
+                  "SwinIR-light": 11.04}
+CASES = {"EDSR": 16, "SwinIR": 8, "RCAN": 16, "HAT": 4, "SwinIR-light": 8}
+
+
+def build(kind: str):
+    if kind == "SwinIR-light":
+        return S.SwinIR(scale=4, embed_dim=60, depths=[6, 6, 6, 6], num_heads=[6, 6, 6, 6], upsampler="pixelshuffledirect")
+    return getattr(S, kind)(scale=4)
 
 
 def main():
@@ -28,7 +37,7 @@ def main():
         B = int(parts[1]) if len(parts) > 1 and parts[1] else CASES[kind]
         inflight = int(parts[2]) if len(parts) > 2 else 1
         torch.manual_seed(0)
-        m = getattr(S, kind)(scale=4).eval().to(dev).set_precision("bf16")
+        m = build(kind).eval().to(dev).set_precision("bf16")
         x = torch.rand(B, 3, 64, 64, device=dev)
         with torch.no_grad():
             pipes = []

@@ -17,7 +17,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmc_write" -o ben
 cd "$ROOT"
 python3 tools/trace_summary.py "$OUT/${TAG}_trace" > "$OUT/${TAG}_bench_kernel_trace_summary.txt"
 python3 tools/trace_summary.py "$OUT/${TAG}_trace1" > "$OUT/${TAG}_bench_inflight1_kernel_trace_summary.txt"
-{ python3 tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch"; python3 tools/pmc_summary.py "$OUT/${TAG}_pmc_write"; } > "$OUT/${TAG}_bench_hbm_counters.txt"
+# first line: what the dominant kernel's source looked like when the counters were taken (bench.py refuses a profile whose hash differs from the tree's)
+{ echo "# kernel_src_sha16 = $(python3 -c 'import bench; print(bench.dominant_kernel_src_sha16())')"; python3 tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch"; python3 tools/pmc_summary.py "$OUT/${TAG}_pmc_write"; } > "$OUT/${TAG}_bench_hbm_counters.txt"
 find "$OUT/${TAG}_trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/${TAG}_bench_kernel_stats.csv" \;
 # the raw traces are large; keep only the summaries
 rm -rf "$OUT/${TAG}_trace" "$OUT/${TAG}_trace1" "$OUT/${TAG}_pmc_fetch" "$OUT/${TAG}_pmc_write"
