@@ -488,6 +488,8 @@ typedef struct SrTrWgradJob {
     const void* A; const void* B; float* out;
     int lda, ldb, Np, Kp, T, taps, H, W, ones_col, ks;
     int a_f32, b_f32;   /* 1: that operand is fp32 (rounded to bf16 while it is staged), 0: bf16 */
+    int halo;           /* taps 9 only, H % 4 == 0, W % 8 == 0: steps are 4 x 8-pixel patches whose 6 x 10 halo of B is staged ONCE for all nine taps
+                         * (same result; a sixth of the operand traffic) */
 } SrTrWgradJob;
 int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream); /* jobs: HOST array, at most 8 per launch */
 long long sr_tr_wgrad_out_floats(const SrTrWgradJob* j);

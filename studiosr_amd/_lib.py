@@ -155,7 +155,7 @@ class SrBgemm(C.Structure):
 # ---- fast training path (ABI v7)
 class SrTrWgradJob(C.Structure):
     _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("lda", _i), ("ldb", _i), ("Np", _i), ("Kp", _i), ("T", _i), ("taps", _i), ("H", _i), ("W", _i),
-                ("ones_col", _i), ("ks", _i), ("a_f32", _i), ("b_f32", _i)]
+                ("ones_col", _i), ("ks", _i), ("a_f32", _i), ("b_f32", _i), ("halo", _i)]
 
 
 class SrTrAttnBwd(C.Structure):

@@ -75,20 +75,148 @@ struct WgradJobs {
 };
 
 // 8 bytes of a transposed fragment: for 16-lane group g, block rows r0 .. r0+3, columns c0 .. c0+15 of a row-major bf16 tile -> lane i gets column c0 + i
+template <int LD = WG_LD>
 SR_DEV s16x4 tr_read(const char* tile, int r0, int c0, int lane) {
     const int i = lane & 15, q = i >> 2, p = i & 3;
-    auto* ptr = (__attribute__((address_space(3))) s16x4*)(tile + (r0 + q) * WG_LD + (c0 + 4 * p) * 2);
+    auto* ptr = (__attribute__((address_space(3))) s16x4*)(tile + (r0 + q) * LD + (c0 + 4 * p) * 2);
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(ptr);
+}
+SR_DEV Frag<bf16> frag2(const s16x4& a, const s16x4& b) {
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    return f;
+}
+
+// ---- 3x3 weight gradient on 2-D pixel patches: all nine taps from ONE staged halo tile.
+// The generic path above treats a tap as a row shift of B and re-reads both operands per tap (43 % of a HAB's weight-gradient traffic).  Here a
+// step is a 4 x 8-pixel patch: A (dy, 32 pixels x 32 output channels) and B's 6 x 10-pixel halo (x, 60 pixels x 64 input channels) are staged
+// once and every tap's operand is 4 CONSECUTIVE halo rows of the same LDS tile for each k-group (k-group g = pixels (row g >> 1, x 4 (g & 1) ..) and two
+// rows below: 8 consecutive halo rows per 32-lane half, conflict-free at the 160-byte stride).  Workgroup tile 32 n x 64 k x 9 taps, wave tile
+// 16 x 32 x 9 (72 accumulator registers); 18 MFMAs per wave and step against 11.6 KB of staged operands (generic path: 4 against 8 KB).
+constexpr int HC_PH = 4, PW_ = 8, HC_HW = 10, HC_HROWS = 60;
+constexpr int HC_LDA = 96;                        // A tile row stride (32 bf16 + 32 B)
+constexpr int HC_TA = 32 * HC_LDA, HC_TB = HC_HROWS * WG_LD;
+constexpr int HC_BUF = HC_TA + HC_TB;
+static_assert(2 * HC_BUF <= 4 * WG_TILE + 8192, "halo path LDS");
+
+SR_DEV void wgrad_conv_halo(const SrTrWgradJob& j, int rem, int tiles_n, int tiles_k, char* smem) {
+    const int tk = rem % tiles_k;
+    rem /= tiles_k;
+    const int tn = rem % tiles_n;
+    const int slice = rem / tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lg = lane >> 4;
+    const int npx = j.W / PW_, npy = j.H / HC_PH, npi = npx * npy;
+    const int total = (j.T / (j.H * j.W)) * npi;
+    const int chunk = (total + j.ks - 1) / j.ks;
+    const int p_beg = slice * chunk, p_end = min(total, p_beg + chunk);
+    const int n0 = tn * 32, k0 = tk * 64;
+    const bf16* A = reinterpret_cast<const bf16*>(j.A);
+    const bf16* Bm = reinterpret_cast<const bf16*>(j.B);
+    const float* Af = reinterpret_cast<const float*>(j.A);
+    const float* Bf = reinterpret_cast<const float*>(j.B);
+    auto load8 = [](const float* p) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p), v = *reinterpret_cast<const f32x4*>(p + 4);
+        bf16x8 r;
+        r[0] = (bf16)u[0]; r[1] = (bf16)u[1]; r[2] = (bf16)u[2]; r[3] = (bf16)u[3];
+        r[4] = (bf16)v[0]; r[5] = (bf16)v[1]; r[6] = (bf16)v[2]; r[7] = (bf16)v[3];
+        return r;
+    };
+    // staging roles: A: thread t < 128 -> (pixel t >> 2, 16-byte piece t & 3); B: pieces q = t, t + 256 < 480 -> (halo pixel q >> 3, piece q & 7)
+    const int a_px = tid >> 2, a_pc = tid & 3;
+    const bool a_on = tid < 128 && n0 + a_pc * 8 < j.Np;
+    const int ones_piece = (j.ones_col >= k0 && j.ones_col < k0 + 64) ? (j.ones_col - k0) >> 3 : -1;
+    const int ones_elem = (j.ones_col - k0) & 7;
+    bf16x8 ra, rb[2];
+    auto fetch = [&](int p) {
+        ra = (bf16x8)(0.0f);
+        rb[0] = rb[1] = (bf16x8)(0.0f);
+        if (p >= p_end) return;
+        const int b = p / npi, pp = p - b * npi, py = pp / npx, px = pp - py * npx;
+        const int y0 = py * HC_PH, x0 = px * PW_;
+        const size_t img = (size_t)b * j.H * j.W;
+        if (a_on) {
+            const size_t row = img + (size_t)(y0 + (a_px >> 3)) * j.W + x0 + (a_px & 7);
+            ra = j.a_f32 ? load8(Af + row * j.lda + n0 + a_pc * 8) : *reinterpret_cast<const bf16x8*>(A + row * j.lda + n0 + a_pc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u;
+            if (q >= HC_HROWS * 8) continue;
+            const int hp = q >> 3, pc = q & 7;
+            const int y = y0 + hp / HC_HW - 1, x = x0 + hp % HC_HW - 1;
+            if (y < 0 || y >= j.H || x < 0 || x >= j.W) continue;
+            const size_t row = img + (size_t)y * j.W + x;
+            if (k0 + pc * 8 < j.Kp) rb[u] = j.b_f32 ? load8(Bf + row * j.ldb + k0 + pc * 8) : *reinterpret_cast<const bf16x8*>(Bm + row * j.ldb + k0 + pc * 8);
+            if (pc == ones_piece) rb[u][ones_elem] = (bf16)1.0f;
+        }
+    };
+    auto stash = [&](int buf) {
+        char* base = smem + buf * HC_BUF;
+        if (tid < 128) *reinterpret_cast<bf16x8*>(base + a_px * HC_LDA + a_pc * 16) = ra;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u;
+            if (q < HC_HROWS * 8) *reinterpret_cast<bf16x8*>(base + HC_TA + (q >> 3) * WG_LD + (q & 7) * 16) = rb[u];
+        }
+    };
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = (f32x4)(0.0f);
+    const int wn = w & 1, wk = w >> 1;
+    // k-group lg: pixels (row lg >> 1, x 4 (lg & 1) .. + 3) and the same two rows below
+    const int gy = lg >> 1, gx = 4 * (lg & 1);
+    fetch(p_beg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int p = p_beg; p < p_end; ++p) {
+        const bool more = p + 1 < p_end;
+        if (more) fetch(p + 1);
+        const char* ta = smem + buf * HC_BUF;
+        const char* tb = ta + HC_TA;
+        const Frag<bf16> xa = frag2(tr_read<HC_LDA>(ta, gy * PW_ + gx, wn * 16, lane), tr_read<HC_LDA>(ta, (gy + 2) * PW_ + gx, wn * 16, lane));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r0 = (gy + t / 3) * HC_HW + gx + t % 3;  // halo row of pixel (gy, gx) shifted by tap t (offset (t / 3 - 1, t % 3 - 1), halo origin (-1, -1))
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Frag<bf16> yb = frag2(tr_read(tb, r0, wk * 32 + 16 * i, lane), tr_read(tb, r0 + 2 * HC_HW, wk * 32 + 16 * i, lane));
+                mma(xa, yb, acc[t][i]);
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = j.out + ((size_t)(slice * 9 + t) * j.Np) * j.Kp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + wk * 32 + 16 * i + (lane & 15);
+            if (k >= j.Kp) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 16 + 4 * lg + r;
+                if (n < j.Np) out[(size_t)n * j.Kp + k] = acc[t][i][r];
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * WG_TILE];  // [buffer][operand]
+    __shared__ __attribute__((aligned(16))) char smem[2 * HC_BUF > 4 * WG_TILE ? 2 * HC_BUF : 4 * WG_TILE];  // generic: [buffer][operand]; halo path: [buffer][A | B halo]
     int jb = 0;
 #pragma unroll
     for (int i = 1; i < WG_MAXJOBS; ++i)
         if (i < J.n && (int)blockIdx.x >= J.wg0[i]) jb = i;
     const SrTrWgradJob& j = J.j[jb];
     int rem = blockIdx.x - J.wg0[jb];
+    if (j.halo) {  // (job-uniform branch)
+        wgrad_conv_halo(j, rem, J.tiles_n[jb], J.tiles_k[jb], smem);
+        return;
+    }
     const int tk = rem % J.tiles_k[jb];
     rem /= J.tiles_k[jb];
     const int tn = rem % J.tiles_n[jb];
@@ -298,10 +426,17 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
         SR_REQUIRE((((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0, "sr_tr_wgrad: operands must be 16-byte aligned");
         SR_REQUIRE((j.a_f32 == 0 || j.a_f32 == 1) && (j.b_f32 == 0 || j.b_f32 == 1), "sr_tr_wgrad: a_f32 / b_f32 are flags");
         J.j[i] = j;
-        J.tiles_n[i] = (j.Np + WG_TN - 1) / WG_TN;
-        J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
+        SR_REQUIRE(!j.halo || (j.taps == 9 && j.H % 4 == 0 && j.W % 8 == 0), "sr_tr_wgrad: the halo form needs 9 taps, H %% 4 == 0, W %% 8 == 0");
         J.wg0[i] = wg;
-        wg += J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
+        if (j.halo) {
+            J.tiles_n[i] = (j.Np + 31) / 32;
+            J.tiles_k[i] = (j.Kp + 63) / 64;
+            wg += J.tiles_n[i] * J.tiles_k[i] * j.ks;
+        } else {
+            J.tiles_n[i] = (j.Np + WG_TN - 1) / WG_TN;
+            J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
+            wg += J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
+        }
     }
     J.wg0[njobs] = wg;
     for (int i = njobs; i < WG_MAXJOBS; ++i) {

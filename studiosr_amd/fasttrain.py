@@ -412,17 +412,6 @@ class BlockPlan:
         self.f_fc2 = fm.alloc(ks * CP * HP)
         fm.put(fp.pidx(mlp.fc2.weight), self.f_fc2 + np.arange(C_REAL)[:, None] * HP + np.arange(HID)[None, :], CP * HP, ks)
         fm.put(fp.pidx(mlp.fc2.bias), self.f_fc2 + np.arange(C_REAL) * HP + HID, CP * HP, ks)
-        if self.cab is not None:  # CAB convs: out [ks][9][Np][Kp]
-            cab = self.cab
-            c3 = cab[0].weight.shape[0]
-            self.f_c1 = fm.alloc(ks * 9 * 64 * CP)
-            co, ci, tp = np.arange(c3)[:, None, None], np.arange(C_REAL)[None, :, None], np.arange(9)[None, None, :]
-            fm.put(fp.pidx(cab[0].weight).reshape(c3, C_REAL, 9), self.f_c1 + (tp * 64 + co) * CP + ci, 9 * 64 * CP, ks)
-            fm.put(fp.pidx(cab[0].bias), self.f_c1 + (4 * 64 + np.arange(c3)) * CP + C_REAL, 9 * 64 * CP, ks)  # centre tap, the ones channel of n1
-            self.f_c2 = fm.alloc(ks * 9 * CP * 64)
-            co, ci = np.arange(C_REAL)[:, None, None], np.arange(c3)[None, :, None]
-            fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
-            fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
 
     def prepare(self, B: int, H: int, W: int, dev, groups: int) -> None:
         """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images; static activations."""
@@ -434,6 +423,17 @@ class BlockPlan:
             fm.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
             fm.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
         if self.cab is not None:
+            cab, ks = self.cab, conv_ks(B, H, W)  # CAB convs: out [ks][9][Np][Kp]
+            self.ks_conv = ks
+            c3 = cab[0].weight.shape[0]
+            self.f_c1 = fm.alloc(ks * 9 * 64 * CP)
+            co, ci, tp = np.arange(c3)[:, None, None], np.arange(C_REAL)[None, :, None], np.arange(9)[None, None, :]
+            fm.put(fp.pidx(cab[0].weight).reshape(c3, C_REAL, 9), self.f_c1 + (tp * 64 + co) * CP + ci, 9 * 64 * CP, ks)
+            fm.put(fp.pidx(cab[0].bias), self.f_c1 + (4 * 64 + np.arange(c3)) * CP + C_REAL, 9 * 64 * CP, ks)  # centre tap, the ones channel of n1
+            self.f_c2 = fm.alloc(ks * 9 * CP * 64)
+            co, ci = np.arange(C_REAL)[:, None, None], np.arange(c3)[None, :, None]
+            fm.put(fp.pidx(cab[2].weight).reshape(C_REAL, c3, 9), self.f_c2 + (tp * CP + co) * 64 + ci, 9 * CP * 64, ks)
+            fm.put(fp.pidx(cab[2].bias), self.f_c2 + (4 * CP + np.arange(C_REAL)) * 64 + c3, 9 * CP * 64, ks)    # ones_col = c3
             ca = self.ca_mod
             cr = ca[1].weight.shape[0]
             self.ca_stride = (2 * cr * C_REAL + cr + C_REAL + 63) // 64 * 64
@@ -536,8 +536,8 @@ class BlockPlan:
             L.check(lib.sr_tr_gelu(sc.mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
             _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
             jobs += [
-                dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=ks),
-                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=ks),
+                dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
+                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
             ]
         _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
               dn1c=None if self.oca else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
@@ -576,11 +576,23 @@ def _conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, B: int, H:
                 out_scale=1.0, out_mode=L.OUT_NHWC, ps_r=0, cps_p=0, act_slope=0.0, tile_rows=0)
 
 
+def conv_ks(B: int, H: int, W: int) -> int:
+    """Token slices of a 3x3 weight-gradient job: the halo form runs few, MFMA-dense workgroups whose steps (one 4 x 8 patch each) are a dependent
+    chain, so a slice gets ~16 steps instead of the generic form's T / 8 / 32."""
+    if HALO and H % 4 == 0 and W % 8 == 0:
+        return max(WG_KS, min(256, (B * H * W // 32) // int(os.environ.get("SR_WG_HALO_STEPS", "16"))))
+    return WG_KS
+
+
+HALO = os.environ.get("SR_WG_HALO", "1") != "0"  # A/B knob: 3x3 weight gradients on 2-D patches with one staged halo for all nine taps
+
+
 def _wgrad(jobs: List[dict]) -> None:
     arr = (L.SrTrWgradJob * len(jobs))()
     for a, j in zip(arr, jobs):
         for k, v in j.items():
             setattr(a, k, v)
+        a.halo = int(HALO and j.get("taps") == 9 and j["H"] % 4 == 0 and j["W"] % 8 == 0)
     L.check(L.lib().sr_tr_wgrad(arr, len(jobs), _st()), "sr_tr_wgrad")
 
 
@@ -690,7 +702,12 @@ class ConvPlan:
             r2[:cout_p] = rows
             self.o_wt = wa.add(pack_conv(fp, w, self.dg_in, cin_p, transpose=True, rows=r2))
         self.o_b = fa.add(pack_vec(fp, b, cout_p, rows))
-        ks = WG_KS
+        self.fp, self.w, self.b, self.rows = fp, w, b, rows
+
+    def prepare(self, fm: FinalMap, B: int, H: int, W: int) -> None:
+        """Gradient map of this conv's weight-gradient job at its (own) geometry: [ks][9][cout_p][cin_p] partial sums."""
+        fp, w, b, rows, cout, cin, cout_p, cin_p = self.fp, self.w, self.b, self.rows, self.cout, self.cin, self.cout_p, self.cin_p
+        ks = self.ks = conv_ks(B, H, W)
         n_of = np.zeros(cout, dtype=np.int64)
         n_of[rows[rows >= 0]] = np.nonzero(rows >= 0)[0]
         self.f_w = fm.alloc(ks * 9 * cout_p * cin_p)
@@ -700,8 +717,8 @@ class ConvPlan:
             self.ones_col, self.f_b = cin, None
             fm.put(fp.pidx(b), self.f_w + (4 * cout_p + n_of) * cin_p + cin, 9 * cout_p * cin_p, ks)
         else:            # no spare input channel: a second job against a constant-one operand
-            self.ones_col, self.f_b = -1, fm.alloc(ks * cout_p * 8)
-            fm.put(fp.pidx(b), self.f_b + n_of * 8, cout_p * 8, ks)
+            self.ones_col, self.f_b = -1, fm.alloc(WG_KS * cout_p * 8)
+            fm.put(fp.pidx(b), self.f_b + n_of * 8, cout_p * 8, WG_KS)
 
     def fwd(self, plan, x: Tensor, out: Tensor, B: int, H: int, W: int, *, act: int = L.ACT_NONE, skip: Optional[Tensor] = None, out_mode: int = L.OUT_NHWC, ps_r: int = 0,
             cps_p: int = 0, fin=None) -> None:
@@ -723,7 +740,7 @@ class ConvPlan:
         T = B * H * W
         f32 = torch.float32
         jobs = [dict(A=dy.data_ptr(), B=x.data_ptr(), out=pp(self.f_w), lda=lda, ldb=self.cin_p, Np=self.cout_p, Kp=self.cin_p, T=T, taps=9, H=H, W=W, ones_col=self.ones_col,
-                     ks=WG_KS, a_f32=int(dy.dtype == f32), b_f32=int(x.dtype == f32))]
+                     ks=self.ks, a_f32=int(dy.dtype == f32), b_f32=int(x.dtype == f32))]
         if self.f_b is not None:
             jobs.append(dict(A=dy.data_ptr(), B=plan.ones.data_ptr(), out=pp(self.f_b), lda=lda, ldb=8, Np=self.cout_p, Kp=8, T=T, taps=1, H=H, W=W, ones_col=-1, ks=WG_KS,
                              a_f32=int(dy.dtype == f32), b_f32=0))
@@ -816,6 +833,14 @@ class HatPlan:
         self.scratch = Scratch(B, H, W, dev, groups)
         for s in self.stages:
             s.prepare(B, H, W, dev, self.scratch)
+        self.c_first.prepare(fm, B, H, W)
+        for c in self.c_layers + [self.c_after, self.c_before]:
+            c.prepare(fm, B, H, W)
+        h, w = H, W
+        for cp, r, _ in self.c_up:
+            cp.prepare(fm, B, h, w)
+            h, w = h * r, w * r
+        self.c_last.prepare(fm, B, h, w)
         # LayerNorm partials of patch_embed.norm / norm
         nwg = B * H * W // 64
         self.f_pe, self.f_nm = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
