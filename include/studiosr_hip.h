@@ -142,6 +142,23 @@ typedef struct SrSwinBlock {
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);
 
+typedef struct SrSwinLight {
+    /* The WHOLE SwinTransformerBlock (swinir.py:146-174) of the reference's lightweight SwinIR geometry (SwinIR.from_pretrained(light=True),
+     * swinir.py:418-427: embed_dim 60, 6 heads of 10, window 8, hidden 120) in ONE launch, ABI v7: one window per 4-wave workgroup, padded sizes
+     * 64 channels / 16 features per head / 128 hidden.  Weights in fragment order (packing.to_fragments), LayerNorm affines folded into the
+     * following Linear, attention scale in the q rows: wqkv [288 x 64] with row part * 96 + head * 16 + d, wproj [64 x 96] (column head * 16 + d),
+     * w1 [128 x 64], w2 [64 x 128]; biases fp32, zero in the pads; bias = relative-position bias in accumulator-fragment order
+     * [heads][4][4][64][4] (packing.bias_fragments).  bf16 operands, fp32 stream / statistics / softmax; out may alias x. */
+    const float* x; float* out;
+    const void* wqkv; const float* bqkv; const void* wproj; const float* bproj; const void* w1; const float* b1; const void* w2; const float* b2;
+    const float* bias;
+    int B, H, W, C, ldx, shift;
+    float eps;
+    int y_mode;            /* SR_Y_* */
+} SrSwinLight;
+int sr_swin_light_supported(int C, int Cp, int heads, int hd, int ws, int hidden, int compute_dtype);
+int sr_swin_light(const SrSwinLight* a, void* stream);
+
 typedef struct SrSwinQkv {
     /* q, k, v = qkv(LayerNorm1(x)) in front of sr_window_attention, ABI v6 (hat.py:164-176; swinir.py:146-160 for geometries sr_swin_block
      * does not cover): the stream-form replacement of sr_gemm's SR_EPI_QKV launch.  One workgroup per 64 consecutive window-order tokens

@@ -60,6 +60,13 @@ class SrSwinBlock(C.Structure):
     ]
 
 
+class SrSwinLight(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("bias", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("ldx", _i), ("shift", _i), ("eps", _f), ("y_mode", _i),
+    ]
+
+
 class SrCab(C.Structure):
     _fields_ = [
         ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
@@ -233,6 +240,8 @@ SYMBOLS = {
     "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
     "sr_swin_block_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_block": (_i, [C.POINTER(SrSwinBlock), _vp]),
+    "sr_swin_light_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "sr_swin_light": (_i, [C.POINTER(SrSwinLight), _vp]),
     "sr_cab_supported": (_i, [_i, _i, _i, _i]),
     "sr_cab_pool_tiles": (_i, [_i, _i]),
     "sr_cab_fused": (_i, [C.POINTER(SrCab), _vp]),

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
         for (int r = 0; r < 4; ++r) cdiff[u][r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != kcol;
         dk[u][0] = dk[u][1] = dv[u][0] = dv[u][1] = (f32x4)(0.0f);
     }
-#pragma unroll 2
+#ifndef SR_KV_UNROLL
+#define SR_KV_UNROLL 2
+#endif
+#pragma unroll SR_KV_UNROLL
     for (int qs = 0; qs < QT / 2; ++qs) {
         f32x4 p[KPW][2], ds[KPW][2];
 #pragma unroll
@@ -502,7 +505,10 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
     } else
         hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<36, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (q)");
-    hipLaunchKernelGGL((sr_tr_attn_bwd_kv_kernel<16, 2>), dim3((items_kv + 3) / 4), dim3(256), 0, st, b);
+#ifndef SR_KV_KPW
+#define SR_KV_KPW 2
+#endif
+    hipLaunchKernelGGL((sr_tr_attn_bwd_kv_kernel<16, SR_KV_KPW>), dim3((a.n_bwin * a.heads * (a.Nk / 16 / SR_KV_KPW) + 3) / 4), dim3(256), 0, st, b);
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv)");
     return SR_OK;
 }

@@ -160,6 +160,22 @@ def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dic
     return dict(stream=stream, bias_frag_l2=packing.bias_fragments(bias * packing.LOG2E), stream_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
 
 
+def pack_light_block(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
+    """Operands of sr_swin_light (ABI v7: the whole block of the lightweight geometry, swinir.py:418-427, in one launch) when it covers the
+    geometry (bf16 path): heads padded to 16 features, LayerNorm affines folded, attention scale in the q rows."""
+    if not (fold_ln(dt) and geo.Cp == 64 and geo.heads == 6 and geo.hd <= 16 and geo.ws == 8 and 64 < geo.hidden <= 128 and 48 < geo.C):
+        return {}
+    attn, mlp = blk.attn, blk.mlp
+    C, hd = geo.C, geo.hd
+    qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, blk.norm1.weight, blk.norm1.bias)
+    w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, blk.norm2.weight, blk.norm2.bias)
+    wqkv, bqkv = packing.pack_qkv(qw, qb, C, 64, geo.heads, 16, dt)
+    wproj, bproj = packing.pack_linear(attn.proj.weight, attn.proj.bias, packing.identity_idx(C, 64), packing.head_idx(geo.heads, hd, 16), dt)
+    fc1, fb1 = packing.pack_linear(w1, b1, packing.identity_idx(geo.hidden, 128), packing.identity_idx(C, 64), dt)
+    fc2, fb2 = packing.pack_linear(mlp.fc2.weight, mlp.fc2.bias, packing.identity_idx(C, 64), packing.identity_idx(geo.hidden, 128), dt)
+    return dict(light=(wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2))
+
+
 def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
     """Weight stream of sr_swin_tail (ABI v6: projection + shortcut + LayerNorm2 + MLP behind a separate attention kernel; hat.py:172-194,
     286-293) when the kernel covers the geometry (bf16 path only)."""
@@ -241,6 +257,11 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
             x=t_in.data_ptr(), out=t_out.data_ptr(), wstream=p["stream"].data_ptr(), bias=p["bias_frag_l2"].data_ptr(), B=B, H=H, W=W, C=geo.C,
             Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode, compute_dtype=want,
         )
+        return
+    if "light" in p and cdt == torch.bfloat16 and knob("SR_SWIN_LIGHT", "1") != "0" and ops.swin_light_supported(geo.C, Cp, geo.heads, geo.hd, geo.ws, geo.hidden, L.SR_BF16):
+        wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2 = p["light"]
+        ops.swin_light(x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=wqkv.data_ptr(), bqkv=bqkv.data_ptr(), wproj=wproj.data_ptr(), bproj=bproj.data_ptr(), w1=fc1.data_ptr(),
+                       b1=fb1.data_ptr(), w2=fc2.data_ptr(), b2=fb2.data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, ldx=Cp, shift=shift, eps=1e-5, y_mode=y_mode)
         return
     if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):
         ops.swin_attn_fused(
@@ -430,6 +451,7 @@ class SwinIR(Model):
                 e.update(pack_attention(blk.attn, geo, dt, norm=blk.norm1))
                 e.update(pack_mlp(blk.mlp, geo, dt, norm=blk.norm2))
                 e.update(pack_block_stream(blk, geo, dt))
+                e.update(pack_light_block(blk, geo, dt))
                 blocks.append(e)
             P["layers"].append(dict(blocks=blocks, conv=self._pack_resi(layer.conv, C, Cp, dt), geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)

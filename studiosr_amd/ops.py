@@ -73,6 +73,18 @@ def swin_attn_fused(**kw) -> None:
     L.check(L.lib().sr_swin_attn_fused(C.byref(a), _stream()), "sr_swin_attn_fused")
 
 
+def swin_light_supported(C_: int, Cp: int, heads: int, hd: int, ws: int, hidden: int, compute_dtype: int) -> bool:
+    return bool(L.lib().sr_swin_light_supported(C_, Cp, heads, hd, ws, hidden, compute_dtype))
+
+
+def swin_light(**kw) -> None:
+    """The whole SwinTransformerBlock of the lightweight geometry (embed 60, 6 heads, window 8, hidden 120) in one launch (ABI v7)."""
+    a = L.SrSwinLight()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    L.check(L.lib().sr_swin_light(C.byref(a), _stream()), "sr_swin_light")
+
+
 def swin_block_supported(C_: int, Cp: int, heads: int, hd_p: int, ws: int, Hp: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_swin_block_supported(C_, Cp, heads, hd_p, ws, Hp, compute_dtype))
 

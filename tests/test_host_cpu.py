@@ -42,7 +42,7 @@ def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() of every argument struct."""
     import subprocess
 
-    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd"]
+    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrSwinLight", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd"]
     c = tmp_path / "sz.c"
     c.write_text('#include <stdio.h>\n#include "studiosr_hip.h"\nint main(){' + "".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}\n")
     exe = tmp_path / "sz"
