@@ -13,10 +13,12 @@ namespace {
 
 constexpr int L_CP = 64, L_HEADS = 6, L_HDP = 16, L_HP = 128, L_QKV = 3 * L_HEADS * L_HDP;  // 288
 constexpr int L_VT_LD = 144;  // bytes per V^T row (64 keys bf16 + 16 B): 16 rows hit 16 different 4-bank groups
-// LDS (bytes): A image [8][64] cells | Q [6][2][64] | K [6][2][64] | V^T [6][16] rows | O image [12][64] | partial sums; the hidden image [16][64] reuses Q | K
-constexpr int L_OFF_Q = 8 * 64 * 16, L_OFF_K = L_OFF_Q + 12 * 64 * 16, L_OFF_V = L_OFF_K + 12 * 64 * 16, L_OFF_O = L_OFF_V + 6 * 16 * L_VT_LD,
-              L_OFF_RED = L_OFF_O + 12 * 64 * 16, L_LDS = L_OFF_RED + 64 * 4 * 2 * 4;
+// LDS (bytes): [A image [8][64] cells, later the O image [12][64]] | Q [6][2][64] | K [6][2][64] | V^T [6][16] rows | partial sums; the hidden image
+// [16][64] reuses Q | K.  52 KB: three workgroups per CU, i.e. all 648 windows of the 8-tile bench shape resident at once.
+constexpr int L_OFF_Q = 12 * 64 * 16, L_OFF_K = L_OFF_Q + 12 * 64 * 16, L_OFF_V = L_OFF_K + 12 * 64 * 16, L_OFF_O = 0,
+              L_OFF_RED = L_OFF_V + 6 * 16 * L_VT_LD, L_LDS = L_OFF_RED + 64 * 4 * 2 * 4;
 static_assert(16 * 64 * 16 <= 2 * 12 * 64 * 16, "hidden image fits the Q | K region");
+static_assert(3 * L_LDS <= 160 * 1024, "three workgroups per CU");
 
 struct SwinLightDev {
     SrSwinLight a;
@@ -51,7 +53,7 @@ SR_DEV void light_ln(const f32x4 (&v)[4], float* red, int w, int ar, int ag, int
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void sr_swin_light_kernel(SwinLightDev dv) {
+__global__ __launch_bounds__(256, 3) void sr_swin_light_kernel(SwinLightDev dv) {
     const SrSwinLight& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<bf16>* Aimg = reinterpret_cast<Frag<bf16>*>(smem);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void sr_swin_light_kernel(SwinLightDev dv) 
             x1[m] = acc * cmask;  // (pad channels stay exactly 0: zero weight rows, zero bias pads)
         }
     }
-    // ---- LayerNorm2 -> image (the last reads of the LayerNorm1 image were before the attention barrier)
+    // ---- LayerNorm2 -> image, over the O image: the barriers inside light_ln order every wave's projection reads before the writes
     light_ln(x1, red, w, ar, ag, a.C, a.eps, mean, rstd);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {

@@ -365,10 +365,12 @@ FULL_DEPTH = [
     ("EDSR", dict(scale=4), OM.edsr_forward, False),            # config 2's model: 256 features, 32 resblocks
     ("RCAN", dict(scale=4), OM.rcan_forward, False),            # 10 groups x 20 RCABs
     ("HAT", dict(scale=4, drop_path_rate=0.0), OM.hat_forward, True),  # config 5's forward: 6 x (6 HAB + OCAB), ws 16, reflect-pad geometry
+    # the reference's lightweight SwinIR (from_pretrained(light=True), swinir.py:418-427): 4 x 6 blocks on sr_swin_light (one launch per block), pixelshuffledirect
+    ("SwinIR", dict(scale=4, embed_dim=60, depths=[6, 6, 6, 6], num_heads=[6, 6, 6, 6], upsampler="pixelshuffledirect"), OM.swinir_forward, False),
 ]
 
 
-@pytest.mark.parametrize("kind,cfg,oracle_fwd,train", FULL_DEPTH, ids=[f[0] for f in FULL_DEPTH])
+@pytest.mark.parametrize("kind,cfg,oracle_fwd,train", FULL_DEPTH, ids=["EDSR", "RCAN", "HAT", "SwinIR-light"])
 def test_full_depth_one_tile_against_oracle(kind, cfg, oracle_fwd, train):
     """Default-depth models on ONE 64x64 LR tile against the CPU oracle: error growth over 65 convs / 200 RCABs / 42 HAT blocks.
     fp32 path <= 5e-5 of the output range; bf16 path: the metric's PSNR delta <= 1e-2 dB and >= 50 dB against the oracle output."""
