@@ -155,6 +155,7 @@ typedef struct SrSwinLight {
     int B, H, W, C, ldx, shift;
     float eps;
     int y_mode;            /* SR_Y_* */
+    int compute_dtype;     /* SR_BF16, or SR_BF16X3 (weights packed hi | lo, precision "fp32x3": fp32-class accuracy, erf GELU) */
 } SrSwinLight;
 int sr_swin_light_supported(int C, int Cp, int heads, int hd, int ws, int hidden, int compute_dtype);
 int sr_swin_light(const SrSwinLight* a, void* stream);

@@ -63,7 +63,7 @@ class SrSwinBlock(C.Structure):
 class SrSwinLight(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("bias", _vp),
-        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("ldx", _i), ("shift", _i), ("eps", _f), ("y_mode", _i),
+        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("ldx", _i), ("shift", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
     ]
 
 

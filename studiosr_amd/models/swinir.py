@@ -163,7 +163,10 @@ def pack_block_stream(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dic
 def pack_light_block(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
     """Operands of sr_swin_light (ABI v7: the whole block of the lightweight geometry, swinir.py:418-427, in one launch) when it covers the
     geometry (bf16 path): heads padded to 16 features, LayerNorm affines folded, attention scale in the q rows."""
-    if not (fold_ln(dt) and geo.Cp == 64 and geo.heads == 6 and geo.hd <= 16 and geo.ws == 8 and 64 < geo.hidden <= 128 and 48 < geo.C):
+    from ..runtime import X3_KEY
+
+    x3 = dt == X3_KEY  # split operands (hi | lo) for precision "fp32x3": what inference() runs by default
+    if not ((x3 or fold_ln(dt)) and geo.Cp == 64 and geo.heads == 6 and geo.hd <= 16 and geo.ws == 8 and 64 < geo.hidden <= 128 and 48 < geo.C):
         return {}
     attn, mlp = blk.attn, blk.mlp
     C, hd = geo.C, geo.hd
@@ -173,7 +176,7 @@ def pack_light_block(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict
     wproj, bproj = packing.pack_linear(attn.proj.weight, attn.proj.bias, packing.identity_idx(C, 64), packing.head_idx(geo.heads, hd, 16), dt)
     fc1, fb1 = packing.pack_linear(w1, b1, packing.identity_idx(geo.hidden, 128), packing.identity_idx(C, 64), dt)
     fc2, fb2 = packing.pack_linear(mlp.fc2.weight, mlp.fc2.bias, packing.identity_idx(C, 64), packing.identity_idx(geo.hidden, 128), dt)
-    return dict(light=(wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2))
+    return dict(light=(wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2), light_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
 
 
 def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
@@ -258,10 +261,10 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
             Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode, compute_dtype=want,
         )
         return
-    if "light" in p and cdt == torch.bfloat16 and knob("SR_SWIN_LIGHT", "1") != "0" and ops.swin_light_supported(geo.C, Cp, geo.heads, geo.hd, geo.ws, geo.hidden, L.SR_BF16):
+    if p.get("light_dtype", -2) == want and knob("SR_SWIN_LIGHT", "1") != "0" and ops.swin_light_supported(geo.C, Cp, geo.heads, geo.hd, geo.ws, geo.hidden, want):
         wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2 = p["light"]
         ops.swin_light(x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=wqkv.data_ptr(), bqkv=bqkv.data_ptr(), wproj=wproj.data_ptr(), bproj=bproj.data_ptr(), w1=fc1.data_ptr(),
-                       b1=fb1.data_ptr(), w2=fc2.data_ptr(), b2=fb2.data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, ldx=Cp, shift=shift, eps=1e-5, y_mode=y_mode)
+                       b1=fb1.data_ptr(), w2=fc2.data_ptr(), b2=fb2.data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, ldx=Cp, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=want)
         return
     if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):
         ops.swin_attn_fused(

@@ -36,6 +36,12 @@ def knob(name: str, default: str) -> str:
     return v
 
 
+def reset_knobs() -> None:
+    """Forget the cached A/B switches (Workspace.begin_forward() does this at the start of every model forward; callers that drive the block
+    helpers directly -- tests, tools -- call it after changing the environment)."""
+    _KNOBS.clear()
+
+
 X3_KEY = "bf16x3"  # key of the split-operand weight packing
 _x3_depth = 0      # > 0 while a forward with precision "fp32x3" is enqueueing (one forward at a time per process: SURVEY 8b)
 

@@ -616,6 +616,7 @@ def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launche
         for flag in ("1", "0"):
             monkeypatch.setenv("SR_SWIN_QKV", flag)
             monkeypatch.setenv("SR_SWIN_TAIL", flag)
+            S.runtime.reset_knobs()  # (the switches are read once per forward; this test drives the block helpers directly)
             out = torch.full_like(t_in, float("nan"))
             used = SW.run_window_msa(bp, bp["ln1"], geo, t_in, out, skip, Workspace(DEV), cdt, bp["shift"], name=f"t{flag}", with_mlp=True)
             assert (used == "tail") == (flag == "1")

@@ -37,7 +37,7 @@ def main():
         B = int(parts[1]) if len(parts) > 1 and parts[1] else CASES[kind]
         inflight = int(parts[2]) if len(parts) > 2 else 1
         torch.manual_seed(0)
-        m = build(kind).eval().to(dev).set_precision("bf16")
+        m = build(kind).eval().to(dev).set_precision(os.environ.get("MB_PREC", "bf16"))  # MB_PREC=fp32x3: what inference() runs
         x = torch.rand(B, 3, 64, 64, device=dev)
         with torch.no_grad():
             pipes = []
@@ -67,7 +67,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
         tf = B * GFLOP_PER_TILE[kind] / dt / 1e3
-        print(json.dumps({"model": f"{kind} x4", "batch": B, "in_flight": inflight, "ms": round(dt * 1e3, 3), "hr_mpix_per_s": round(B * 256 * 256 / 1e6 / dt, 1),
+        print(json.dumps({"model": f"{kind} x4", "precision": os.environ.get("MB_PREC", "bf16"), "batch": B, "in_flight": inflight, "ms": round(dt * 1e3, 3), "hr_mpix_per_s": round(B * 256 * 256 / 1e6 / dt, 1),
                           "tflops": round(tf, 1), "frac_bf16_mfma_peak": round(tf / 2500.0, 4)}), flush=True)
         del pipes, m
         torch.cuda.empty_cache()
