@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 7
+#define SR_ABI_VERSION 8
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -334,6 +334,13 @@ typedef struct SrWindowAttn {
                              * = d 16 dt + i, keys 64 kb + 32 ks + 16 (e >> 2) + 4 g + (e & 3)): every operand fragment is one coalesced 1-KiB load */
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
+
+/* The two independent middle stages of a HAB as ONE launch, ABI v8 (hat.py:165-176: conv_x = conv_block(norm1(x)) beside attn_x = attn(x_windows)):
+ * the first sr_cab_pool_tiles(H, W) * B workgroups run sr_cab_fused's tiles on `cab`, the others sr_window_attention's flash form on `attn` (16 x 16
+ * windows, head_dim <= 32, bf16, attn->bias_frag required, attn->qkv_frag honoured).  Same outputs as the two separate calls (the CAB's conv1 sums its K in
+ * two 96-channel phases: same products, another fp32 order); one launch instead of a fork / join across two queues of a captured graph. */
+int sr_hab_mid_supported(int ntok, int hd_p, int ws, int attn_dtype, int Cin_p, int Cmid_p, int Cout_p, int cab_dtype);
+int sr_hab_mid(const SrWindowAttn* attn, const SrCab* cab, void* stream);
 
 typedef struct SrOcaAttn {
     /* HAT overlapping cross attention core (hat.py:266-283): every ws x ws query window attends to the

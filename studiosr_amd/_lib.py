@@ -24,7 +24,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -255,6 +255,8 @@ SYMBOLS = {
     "sr_conv3x3_pool_tiles": (_i, [_i, _i, _i, _i]),
     "sr_conv3x3_pool_tiles_rows": (_i, [_i, _i, _i, _i]),
     "sr_window_attention": (_i, [C.POINTER(SrWindowAttn), _vp]),
+    "sr_hab_mid_supported": (_i, [_i] * 8),
+    "sr_hab_mid": (_i, [C.POINTER(SrWindowAttn), C.POINTER(SrCab), _vp]),  # ABI v8
     "sr_oca_attention": (_i, [C.POINTER(SrOcaAttn), _vp]),
     "sr_pixel_shuffle_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sr_rcab_conv_pair": (_i, [C.POINTER(SrRcab), _vp]),

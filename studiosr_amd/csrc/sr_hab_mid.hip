@@ -1,0 +1,55 @@
+// The two independent middle stages of a HAB as ONE launch (C ABI v8 sr_hab_mid; hat.py:165-176):
+//     y = conv2(GELU(conv1(LayerNorm1(x))))   -- the CAB body, sr_cab.hip                          (hat.py:41-49, 165-170)
+//     o = softmax(q k^T + bias + mask) v      -- (S)W-MSA of the 16 x 16 windows, sr_attn.hip      (hat.py:85-110, 172-176)
+// Why: both read what the previous block's sr_swin_tail wrote and feed the next sr_swin_tail; as two launches they ran on two HIP streams,
+// and in the captured graph every fork / join edge between the two queues costs 5-12 us (profiles/r03_hat_timeline.txt: a HAB period of
+// 75.7 us = tail 28.6 + fork 11.7 + attention 24.2 + join 11.2) -- a third of HAT x4 b4.  Here the first n_cab workgroups are CAB tiles (the
+// longer latency chain: dispatched first), the rest are attention workgroups (4 waves = 4 (window, head, 32 queries) items, no LDS, no
+// barriers); the roles share nothing but the launch, so the chain tail -> mid -> tail stays on ONE queue with back-to-back dispatch.
+// The CAB role is the two-K-phase form of sr_cab.hip (52 KiB of LDS: the launch's dynamic LDS applies to attention workgroups too, and two
+// workgroups per CU -- the attention role's 221 VGPRs -- must fit); its conv1 therefore sums K phase-major (same products, another fp32 order).
+#define SR_CAB_PH 2
+#include "sr_cab_body.h"
+#include "sr_wattn_body.h"
+
+namespace {
+
+template <bool FR>
+__global__ __launch_bounds__(256, 2) void sr_hab_mid_kernel(SrWindowAttn a, SrCab c, int n_cab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    if (block < n_cab)
+        cab_block(c, block, smem);
+    else
+        wattn_flash_block<bf16, 16, 2, 1, FR>(a, block - n_cab);
+}
+
+}  // namespace
+
+extern "C" int sr_hab_mid_supported(int ntok, int hd_p, int ws, int attn_dtype, int Cin_p, int Cmid_p, int Cout_p, int cab_dtype) {
+    return (ntok == 256 && hd_p == 32 && ws == 16 && attn_dtype == SR_BF16 && Cin_p == CI && Cmid_p == CM && Cout_p == CO && cab_dtype == SR_BF16) ? 1 : 0;
+}
+
+extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream) {
+    SR_REQUIRE(pa && pa->q && pa->k && pa->vt && pa->bias_frag && pa->out, "sr_hab_mid: null pointer (attention operands; bias_frag is required)");
+    if (const int rc = cab_check(pc, "sr_hab_mid")) return rc;
+    const SrWindowAttn& a = *pa;
+    const SrCab& c = *pc;
+    SR_REQUIRE(sr_hab_mid_supported(a.ntok, a.hd_p, a.ws, a.dtype, c.Cin_p, c.Cmid_p, c.Cout_p, c.dtype), "sr_hab_mid: unsupported geometry (16 x 16 windows, head_dim <= 32, bf16)");
+    SR_REQUIRE(a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.heads > 0, "sr_hab_mid: bad attention geometry");
+    SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_hab_mid: n_bwin");
+    const long n_cab = (long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B;
+    const long items = (long)a.n_bwin * a.heads * 8;  // (window, head, block of 32 queries)
+    const long blocks = n_cab + (items + 3) / 4;
+    SR_REQUIRE(blocks < (1l << 31), "sr_hab_mid: too many workgroups");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static SrDeviceOnce once[2];
+    auto launch = [&](auto kernel, SrDeviceOnce& o) -> int {
+        const hipError_t e = sr_once_per_device(o, [&] { return sr_allow_lds(kernel, LDS_BYTES); });
+        SR_REQUIRE(e == hipSuccess, "sr_hab_mid: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), LDS_BYTES, st, a, c, (int)n_cab);
+        SR_CHECK_LAUNCH("sr_hab_mid");
+        return SR_OK;
+    };
+    return a.qkv_frag ? launch(sr_hab_mid_kernel<true>, once[1]) : launch(sr_hab_mid_kernel<false>, once[0]);
+}

@@ -309,14 +309,24 @@ class HAT(Model):
         fuse_next_qkv = (unfused and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
                          and knob("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
 
+        # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
+        mid_fused = (unfused and cab_fused and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
+                     and ops.hab_mid_supported(geo.ntok, geo.hd_p, geo.ws, L.SR_BF16, Cp, P["c3p"], Cp, L.SR_BF16))
+        if mid_fused:
+            side = main
+            if not n1_ready:
+                ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+        cab_kw = dict(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(), b2=bp["cab2"][1].data_ptr(),
+                      y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=L.SR_BF16)
+
         def conv_branch():
+            if mid_fused:
+                return
             with torch.cuda.stream(side):
                 if unfused and not n1_ready:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
                 if cab_fused:
-                    ops.cab_fused(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(),
-                                  b2=bp["cab2"][1].data_ptr(), y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"],
-                                  Cout_p=Cp, dtype=L.SR_BF16)
+                    ops.cab_fused(**cab_kw)
                 else:
                     conv_call(n1, *bp["cab1"], mid, cdt, act=L.ACT_GELU)
                     conv_call(mid, *bp["cab2"], y, cdt, pool=pool, tile_rows=th)
@@ -361,7 +371,8 @@ class HAT(Model):
             return d
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
-        used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready)
+        used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready,
+                              attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None)
         if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
             return next_ln is not None and n1.dtype == torch.bfloat16, fuse_next_qkv
         if not used:

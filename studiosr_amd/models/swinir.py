@@ -279,14 +279,15 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False):
+                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False, attn_launch=None):
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
     before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
     second residual).  Returns True iff it was used (the one-kernel attention half has no hook).
     with_mlp: the caller's next step is run_mlp(p, ...) on t_out; when sr_swin_tail covers the geometry the projection AND that MLP run as
     one launch and the function returns "tail" (the caller must then skip run_mlp).
-    qkv_ready: q / k / v^T of this block are already in the workspace (written by the previous block's sr_swin_tail): no QKV launch."""
+    qkv_ready: q / k / v^T of this block are already in the workspace (written by the previous block's sr_swin_tail): no QKV launch.
+    attn_launch (HAT): called with the fields of ops.window_attention INSTEAD of that launch (sr_hab_mid: attention + CAB as one launch)."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -316,11 +317,13 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
             a_dtype=L.SR_F32, out_dtype=sdt, compute_dtype=sdt, act=L.ACT_NONE, out_scale=1.0, a_map=L.MAP_WINDOW, o_map=L.MAP_IDENTITY,
             H=H, W=W, ws=geo.ws, shift=shift, epi=L.EPI_QKV, heads=geo.heads, hd_p=geo.hd_p, ntok=geo.ntok, ln_eps=1e-5, y_mode=y_mode,
         )
-    ops.window_attention(
-        q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
-        hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
-        qkv_frag=int(frag),
-    )
+    akw = dict(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
+               hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
+               qkv_frag=int(frag))
+    if attn_launch is not None:
+        attn_launch(akw)
+    else:
+        ops.window_attention(**akw)
     extra = before_proj() if before_proj is not None else {}
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
         run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)

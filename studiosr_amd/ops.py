@@ -174,6 +174,20 @@ def window_attention(**kw) -> None:
     L.check(L.lib().sr_window_attention(C.byref(a), _stream()), "sr_window_attention")
 
 
+def hab_mid_supported(ntok: int, hd_p: int, ws: int, attn_dtype: int, cin_p: int, cmid_p: int, cout_p: int, cab_dtype: int) -> bool:
+    return bool(L.lib().sr_hab_mid_supported(ntok, hd_p, ws, attn_dtype, cin_p, cmid_p, cout_p, cab_dtype))
+
+
+def hab_mid(attn: dict, cab: dict) -> None:
+    """Window attention and CAB body of one HAB as ONE launch (ABI v8; hat.py:165-176): `attn` = the fields of window_attention, `cab` = those of cab_fused."""
+    a, c = L.SrWindowAttn(), L.SrCab()
+    for k, v in attn.items():
+        setattr(a, k, v)
+    for k, v in cab.items():
+        setattr(c, k, v)
+    L.check(L.lib().sr_hab_mid(C.byref(a), C.byref(c), _stream()), "sr_hab_mid")
+
+
 def oca_attention(**kw) -> None:
     a = L.SrOcaAttn()
     for k, v in kw.items():

@@ -800,6 +800,74 @@ def test_cab_fused_equals_two_conv_launches_and_a_torch_reference():
     assert torch.allclose(pool.sum(1)[:, :C], ref.sum((1, 2)), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) * 8)
 
 
+@pytest.mark.parametrize("frag", [0, 1])
+def test_hab_mid_one_launch_equals_the_attention_and_cab_launches(frag):
+    """sr_hab_mid (ABI v8; hat.py:165-176: CAB and window attention of a HAB as ONE launch, CAB tiles first) against sr_window_attention and
+    sr_cab_fused on the same operands: the attention role is the same code on the same data (bit-identical output, shifted window mask
+    included); the CAB role sums conv1's K in two phases (fp32 order only), its pool partials keep sr_cab_pool_tiles' layout."""
+    torch.manual_seed(41)
+    B, H, W, C, Cp, c3, c3p, heads, hd_p, ws = 2, 32, 48, 180, 192, 60, 64, 6, 32, 16
+    ntok, nb = ws * ws, B * (H // ws) * (W // ws)
+    w1, b1 = torch.randn(c3, C, 3, 3, device=DEV) * 0.03, torch.randn(c3, device=DEV) * 0.1
+    w2, b2 = torch.randn(C, c3, 3, 3, device=DEV) * 0.05, torch.randn(C, device=DEV) * 0.1
+    p1 = packing.pack_conv3x3(w1, b1, Cp, packing.identity_idx(c3, c3p), torch.bfloat16)
+    p2 = packing.pack_conv3x3(w2, b2, c3p, packing.identity_idx(C, Cp), torch.bfloat16)
+    x = torch.randn(B, H, W, Cp, device=DEV).to(torch.bfloat16)
+    x[..., C:] = 0
+    q = (torch.randn(nb, heads, ntok, hd_p, device=DEV) * 0.3).to(torch.bfloat16)  # (fragment order is a permutation of these: any values do)
+    k = torch.randn(nb, heads, ntok, hd_p, device=DEV).to(torch.bfloat16)
+    vt = torch.randn(nb, heads, hd_p, ntok, device=DEV).to(torch.bfloat16)
+    bias = torch.randn(heads, ntok, ntok, device=DEV)
+    bias_frag = packing.bias_fragments(bias)
+    nt = ops.cab_pool_tiles(H, W)
+    assert ops.hab_mid_supported(ntok, hd_p, ws, L.SR_BF16, Cp, c3p, Cp, L.SR_BF16)
+
+    def run(one_launch):
+        o = torch.full((nb * ntok, heads * hd_p), float("nan"), device=DEV).to(torch.bfloat16)
+        y = torch.full((B, H, W, Cp), float("nan"), device=DEV).to(torch.bfloat16)
+        pool = torch.full((B, nt, Cp), float("nan"), device=DEV)
+        akw = dict(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=bias.data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=heads, hd_p=hd_p, ntok=ntok,
+                   H=H, W=W, ws=ws, shift=ws // 2, dtype=L.SR_BF16, y_mode=L.Y_ROLL, bias_frag=bias_frag.data_ptr(), qkv_frag=frag)
+        ckw = dict(x=x.data_ptr(), w1p=p1[0].data_ptr(), b1=p1[1].data_ptr(), w2p=p2[0].data_ptr(), b2=p2[1].data_ptr(), y=y.data_ptr(),
+                   pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=c3p, Cout_p=Cp, dtype=L.SR_BF16)
+        if one_launch:
+            ops.hab_mid(akw, ckw)
+        else:
+            ops.window_attention(**akw)
+            ops.cab_fused(**ckw)
+        torch.cuda.synchronize()
+        return o.float(), y.float(), pool
+
+    o1, y1, pool1 = run(True)
+    o0, y0, pool0 = run(False)
+    assert not torch.isnan(o1).any() and not torch.isnan(y1).any() and not torch.isnan(pool1).any()
+    assert torch.equal(o1, o0)
+    scale = float(y0.abs().max())
+    assert float((y1 - y0).abs().max()) <= 1.0e-2 * scale and float((y1 - y0).pow(2).mean().sqrt()) <= 1.0e-3 * scale
+    assert float(y1[..., C:].abs().max()) == 0.0
+    assert torch.allclose(pool1, pool0, rtol=1e-3, atol=1e-3 * scale * 84)
+    with pytest.raises(RuntimeError):  # the flash form needs the fragment-ordered bias
+        akw = dict(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=bias.data_ptr(), out=o1.data_ptr(), n_bwin=nb, heads=heads, hd_p=hd_p, ntok=ntok,
+                   H=H, W=W, ws=ws, shift=0, dtype=L.SR_BF16, y_mode=L.Y_ROLL)
+        ops.hab_mid(akw, dict(x=x.data_ptr()))
+
+
+def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(monkeypatch):
+    """A default-width HAT forward (shifted and unshifted HABs, OCAB) with sr_hab_mid (default) and with the two-stream attention || CAB launches."""
+    torch.manual_seed(5)
+    m = _randomised(S.HAT(scale=2, depths=[2, 2], num_heads=[6, 6]), seed=7).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(2, 3, 48, 32, device=DEV)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SR_HAB_MID", flag)
+        with torch.no_grad():
+            outs.append(m(x).clone())
+    torch.cuda.synchronize()
+    new, old = outs
+    assert not torch.isnan(new).any()
+    assert float((new - old).abs().max()) <= 5e-3 * max(1.0, float(old.abs().max()))
+
+
 def test_gated_second_residual_of_the_projection_gemm_equals_channel_attention():
     """HAT's combine x = shortcut + attn + conv_scale * CA(cab) (hat.py:192): sr_channel_gate + sr_gemm's gated second residual against the
     two-pass form (projection GEMM with the shortcut, then sr_channel_attention over the stream)."""
