@@ -332,6 +332,10 @@ typedef struct SrWindowAttn {
     int qkv_frag;           /* 1 (ABI v6; bf16, ntok 256, hd_p 32): q, k, vt are in FRAGMENT order as written by sr_swin_qkv / sr_swin_tail with frag_order = 1
                              * (q, k: [tile of 16 tokens][lane = 16 g + i][8] = token 16 tile + i, features 8 g ..; vt: [64-key block][d tile][32-key step][lane][8]
                              * = d 16 dt + i, keys 64 kb + 32 ks + 16 (e >> 2) + 4 g + (e & 3)): every operand fragment is one coalesced 1-KiB load */
+    const float* bias_tiles; /* optional (ABI v8; bf16, 16 x 16 windows, hd_p 32): the bias as its 31 DISTINCT 16 x 16 tiles per head, [heads][31][lane][4] in the
+                              * accumulator-fragment order of bias_frag -- valid when bias[h][q][k] depends on (q >> 4) - (k >> 4) and the in-row offsets only, as
+                              * every relative-position bias does (tile d = (q >> 4) - (k >> 4) + 15).  Selects the LDS form: one (window, head) per workgroup with K,
+                              * V^T and these tiles staged in LDS once (csrc/sr_wattn_lds_body.h) */
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
 

@@ -11,7 +11,7 @@
 //   the O^T accumulator gives every lane 4 consecutive features of one query -> 8/16-byte stores.
 // The -100 shift mask is recomputed from window coordinates (same labels as the reference's
 // calculate_mask) instead of being read from memory.
-#include "sr_wattn_body.h"
+#include "sr_wattn_lds_body.h"
 
 namespace {
 
@@ -147,6 +147,22 @@ __global__ __launch_bounds__(256, SR_ATTN_FLASH_WGS) void sr_window_attn_flash_k
     wattn_flash_block<TC, KT, QT, DC, FR>(a, blockIdx.x);
 }
 
+template <bool FR>
+__global__ __launch_bounds__(256, 2) void sr_window_attn_lds_kernel(SrWindowAttn a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wattn_lds_block<FR>(a, blockIdx.x, smem);
+}
+
+template <bool FR>
+int launch_lds(const SrWindowAttn& a, hipStream_t st) {
+    static SrDeviceOnce once;
+    const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_window_attn_lds_kernel<FR>, WL_LDS); });
+    SR_REQUIRE(e == hipSuccess, "sr_window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(sr_window_attn_lds_kernel<FR>, dim3(a.n_bwin * a.heads), dim3(256), WL_LDS, st, a);
+    SR_CHECK_LAUNCH("sr_window_attention");
+    return SR_OK;
+}
+
 template <typename TC, int KT, int QT, int DC, bool FR = false>
 int launch_flash(const SrWindowAttn& a, hipStream_t st) {
     const int items = a.n_bwin * a.heads * (KT / QT);
@@ -168,6 +184,7 @@ int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
     if (a.bias_frag && a.ws % 4 == 0) {  // fragment-ordered bias available: flash form
         if (a.ntok == 256 && a.hd_p == 32) {
             if constexpr (sizeof(TC) == 2) {
+                if (a.bias_tiles) return a.qkv_frag ? launch_lds<true>(a, st) : launch_lds<false>(a, st);  // K / V^T / distinct bias tiles in LDS
                 if (a.qkv_frag) return launch_flash<TC, 16, 2, 1, true>(a, st);
             }
             return launch_flash<TC, 16, 2, 1>(a, st);  // 2 query tiles per wave, two workgroups per CU
@@ -193,6 +210,7 @@ extern "C" int sr_window_attention(const SrWindowAttn* p, void* stream) {
                "sr_window_attention: bad geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_window_attention: n_bwin");
     SR_REQUIRE(!a.qkv_frag || (a.dtype == SR_BF16 && a.ntok == 256 && a.hd_p == 32 && a.bias_frag && a.ws % 4 == 0), "sr_window_attention: qkv_frag needs bf16, 16 x 16 windows, hd_p 32 and bias_frag");
+    SR_REQUIRE(!a.bias_tiles || (a.dtype == SR_BF16 && a.ntok == 256 && a.ws == 16 && a.hd_p == 32 && a.bias_frag), "sr_window_attention: bias_tiles needs bf16, 16 x 16 windows, hd_p 32 (and bias_frag for the fallback contract)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return a.dtype == SR_BF16 ? dispatch_attn<bf16>(a, st) : dispatch_attn<float>(a, st);
 }

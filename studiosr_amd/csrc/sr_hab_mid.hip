@@ -8,20 +8,26 @@
 // barriers); the roles share nothing but the launch, so the chain tail -> mid -> tail stays on ONE queue with back-to-back dispatch.
 // The CAB role is the two-K-phase form of sr_cab.hip (52 KiB of LDS: the launch's dynamic LDS applies to attention workgroups too, and two
 // workgroups per CU -- the attention role's 221 VGPRs -- must fit); its conv1 therefore sums K phase-major (same products, another fp32 order).
+// With SrWindowAttn.bias_tiles the attention role is the LDS form (sr_wattn_lds_body.h: one (window, head) per workgroup, K / V^T / the 31 distinct bias
+// tiles staged once; 63 KiB of LDS).
 #define SR_CAB_PH 2
 #include "sr_cab_body.h"
-#include "sr_wattn_body.h"
+#include "sr_wattn_lds_body.h"
 
 namespace {
 
-template <bool FR>
+// MODE bit 0: q / k / v^T in fragment order (SrWindowAttn.qkv_frag); bit 1: the LDS form of the attention (SrWindowAttn.bias_tiles: one (window, head) per
+// workgroup, sr_wattn_lds_body.h) instead of the register-only flash form (four (window, head, 32 queries) items per workgroup)
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void sr_hab_mid_kernel(SrWindowAttn a, SrCab c, int n_cab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
     if (block < n_cab)
         cab_block(c, block, smem);
+    else if constexpr ((MODE & 2) != 0)
+        wattn_lds_block<(MODE & 1) != 0>(a, block - n_cab, smem);
     else
-        wattn_flash_block<bf16, 16, 2, 1, FR>(a, block - n_cab);
+        wattn_flash_block<bf16, 16, 2, 1, (MODE & 1) != 0>(a, block - n_cab);
 }
 
 }  // namespace
@@ -39,17 +45,21 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
     SR_REQUIRE(a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.heads > 0, "sr_hab_mid: bad attention geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_hab_mid: n_bwin");
     const long n_cab = (long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B;
-    const long items = (long)a.n_bwin * a.heads * 8;  // (window, head, block of 32 queries)
-    const long blocks = n_cab + (items + 3) / 4;
+    const bool lds_form = a.bias_tiles != nullptr;
+    const long items = (long)a.n_bwin * a.heads * 8;  // flash form: (window, head, block of 32 queries), four per workgroup
+    const long blocks = n_cab + (lds_form ? (long)a.n_bwin * a.heads : (items + 3) / 4);
     SR_REQUIRE(blocks < (1l << 31), "sr_hab_mid: too many workgroups");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static SrDeviceOnce once[2];
-    auto launch = [&](auto kernel, SrDeviceOnce& o) -> int {
-        const hipError_t e = sr_once_per_device(o, [&] { return sr_allow_lds(kernel, LDS_BYTES); });
+    static SrDeviceOnce once[4];
+    auto launch = [&](auto kernel, SrDeviceOnce& o, int lds) -> int {
+        const hipError_t e = sr_once_per_device(o, [&] { return sr_allow_lds(kernel, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_hab_mid: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), LDS_BYTES, st, a, c, (int)n_cab);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds, st, a, c, (int)n_cab);
         SR_CHECK_LAUNCH("sr_hab_mid");
         return SR_OK;
     };
-    return a.qkv_frag ? launch(sr_hab_mid_kernel<true>, once[1]) : launch(sr_hab_mid_kernel<false>, once[0]);
+    constexpr int LDS_BOTH = LDS_BYTES > WL_LDS ? LDS_BYTES : WL_LDS;
+    static_assert(2 * LDS_BOTH <= 160 * 1024, "two workgroups per CU");
+    if (lds_form) return a.qkv_frag ? launch(sr_hab_mid_kernel<3>, once[3], LDS_BOTH) : launch(sr_hab_mid_kernel<2>, once[2], LDS_BOTH);
+    return a.qkv_frag ? launch(sr_hab_mid_kernel<1>, once[1], LDS_BYTES) : launch(sr_hab_mid_kernel<0>, once[0], LDS_BYTES);
 }

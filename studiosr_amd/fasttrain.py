@@ -31,6 +31,7 @@ from . import ops
 Tensor = torch.Tensor
 CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
+HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
 WG_KS = int(os.environ.get("SR_WG_KS", "8"))  # token slices of the weight-gradient GEMMs (A/B knob)
 
 
@@ -484,11 +485,16 @@ class BlockPlan:
             _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
                   wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
                   vT=self.vT.data_ptr(), n1=self.n1.data_ptr(), ldn=CP, shift=self.shift, **g)
-            ops.window_attention(q=self.q.data_ptr(), k=self.k.data_ptr(), vt=self.vT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), out=self.o.data_ptr(), n_bwin=nbw,
-                                 heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
-                                 bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0)
-            ops.cab_fused(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
-                          y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
+            akw = dict(q=self.q.data_ptr(), k=self.k.data_ptr(), vt=self.vT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), out=self.o.data_ptr(), n_bwin=nbw,
+                       heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
+                       bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0)
+            ckw = dict(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
+                       y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
+            if HAB_MID:  # the two independent launches as one (sr_hab_mid, ABI v8)
+                ops.hab_mid(akw, ckw)
+            else:
+                ops.window_attention(**akw)
+                ops.cab_fused(**ckw)
         kw = {}
         if self.cab is not None:
             w1, b1, w2, b2 = self.ca

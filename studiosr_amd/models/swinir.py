@@ -131,8 +131,12 @@ def pack_attention(attn: nn.Module, geo: SwinGeometry, dt: torch.dtype, rpi: Opt
     bv = qb.detach().to(torch.float32)[2 * C :] if qb is not None else torch.zeros(C, device=qw.device)
     pb = attn.proj.bias.detach().to(torch.float32) if attn.proj.bias is not None else torch.zeros(C, device=qw.device)
     proj_b_fused = packing.pad_vec(pb + attn.proj.weight.detach().to(torch.float32) @ bv, Cp).contiguous()
-    return dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, proj_b_fused=proj_b_fused, bias=bias,
-                bias_frag=packing.bias_fragments(bias))
+    out = dict(qkv_w=qkv_w, qkv_b=qkv_b, proj_w=proj_w, proj_b=proj_b, proj_b_fused=proj_b_fused, bias=bias, bias_frag=packing.bias_fragments(bias))
+    if geo.ntok == 256 and hd_p == 32 and dt == torch.bfloat16:  # 16 x 16 windows: the 31 distinct bias tiles select the LDS form of the attention (ABI v8)
+        tiles = packing.bias_distinct_tiles(bias)
+        if tiles is not None:
+            out["bias_tiles"] = tiles
+    return out
 
 
 def pack_mlp(mlp: nn.Module, geo: SwinGeometry, dt: torch.dtype, norm: Optional[nn.LayerNorm] = None) -> Dict:
@@ -320,6 +324,8 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     akw = dict(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=p["bias"].data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=geo.heads,
                hd_p=geo.hd_p, ntok=geo.ntok, H=H, W=W, ws=geo.ws, shift=shift, dtype=sdt, y_mode=y_mode, bias_frag=p["bias_frag"].data_ptr(),
                qkv_frag=int(frag))
+    if "bias_tiles" in p and sdt == L.SR_BF16 and knob("SR_ATTN_LDS", "1") != "0":  # K / V^T / distinct bias tiles staged in LDS once per (window, head)
+        akw["bias_tiles"] = p["bias_tiles"].data_ptr()
     if attn_launch is not None:
         attn_launch(akw)
     else:

@@ -142,6 +142,23 @@ def bias_fragments(bias: Tensor) -> Tensor:
     return b.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)  # [h, qt, kt, g, q16, r] -> lane = g*16 + q16
 
 
+def bias_distinct_tiles(bias: Tensor) -> Optional[Tensor]:
+    """[heads, 256, 256] fp32 bias of 16 x 16 windows -> its 31 distinct 16 x 16 tiles [heads][31][lane][4] in the accumulator-fragment
+    order of bias_fragments (SrWindowAttn.bias_tiles, ABI v8), or None when the bias does not have the structure.  A relative-position bias
+    table[(qy - ky + 15) * 31 + (qx - kx + 15)] (hat.py:85-110, rpi of common.py:276-290) has: tile (qt, kt) = rows 16 qt.., columns 16 kt.. is one
+    (query window row, key window row) pair and depends on qt - kt only.  Checked element for element on the gathered bias."""
+    heads, nq, nk = bias.shape
+    if nq != 256 or nk != 256:
+        return None
+    b = bias.reshape(heads, 16, 16, 16, 16).permute(0, 1, 3, 2, 4)  # [h, qt, kt, i, j]
+    qt = torch.arange(16, device=bias.device)
+    d = qt[:, None] - qt[None, :] + 15  # [qt, kt] -> tile index
+    first = torch.stack([b[:, max(t - 15, 0), max(15 - t, 0)] for t in range(31)], 1)  # [h, 31, i, j]
+    if not torch.equal(first[:, d], b):
+        return None
+    return first.reshape(heads, 31, 16, 4, 4).permute(0, 1, 3, 2, 4).contiguous().reshape(-1)  # [h, d, g, i, r] -> lane = g * 16 + i
+
+
 # --------------------------------------------------------------------------- Swin block weight stream (C ABI v5, sr_swin_block)
 LOG2E = 1.4426950408889634
 SWIN_STREAM_SLOTS = 48

@@ -852,6 +852,55 @@ def test_hab_mid_one_launch_equals_the_attention_and_cab_launches(frag):
         ops.hab_mid(akw, dict(x=x.data_ptr()))
 
 
+@pytest.mark.parametrize("frag,shift,y_mode", [(0, 0, "roll"), (0, 8, "roll"), (1, 8, "roll"), (1, 4, "strip")])
+def test_window_attention_lds_form_equals_the_flash_form(frag, shift, y_mode):
+    """sr_window_attention with SrWindowAttn.bias_tiles (ABI v8: K / V^T / the 31 distinct bias tiles of a head staged in LDS once per (window, head)) against the
+    register-only flash form on the same operands (hat.py:85-110): same products, same online softmax over key blocks of 64, so the outputs agree to bf16
+    rounding of o; also inside sr_hab_mid.  The bias is a real relative-position bias (table[rpi_sa(16)]); a bias without that structure is refused by the packer."""
+    from studiosr_amd.models.hat import rpi_sa
+
+    torch.manual_seed(43)
+    B, H, W, heads, hd_p, ws = 2, 32, 48, 6, 32, 16
+    ntok, nb = ws * ws, B * (H // ws) * (W // ws)
+    q = (torch.randn(nb, heads, ntok, hd_p, device=DEV) * 0.4).to(torch.bfloat16)
+    k = torch.randn(nb, heads, ntok, hd_p, device=DEV).to(torch.bfloat16)
+    vt = torch.randn(nb, heads, hd_p, ntok, device=DEV).to(torch.bfloat16)
+    table = torch.randn((2 * ws - 1) ** 2, heads, device=DEV)
+    bias = packing.gather_bias(table, rpi_sa(ws), ntok, ntok)
+    bias_frag = packing.bias_fragments(bias)
+    tiles = packing.bias_distinct_tiles(bias)
+    assert tiles is not None and tiles.numel() == heads * 31 * 256
+    assert packing.bias_distinct_tiles(torch.randn(heads, ntok, ntok, device=DEV)) is None
+    ym = L.Y_ROLL if y_mode == "roll" else L.Y_STRIP
+
+    def run(lds):
+        o = torch.full((nb * ntok, heads * hd_p), float("nan"), device=DEV).to(torch.bfloat16)
+        ops.window_attention(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=bias.data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=heads, hd_p=hd_p, ntok=ntok,
+                             H=H, W=W, ws=ws, shift=shift, dtype=L.SR_BF16, y_mode=ym, bias_frag=bias_frag.data_ptr(), qkv_frag=frag,
+                             bias_tiles=tiles.data_ptr() if lds else None)
+        torch.cuda.synchronize()
+        return o.float()
+
+    new, old = run(True), run(False)
+    assert not torch.isnan(new).any()
+    scale = float(old.abs().max())
+    assert float((new - old).abs().max()) <= 8e-3 * scale, float((new - old).abs().max()) / scale  # one bf16 ulp of o
+    assert float((new - old).pow(2).mean().sqrt()) <= 5e-4 * scale
+    if frag == 0:  # torch reference on the same rounded operands, shift mask from the reference's labels (common.py:250-274)
+        from oracle import functional as OF
+
+        s = torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) + bias[None]
+        if shift:
+            mask = OF.calculate_mask(H, W, ws, shift).to(DEV)  # [nW, ntok, ntok]
+            if y_mode == "strip":
+                mask = None
+            if mask is not None:
+                s = (s.reshape(B, -1, heads, ntok, ntok) + mask[None, :, None]).reshape(nb, heads, ntok, ntok)
+        if not (shift and y_mode == "strip"):
+            ref = torch.einsum("bhqk,bhdk->bqhd", torch.softmax(s, -1), vt.float()).reshape(nb * ntok, heads * hd_p)
+            assert float((new - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(monkeypatch):
     """A default-width HAT forward (shifted and unshifted HABs, OCAB) with sr_hab_mid (default) and with the two-stream attention || CAB launches."""
     torch.manual_seed(5)
