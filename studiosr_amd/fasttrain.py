@@ -31,6 +31,7 @@ from . import ops
 Tensor = torch.Tensor
 CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
+ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
 HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
 WG_KS = int(os.environ.get("SR_WG_KS", "8"))  # token slices of the weight-gradient GEMMs (A/B knob)
 
@@ -341,9 +342,10 @@ def pack_vec(fp: FlatParams, v: Tensor, n_p: int, rows: Optional[np.ndarray] = N
     return m
 
 
-def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) -> Tuple[IM, IM, IM]:
-    """relative-position bias gathered through rpi (negative indices wrap): [heads][nq][nk], its transpose [heads][nk][nq], and the
-    accumulator-fragment order of packing.bias_fragments."""
+def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) -> Tuple[IM, IM, IM, Optional[IM]]:
+    """relative-position bias gathered through rpi (negative indices wrap): [heads][nq][nk], its transpose [heads][nk][nq], the
+    accumulator-fragment order of packing.bias_fragments, and (16 x 16 windows with a relative-position index: tile (qt, kt) depends on qt - kt
+    only) the 31 distinct tiles of packing.bias_distinct_tiles (SrWindowAttn.bias_tiles: the LDS form of the window attention)."""
     T = table.shape[0]
     r = np.asarray(rpi, dtype=np.int64).reshape(nq, nk)
     r = np.where(r < 0, r + T, r)
@@ -352,7 +354,15 @@ def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) 
     b.put(slice(None), pi[r].transpose(2, 0, 1))
     bt = b.map(lambda a: np.ascontiguousarray(a.transpose(0, 2, 1)))
     bf = b.map(lambda a: a.reshape(HEADS, nq // 16, 16, nk // 16, 4, 4).transpose(0, 1, 3, 4, 2, 5).reshape(-1))
-    return b, bt, bf
+    b31 = None
+    if nq == 256 and nk == 256:
+        r5 = r.reshape(16, 16, 16, 16).transpose(0, 2, 1, 3)  # [qt, kt, i, j]
+        first = np.stack([r5[max(d - 15, 0), max(15 - d, 0)] for d in range(31)])
+        qt = np.arange(16)
+        if np.array_equal(first[qt[:, None] - qt[None, :] + 15], r5):
+            b31 = b.map(lambda a: np.stack([a.reshape(HEADS, 16, 16, 16, 16)[:, max(d - 15, 0), :, max(15 - d, 0), :] for d in range(31)], 1)
+                        .reshape(HEADS, 31, 16, 4, 4).transpose(0, 1, 3, 2, 4).reshape(-1))
+    return b, bt, bf, b31
 
 
 # --------------------------------------------------------------------------- one block (HAB or OCAB)
@@ -375,9 +385,10 @@ class BlockPlan:
         self.o_g2, self.o_b2 = fa.add(pack_vec(fp, blk.norm2.weight, CP)), fa.add(pack_vec(fp, blk.norm2.bias, CP))
         self.o_bp = fa.add(pack_vec(fp, at.proj.bias, CP))
         self.table = at.relative_position_bias_table
-        b, bt, bf = pack_bias(fp, self.table, rpi, 256, self.nk)
+        b, bt, bf, b31 = pack_bias(fp, self.table, rpi, 256, self.nk)
         self.o_bias, self.o_biasT = fa.add(b), fa.add(bt)
         self.o_biasF = None if oca else fa.add(bf)
+        self.o_bias31 = None if (oca or b31 is None or not ATTN_LDS) else fa.add(b31)
         self.cab = None
         if not oca:
             cab = blk.conv_block.cab
@@ -487,7 +498,7 @@ class BlockPlan:
                   vT=self.vT.data_ptr(), n1=self.n1.data_ptr(), ldn=CP, shift=self.shift, **g)
             akw = dict(q=self.q.data_ptr(), k=self.k.data_ptr(), vt=self.vT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), out=self.o.data_ptr(), n_bwin=nbw,
                        heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
-                       bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0)
+                       bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0, bias_tiles=None if self.o_bias31 is None else fa[self.o_bias31:].data_ptr())
             ckw = dict(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
                        y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
             if HAB_MID:  # the two independent launches as one (sr_hab_mid, ABI v8)

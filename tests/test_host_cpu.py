@@ -321,7 +321,10 @@ def test_index_form_packers_equal_the_value_packers():
     fp3 = FakeFP([table])
     rpi = rpi_sa(16)
     ref = packing.gather_bias(table, rpi, 256, 256)
-    b_, bt, bfr = F.pack_bias(fp3, table, rpi.numpy(), 256, 256)
+    b_, bt, bfr, b31 = F.pack_bias(fp3, table, rpi.numpy(), 256, 256)
+    tiles = packing.bias_distinct_tiles(packing.gather_bias(table, rpi, 256, 256))  # the 31 distinct tiles of the LDS-form window attention (ABI v8)
+    assert tiles is not None and b31 is not None and torch.equal(emulate(fp3, b31, torch.float32), tiles)
+    assert packing.bias_distinct_tiles(torch.randn(F.HEADS, 256, 256)) is None
     assert torch.equal(emulate(fp3, b_, torch.float32).reshape(6, 256, 256), ref)
     assert torch.equal(emulate(fp3, bt, torch.float32).reshape(6, 256, 256), ref.transpose(1, 2))
     assert torch.equal(emulate(fp3, bfr, torch.float32), packing.bias_fragments(ref))
