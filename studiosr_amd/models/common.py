@@ -249,8 +249,22 @@ class Model(nn.Module):
         return cls(scale=scale)
 
     def export(self, path: Optional[str] = None, input_shape: List[int] = [1, 3, 256, 256], format: str = "onnx") -> str:
-        """Reference: common.py:86-98 (torch.onnx.export).  The HIP forward is not traceable to ONNX."""
-        raise NotImplementedError("ONNX export is outside the MI355X hot path (SURVEY.md section 8b item 7)")
+        """Reference: common.py:86-98 (torch.onnx.export of the module's traced forward).  The forward here is a HIP launch sequence, which
+        torch.onnx cannot trace, so the export is ROUTED: format "checkpoint" writes the model in the reference's own
+        terms -- class name, get_model_config() and the state_dict with the reference's keys (torch.save) -- which the reference class loads with
+        `cls(**config).load_state_dict(...)` and exports with its own export(); format "onnx" says so instead of writing a wrong graph."""
+        format = format.lower()
+        if format == "onnx":
+            raise NotImplementedError(
+                "the MI355X forward is a HIP launch sequence and cannot be traced to ONNX: use export(format='checkpoint') and export that "
+                "checkpoint with the reference implementation's export() (same class name, config and state_dict keys)")
+        if format != "checkpoint":
+            raise ValueError(f"unknown export format {format!r} (expected 'onnx' or 'checkpoint')")
+        if path is None:
+            path = f"{self.__class__.__name__}x{self.scale}.pth"
+        torch.save({"class": self.__class__.__name__, "config": self.get_model_config(), "input_shape": list(input_shape),
+                    "state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()}}, path)
+        return path
 
 
 BaseModule = Model

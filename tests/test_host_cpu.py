@@ -328,3 +328,21 @@ def test_index_form_packers_equal_the_value_packers():
     assert torch.equal(emulate(fp3, b_, torch.float32).reshape(6, 256, 256), ref)
     assert torch.equal(emulate(fp3, bt, torch.float32).reshape(6, 256, 256), ref.transpose(1, 2))
     assert torch.equal(emulate(fp3, bfr, torch.float32), packing.bias_fragments(ref))
+
+
+def test_export_routes_to_a_reference_loadable_checkpoint(tmp_path):
+    """Model.export (common.py:86-98): the HIP forward cannot be traced to ONNX; format 'checkpoint' writes class / config / state_dict in the
+    reference's keys (what the reference class needs to rebuild the model and run its own export), format 'onnx' refuses loudly."""
+    import studiosr_amd as S
+
+    m = S.EDSR(scale=2, n_feats=16, n_resblocks=2)
+    with pytest.raises(NotImplementedError):
+        m.export(str(tmp_path / "m.onnx"))
+    with pytest.raises(ValueError):
+        m.export(format="tflite")
+    path = m.export(str(tmp_path / "m.pth"), format="checkpoint")
+    blob = torch.load(path, weights_only=True)
+    assert blob["class"] == "EDSR" and blob["config"] == m.get_model_config()
+    m2 = S.EDSR(**{k: v for k, v in blob["config"].items() if k in ("scale", "n_feats", "n_resblocks", "n_colors", "res_scale", "img_range")})
+    m2.load_state_dict(blob["state_dict"])
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))

@@ -103,6 +103,22 @@ assert out.shape == ref.shape and torch.equal(out, ref), float((out - ref).abs()
 """, 3, 29631)
 
 
+def test_row_strips_two_processes_at_config4_size_equal_the_unsharded_forward(tmp_path):
+    """BASELINE config 4's image size (2048 x 2048 LR, eval pad -> 2056: 257 window rows) over TWO processes with DistStripComm: paired isend / irecv halos of
+    every shifted block and every conv, gather of the 8192-wide HR strips -- bit-identical to the unsharded forward on every rank (reduced depth keeps it short:
+    the exchange pattern per block does not depend on the depth)."""
+    _run_ranks(tmp_path, """
+from studiosr_amd.strips import DistStripComm
+torch.manual_seed(0)
+m = S.SwinIR(scale=4, embed_dim=180, depths=[2, 2], num_heads=[6, 6]).to(dev).eval().set_precision('bf16')
+x = torch.rand(1, 3, 2048, 2048, generator=torch.Generator().manual_seed(1)).to(dev)
+with torch.no_grad():
+    ref = m(x)
+    out = m.forward_strips(x, DistStripComm())
+assert out.shape == (1, 3, 8192, 8192) and torch.equal(out, ref), float((out - ref).abs().max())
+""", 2, 29633)
+
+
 def test_tile_parallel_two_processes_with_the_hip_forward(tmp_path):
     _run_ranks(tmp_path, """
 from studiosr_amd.parallel import TileParallel
