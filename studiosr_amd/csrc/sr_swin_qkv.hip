@@ -7,6 +7,7 @@
 // (pass p: heads 2p, 2p+1; wave w: d-half w & 1 of head 2p + (w >> 1): q, k as [token][feature] tiles, v transposed) from ONE
 // 18-slot weight stream.  All three biases ride on the constant-one pad channels 180 / 181 of the image; the attention scale is in the q rows.
 // No barrier after the LayerNorm: the passes only read the image and write global memory.
+#include <type_traits>
 #include "sr_swin_stream.h"
 
 namespace {
@@ -22,9 +23,17 @@ struct SwinQkvDev {
     int ws_log2, nw;  // windows per image
 };
 
+// T = bf3 (SR_BF16X3, precision "fp32x3"): split operands, q / k / v^T leave as fp32 in the row-major / OCA layouts (what the fp32 attention kernels read).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
-    static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
+__global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 2 : 1) void sr_swin_qkv_kernel(SwinQkvDev dv) {
+    constexpr bool X3 = sizeof(Frag<T>) == 32;
+    using TO = typename std::conditional<X3, float, bf16>::type;  // element type of q / k / v^T
+    auto put4 = [](TO* dst, const f32x4& v) {
+        if constexpr (X3)
+            *reinterpret_cast<f32x4*>(dst) = v;
+        else
+            *reinterpret_cast<bf16x4*>(dst) = cvt4(v);
+    };
     const SrSwinQkv& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
         });
         const int head = 2 * p + hh;
         const size_t bh = bwin * a.heads + head;
-        if (a.frag_order) {
+        if (!X3 && a.frag_order) {
             // fragment order (SrWindowAttn.qkv_frag): q / k cell [tile = token >> 4][g = feature >> 3][i = token & 15][8]; v^T cell
             // [64-key block][d tile][32-key step][g = (key >> 2) & 3][i = d & 15][8] with element (key >> 4 & 1) * 4 + (key & 3)
             const size_t base = (bh << ntok_log2) * a.hd_p;
@@ -164,16 +173,16 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
             __builtin_amdgcn_sched_barrier(0);
             continue;
         }
-        bf16* qd = reinterpret_cast<bf16*>(a.q) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
+        TO* qd = reinterpret_cast<TO*>(a.q) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) *reinterpret_cast<bf16x4*>(qd + m * 16 * a.hd_p) = cvt4(acc[m][0]);
+        for (int m = 0; m < 4; ++m) put4(qd + m * 16 * a.hd_p, acc[m][0]);
         if (a.oca_pad == 0) {
-            bf16* kd = reinterpret_cast<bf16*>(a.k) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
-            bf16* vd = reinterpret_cast<bf16*>(a.vt) + (((bh * a.hd_p + 16 * half + ar) << ntok_log2) + part * NTOK + 4 * ag);
+            TO* kd = reinterpret_cast<TO*>(a.k) + (((bh << ntok_log2) + part * NTOK + ar) * a.hd_p + 16 * half + 4 * ag);
+            TO* vd = reinterpret_cast<TO*>(a.vt) + (((bh * a.hd_p + 16 * half + ar) << ntok_log2) + part * NTOK + 4 * ag);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                *reinterpret_cast<bf16x4*>(kd + m * 16 * a.hd_p) = cvt4(acc[m][1]);
-                *reinterpret_cast<bf16x4*>(vd + m * 16) = cvt4(acc[m][2]);
+                put4(kd + m * 16 * a.hd_p, acc[m][1]);
+                put4(vd + m * 16, acc[m][2]);
             }
         } else {
             // overlapping cross attention (hat.py:247-264): k -> zero-bordered image order [B][H+2e][W+2e][heads][hd_p], v -> transposed zero-bordered
@@ -186,13 +195,13 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
                     const int tw = (int)part * NTOK + m * 16 + ar;
                     const int y = ((int)wy << wsl) + (tw >> wsl), x = ((int)wx << wsl) + (tw & wsm);
                     const size_t off = ((((size_t)bimg * (a.H + 2 * e) + y + e) * Wb + x + e) * a.heads + head) * a.hd_p + 16 * half + 4 * ag;
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k) + off) = cvt4(acc[m][1]);
+                    put4(reinterpret_cast<TO*>(a.k) + off, acc[m][1]);
                 }
                 {
                     const int tw = (int)part * NTOK + m * 16 + 4 * ag;
                     const int y = ((int)wy << wsl) + (tw >> wsl), x = ((int)wx << wsl) + (tw & wsm);
                     const size_t off = (((size_t)bimg * a.heads + head) * a.hd_p + 16 * half + ar) * plane + (size_t)(y + e) * Wb + x + e;
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt) + off) = cvt4(acc[m][2]);
+                    put4(reinterpret_cast<TO*>(a.vt) + off, acc[m][2]);
                 }
             }
         }
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void sr_swin_qkv_kernel(SwinQkvDev dv) {
 }  // namespace
 
 extern "C" int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype) {
-    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16)) ? 1 : 0;
+    return ((compute_dtype == SR_BF16 || compute_dtype == SR_BF16X3) && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16)) ? 1 : 0;
 }
 
 extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
@@ -214,7 +223,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
                    a.y_mode >= SR_Y_ROLL && a.y_mode <= SR_Y_STRIP_LAST,
                "sr_swin_qkv: bad geometry");
     SR_REQUIRE(a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "sr_swin_qkv: the stream rows must be 16-byte aligned (ldx a multiple of 4, x 16-byte aligned)");
-    SR_REQUIRE(!a.frag_order || (a.ws == 16 && a.oca_pad == 0 && a.hd_p == 32), "sr_swin_qkv: frag_order needs 16 x 16 windows and oca_pad == 0");
+    SR_REQUIRE(!a.frag_order || (a.ws == 16 && a.oca_pad == 0 && a.hd_p == 32 && a.compute_dtype == SR_BF16), "sr_swin_qkv: frag_order needs 16 x 16 windows, oca_pad == 0 and SR_BF16");
     SR_REQUIRE(a.oca_pad == 0 || (a.oca_pad > 0 && a.oca_pad % 4 == 0 && a.shift == 0 && a.y_mode == SR_Y_ROLL), "sr_swin_qkv: OCA layouts need shift 0 and a border that is a multiple of 4");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");
     SwinQkvDev dv;
@@ -225,6 +234,14 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
     dv.ws_log2 = a.ws == 8 ? 3 : 4;
     dv.nw = nwx * nwy;
+    if (a.compute_dtype == SR_BF16X3) {
+        static SrDeviceOnce once3;
+        const hipError_t e = sr_once_per_device(once3, [&] { return sr_allow_lds(sr_swin_qkv_kernel<bf3>, Lds<bf3>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_qkv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(sr_swin_qkv_kernel<bf3>, dim3(a.B * nwx * nwy * parts), dim3(256), Lds<bf3>::TOTAL, reinterpret_cast<hipStream_t>(stream), dv);
+        SR_CHECK_LAUNCH("sr_swin_qkv");
+        return SR_OK;
+    }
     static SrDeviceOnce attr_once;
     {
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_qkv_kernel<bf16>, Lds<bf16>::TOTAL); });

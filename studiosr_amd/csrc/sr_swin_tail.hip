@@ -11,6 +11,7 @@
 //   * projection = 6 uniform steps, MLP = 2 x (6 fc1 + 6 fc2) steps from ONE 30-slot weight stream two slots ahead in registers;
 //     fc1 / fc2 biases ride on the constant-one pad channels exactly as in sr_swin_block (same slots 24..47 of that stream);
 //   * x1 never leaves the registers; the result leaves through the LDS row tile as full 768-B rows.
+#include <type_traits>
 #include "sr_swin_stream.h"
 #include "sr_ca.h"
 
@@ -60,9 +61,13 @@ SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
 // QKV = true: the kernel goes on with LayerNorm1 + QKV projection of the NEXT block on the same 64 tokens (sr_swin_qkv.hip's passes; weight
 // slots 30..47 of the stream) and scatters q / k / v^T into that block's window order (its shift differs): one launch less on the critical
 // chain tail -> qkv -> attention of a HAB, and the ring prefetches the QKV weights through the MLP.
+// T = bf3 (compute type SR_BF16X3, precision "fp32x3" = what inference() runs): split operands as in sr_swin_block3.hip; O, y and the LayerNorm side output are
+// fp32 tensors (the fp32 attention kernel / the split-operand convs write and read those), O passes through LDS as fp32 rows (the x-tile geometry) and is
+// split into hi | lo fragments as it is read; 98 KiB of LDS, one workgroup per CU; no fused next-block QKV.
 template <typename T, bool QKV>
-__global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTailDev dv) {
-    static_assert(sizeof(Frag<T>) == 16, "bf16 operands");
+__global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void sr_swin_tail_kernel(SwinTailDev dv) {
+    constexpr bool X3 = sizeof(Frag<T>) == 32;
+    static_assert(!(X3 && QKV), "the fused next-block QKV exists for bf16 operands only");
     const SrSwinTail& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);  // O image (token-major, 400-B rows) first, then the LayerNorm2 image [24 k-groups][64 tokens]
@@ -102,6 +107,11 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         // coalesced 1-KiB LDS-DMA pieces; cell q = 64 j + lane of piece j is 16-B column q % 25 of row q / 25 (column 24 = padding, masked)
         const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
         const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NTOK * OROW;
+        if constexpr (X3) {  // fp32 rows of 768 B -> the x-tile geometry (XS stride), 16 rows per wave
+            const float* of = reinterpret_cast<const float*>(a.o) + (size_t)blockIdx.x * NTOK * 192;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dma_row48(of + (size_t)(16 * w + i) * 192, __builtin_amdgcn_readfirstlane(img_lds + (16 * w + i) * XS), lane);
+        } else
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int j = w + 4 * i;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
     TSTAMP(16);
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
     f32x4 gt[3], bp[3];
-    bf16x4 yv[4][3];
+    typename std::conditional<X3, f32x4, bf16x4>::type yv[4][3];  // y: fp32 on the split-operand path
     const int ch0 = w * 48 + ag * 4;
     {
         int prow[4];
@@ -145,7 +155,12 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 3; ++n) yv[m][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.y) + (size_t)prow[m] * a.ldy + ch0 + n * 16);
+                for (int n = 0; n < 3; ++n) {
+                    if constexpr (X3)
+                        yv[m][n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.y) + (size_t)prow[m] * a.ldy + ch0 + n * 16);
+                    else
+                        yv[m][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(a.y) + (size_t)prow[m] * a.ldy + ch0 + n * 16);
+                }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         SrChannelAttn ca;
         ca.pool_partial = a.pool_partial; ca.w1 = a.ca_w1; ca.b1 = a.ca_b1; ca.w2 = a.ca_w2; ca.b2 = a.ca_b2;
         ca.B = a.B; ca.H = a.H; ca.W = a.W; ca.C = a.C; ca.C_p = a.Cp; ca.Cr = a.ca_Cr; ca.n_tiles = a.ca_n_tiles; ca.y_scale = a.y_scale;
-        const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + NTOK * OSTRIDE));
+        const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + (X3 ? LDS_X : NTOK * OSTRIDE)));
 #pragma unroll
         for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
     }
@@ -176,9 +191,15 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
 
     // ---- projection on top of the shortcut: x1 += O @ Wproj^T (K = 6 heads x 32 features, the pad features are 0 on both sides)
     auto loada_o = [&](int c, int h, Frag<T> (&av)[2]) {
-        const char* ob = smem + (h * 32 + ar) * OSTRIDE + (c * 4 + ag) * 16;
-        av[0] = *reinterpret_cast<const Frag<T>*>(ob);
-        av[1] = *reinterpret_cast<const Frag<T>*>(ob + 16 * OSTRIDE);
+        if constexpr (X3) {  // 8 fp32 features of one token -> hi | lo fragment
+            const char* ob = smem + (h * 32 + ar) * XS + (c * 32 + ag * 8) * 4;
+            av[0] = pack2<T>(*reinterpret_cast<const f32x4*>(ob), *reinterpret_cast<const f32x4*>(ob + 16));
+            av[1] = pack2<T>(*reinterpret_cast<const f32x4*>(ob + 16 * XS), *reinterpret_cast<const f32x4*>(ob + 16 * XS + 16));
+        } else {
+            const char* ob = smem + (h * 32 + ar) * OSTRIDE + (c * 4 + ag) * 16;
+            av[0] = *reinterpret_cast<const Frag<T>*>(ob);
+            av[1] = *reinterpret_cast<const Frag<T>*>(ob + 16 * OSTRIDE);
+        }
     };
     ws.template run<6>(0, lane, loada_o, [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
 #pragma unroll
@@ -269,6 +290,13 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
                 f32x4 g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = gelu_op<T>(acc[m][n][r]);
+                if constexpr (X3) {  // hidden pad columns 360, 361 = the constant one of the fc2 bias rows (sr_swin_block3.hip)
+                    if (hf == 1 && n == 1) {
+                        const bool one_h = (w == 3) && (ag == 2);
+                        g[0] = one_h ? 1.0f : g[0];
+                        g[1] = one_h ? 1.0f : g[1];
+                    }
+                }
                 st_half(Himg + (6 * w + 2 * n + (ag >> 1)) * NTOK + m * 16 + ar, ag & 1, g);
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -330,13 +358,16 @@ __global__ __launch_bounds__(256, SR_TAIL_WGS) void sr_swin_tail_kernel(SwinTail
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            bf16* nrow = reinterpret_cast<bf16*>(a.n1) + (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
+            const size_t noff = (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
                 f32x4 nv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean[m]) * rstd[m], gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
-                *reinterpret_cast<bf16x4*>(nrow + n * 16) = cvt4(nv);
+                if constexpr (X3)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.n1) + noff + n * 16) = nv;
+                else
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.n1) + noff + n * 16) = cvt4(nv);
             }
         }
     }
@@ -439,7 +470,7 @@ extern "C" int sr_debug_tail_stamps(unsigned long long* host32) {
 #endif
 
 extern "C" int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
-    return (compute_dtype == SR_BF16 && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16) && Hp == 384) ? 1 : 0;
+    return ((compute_dtype == SR_BF16 || compute_dtype == SR_BF16X3) && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && (ws == 8 || ws == 16) && Hp == 384) ? 1 : 0;
 }
 
 extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
@@ -459,6 +490,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(!a.q2 || (a.k2 && a.vt2 && a.shift2 >= 0 && a.shift2 < a.ws && a.shift2 % 4 == 0 && a.shift % 4 == 0 && a.y_mode == SR_Y_ROLL),
                "sr_swin_tail: the fused next-block QKV needs q2 / k2 / vt2, shifts that are multiples of 4 and y_mode SR_Y_ROLL");
     SR_REQUIRE(!a.frag_order || (a.q2 && a.ws == 16), "sr_swin_tail: frag_order is a layout of q2 / k2 / vt2 for 16 x 16 windows");
+    SR_REQUIRE(a.compute_dtype == SR_BF16 || !a.q2, "sr_swin_tail: the fused next-block QKV exists for SR_BF16 only");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;
     dv.a = a;
@@ -470,7 +502,12 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     dv.nw = nwx * nwy;
     const dim3 grid(a.B * nwx * nwy * parts);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (a.q2) {
+    if (a.compute_dtype == SR_BF16X3) {
+        static SrDeviceOnce attr_once;
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf3, false>, Lds<bf3>::TOTAL); });
+        SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_swin_tail_kernel<bf3, false>), grid, dim3(256), Lds<bf3>::TOTAL, st, dv);
+    } else if (a.q2) {
         static SrDeviceOnce attr_once;
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true>, Lds<bf16>::TOTAL); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -237,7 +237,7 @@ class HAT(Model):
                 e["ca"] = pack_ca(att[1].weight, att[1].bias, att[3].weight, att[3].bias)
                 blocks.append(e)
             for i in range(len(blocks) - 1):  # sr_swin_tail of block i continues with block i + 1's LayerNorm1 + QKV: one stream
-                if "tail_stream" in blocks[i] and "qkv_stream" in blocks[i + 1]:
+                if blocks[i].get("tail_dtype") == L.SR_BF16 and "qkv_stream" in blocks[i + 1]:
                     blocks[i]["tail_qkv_stream"] = torch.cat([blocks[i]["tail_stream"], blocks[i + 1]["qkv_stream"]]).contiguous()
             oc = layer.residual_group.overlap_attn
             o = dict(ln1=pack_ln(oc.norm1, Cp), ln2=pack_ln(oc.norm2, Cp))
@@ -306,7 +306,7 @@ class HAT(Model):
         w1, b1, w2, b2 = bp["ca"]
         gate_in_tail = unfused and swin_tail_usable(bp, geo, Cp, cdt) and knob("SR_TAIL_GATE", "1") != "0" and w1.shape[0] <= 8
         # the tail kernel goes on with the next block's LayerNorm1 + QKV (its attention kernel is the next launch of the chain)
-        fuse_next_qkv = (unfused and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
+        fuse_next_qkv = (unfused and cdt == torch.bfloat16 and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
                          and knob("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
 
         # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
@@ -366,7 +366,7 @@ class HAT(Model):
             if gate_in_tail:
                 d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
                                  ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))
-            if next_ln is not None and n1.dtype == torch.bfloat16:  # n1's last reader (this block's first conv) has joined: the tail may overwrite it
+            if next_ln is not None:  # n1's last reader (this block's first conv) has joined: the tail may overwrite it (bf16; fp32 on the split-operand path)
                 d.update(n1=n1, n1_ln=next_ln)
             return d
 
@@ -374,7 +374,7 @@ class HAT(Model):
         used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready,
                               attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None)
         if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
-            return next_ln is not None and n1.dtype == torch.bfloat16, fuse_next_qkv
+            return next_ln is not None, fuse_next_qkv
         if not used:
             # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
             if side is not main:
@@ -397,7 +397,7 @@ class HAT(Model):
         fold = fold_ln(cdt)
         if swin_qkv_usable(op, geo, Cp, cdt) and e % 4 == 0:  # stream form: LayerNorm1 + QKV with k / v^T in the zero-bordered layouts
             ops.swin_qkv(x=t.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=op["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp,
-                         ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=0, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, oca_pad=e)
+                         ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=0, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=op["qkv_dtype"], oca_pad=e)
         else:
             ops.gemm(
                 A=t.data_ptr(), Wp=op["qkv_w"].data_ptr(), bias=op["qkv_b"].data_ptr(), ln_gamma=None if fold else op["ln1"][0].data_ptr(),

@@ -185,37 +185,53 @@ def pack_light_block(blk: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict
 
 def pack_tail_stream(proj: nn.Module, mlp: nn.Module, norm2: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
     """Weight stream of sr_swin_tail (ABI v6: projection + shortcut + LayerNorm2 + MLP behind a separate attention kernel; hat.py:172-194,
-    286-293) when the kernel covers the geometry (bf16 path only)."""
-    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.hidden == 360 and geo.ws in (8, 16)):
+    286-293) when the kernel covers the geometry: bf16 operands, or split operands (hi | lo) for precision "fp32x3"."""
+    from ..runtime import X3_KEY
+
+    x3 = dt == X3_KEY
+    if not ((x3 or fold_ln(dt)) and geo.C == 180 and geo.heads == 6 and geo.hidden == 360 and geo.ws in (8, 16)):
         return {}
     w1, b1 = packing.fold_layernorm(mlp.fc1.weight, mlp.fc1.bias, norm2.weight, norm2.bias)
-    return dict(tail_stream=packing.pack_swin_tail_stream(proj.weight, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden))
+    return dict(tail_stream=packing.pack_swin_tail_stream(proj.weight, w1, b1, mlp.fc2.weight, mlp.fc2.bias, geo.C, geo.heads, geo.hidden, x3=x3),
+                tail_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
 
 
 def pack_qkv_stream(attn: nn.Module, norm1: nn.Module, geo: SwinGeometry, dt: torch.dtype) -> Dict:
-    """Weight stream of sr_swin_qkv (ABI v6: LayerNorm1 + QKV projection in front of sr_window_attention; hat.py:164-176), bf16 path only."""
-    if not (fold_ln(dt) and geo.C == 180 and geo.heads == 6 and geo.ws in (8, 16)):
+    """Weight stream of sr_swin_qkv (ABI v6: LayerNorm1 + QKV projection in front of sr_window_attention; hat.py:164-176): bf16 operands, or split
+    operands (hi | lo) for precision "fp32x3"."""
+    from ..runtime import X3_KEY
+
+    x3 = dt == X3_KEY
+    if not ((x3 or fold_ln(dt)) and geo.C == 180 and geo.heads == 6 and geo.ws in (8, 16)):
         return {}
     qw, qb = packing.fold_layernorm(attn.qkv.weight, attn.qkv.bias, norm1.weight, norm1.bias)
-    return dict(qkv_stream=packing.pack_swin_qkv_stream(qw, qb, geo.C, geo.heads))
+    return dict(qkv_stream=packing.pack_swin_qkv_stream(qw, qb, geo.C, geo.heads, x3=x3), qkv_dtype=L.SR_BF16X3 if x3 else L.SR_BF16)
+
+
+def stream_compute_dtype(cdt: torch.dtype) -> int:
+    """Compute type of the stream-form kernels for this forward: SR_BF16 (bf16 path), SR_BF16X3 (fp32 tensors inside a precision="fp32x3" forward), -1 (exact fp32)."""
+    from ..runtime import x3_active
+
+    return L.SR_BF16 if cdt == torch.bfloat16 else (L.SR_BF16X3 if x3_active() else -1)
 
 
 def swin_qkv_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_QKV=0 keeps the QKV GEMM (A/B switch, read per call)."""
-    return ("qkv_stream" in p and cdt == torch.bfloat16 and knob("SR_SWIN_QKV", "1") != "0"
-            and ops.swin_qkv_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, L.SR_BF16))
+    want = stream_compute_dtype(cdt)
+    return (p.get("qkv_dtype", -2) == want and knob("SR_SWIN_QKV", "1") != "0" and ops.swin_qkv_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, want))
 
 
 def qkv_frag_order(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """q / k / v^T between sr_swin_qkv (or sr_swin_tail's fused QKV stage) and sr_window_attention in FRAGMENT order (every operand fragment of the attention
     kernel = one coalesced 1-KiB load): 16 x 16 windows, bf16, stream-form producer.  SR_QKV_FRAG=0 keeps the row-major layouts."""
-    return geo.ntok == 256 and geo.hd_p == 32 and swin_qkv_usable(p, geo, Cp, cdt) and knob("SR_QKV_FRAG", "1") != "0"
+    return geo.ntok == 256 and geo.hd_p == 32 and cdt == torch.bfloat16 and swin_qkv_usable(p, geo, Cp, cdt) and knob("SR_QKV_FRAG", "1") != "0"
 
 
 def swin_tail_usable(p: Dict, geo: SwinGeometry, Cp: int, cdt: torch.dtype) -> bool:
     """SR_SWIN_TAIL=0 keeps the projection GEMM + MLP kernel (A/B switch, read per call)."""
-    return ("tail_stream" in p and cdt == torch.bfloat16 and knob("SR_SWIN_TAIL", "1") != "0"
-            and ops.swin_tail_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, L.SR_BF16))
+    want = stream_compute_dtype(cdt)
+    return (p.get("tail_dtype", -2) == want and knob("SR_SWIN_TAIL", "1") != "0"
+            and ops.swin_tail_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, want))
 
 
 def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Tensor, shift: int, y_mode: int = L.Y_ROLL, extra: Optional[Dict] = None) -> None:
@@ -232,16 +248,17 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
         wstream = p["tail_qkv_stream"]
         kw.update(q2=qkv_next["q"].data_ptr(), k2=qkv_next["k"].data_ptr(), vt2=qkv_next["vt"].data_ptr(), shift2=int(qkv_next["shift"]),
                   frag_order=int(bool(qkv_next.get("frag"))))
+    x3 = p["tail_dtype"] == L.SR_BF16X3  # split operands: o, y and the LayerNorm side output are fp32 tensors
     if n1 is not None:
-        assert n1.dtype == torch.bfloat16 and n1.shape == skip.shape
+        assert n1.dtype == (torch.float32 if x3 else torch.bfloat16) and n1.shape == skip.shape
         kw.update(n1=n1.data_ptr(), n1_gamma=n1_ln[0].data_ptr(), n1_beta=n1_ln[1].data_ptr(), ldn=Cp)
     if extra:
-        assert extra["skip2_dtype"] == L.SR_BF16 and extra["gate_rows"] == H * W
+        assert extra["skip2_dtype"] == (L.SR_F32 if x3 else L.SR_BF16) and extra["gate_rows"] == H * W
         kw.update(y=extra["skip2"], gate=extra["skip2_gate"], ldy=extra["ldskip2"], ld_gate=extra["ld_gate"])
     ops.swin_tail(
         x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=wstream.data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
         C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
-        compute_dtype=L.SR_BF16, **kw,
+        compute_dtype=p["tail_dtype"], **kw,
     )
 
 
@@ -312,7 +329,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
         pass
     elif swin_qkv_usable(p, geo, Cp, cdt):
         ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
-                     Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=L.SR_BF16,
+                     Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=p["qkv_dtype"],
                      frag_order=int(frag))
     else:
         ops.gemm(

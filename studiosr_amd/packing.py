@@ -279,8 +279,15 @@ def pack_swin_block_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], proj_w: Tenso
 SWIN_TAIL_SLOTS = 30
 
 
+def _hi_lo_cat(out: Tensor) -> Tensor:
+    """fp32 [..., 8] fragments -> split-operand layout [..., 8 hi | 8 lo] bf16 (compute type SR_BF16X3)."""
+    hi = out.to(torch.bfloat16)
+    lo = (out - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1)
+
+
 def pack_swin_tail_stream(proj_w: Tensor, fc1_w: Tensor, fc1_b: Optional[Tensor], fc2_w: Tensor, fc2_b: Optional[Tensor], C: int, heads: int,
-                          hidden: int) -> Tensor:
+                          hidden: int, x3: bool = False) -> Tensor:
     """The weight stream of sr_swin_tail (include/studiosr_hip.h SrSwinTail; hat.py:172-194): 30 slots x 12 fragments x [64 lanes][8] bf16 --
     6 projection slots (slot = head: K = the head's 32 padded features of the attention output, no bias: the kernel adds bproj itself),
     then the 24 MLP slots of pack_swin_block_stream (fc1 with LayerNorm2 folded by the caller; fc1 / fc2 biases on the constant-one pad
@@ -292,16 +299,17 @@ def pack_swin_tail_stream(proj_w: Tensor, fc1_w: Tensor, fc1_b: Optional[Tensor]
     M_proj = torch.zeros(Cp, heads, hdp, dtype=f32, device=dev)
     M_proj[:C, :, :hd] = proj_w.detach().to(f32).reshape(C, heads, hd)
     # M_proj[ch = 48 w + 16 n + i, head = c, d = 8 g + j] -> [c, 3 w + n, 16 g + i, j]
-    proj = M_proj.reshape(4, 3, 16, heads, 4, 8).permute(3, 0, 1, 4, 2, 5).reshape(heads, 12, 64, 8).to(torch.bfloat16).reshape(-1)
+    proj = M_proj.reshape(4, 3, 16, heads, 4, 8).permute(3, 0, 1, 4, 2, 5).reshape(heads, 12, 64, 8)
+    proj = (_hi_lo_cat(proj) if x3 else proj.to(torch.bfloat16)).reshape(-1)  # x3: [slot][fragment][lane][8 hi | 8 lo]
     zero = torch.zeros(3 * C, C, dtype=f32, device=dev)
-    full = pack_swin_block_stream(zero, None, proj_w, None, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden)
+    full = pack_swin_block_stream(zero, None, proj_w, None, fc1_w, fc1_b, fc2_w, fc2_b, C, heads, hidden, x3=x3)
     return torch.cat([proj, full.reshape(SWIN_STREAM_SLOTS, -1)[24:].reshape(-1)]).contiguous()
 
 
 SWIN_QKV_SLOTS = 18
 
 
-def pack_swin_qkv_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], C: int, heads: int) -> Tensor:
+def pack_swin_qkv_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], C: int, heads: int, x3: bool = False) -> Tensor:
     """The weight stream of sr_swin_qkv (include/studiosr_hip.h SrSwinQkv; hat.py:164-176, 55-83): 18 slots x 12 fragments x [64 lanes][8] bf16
     -- per pass p (heads 2p, 2p+1) six K-chunk slots; wave w = (head 2p + (w >> 1), d-half w & 1) reads fragments 3w .. 3w+2 = its q, k, v
     tiles.  qkv_w / qkv_b are the LayerNorm-folded fp32 matrices; the attention scale hd^-0.5 goes into the q rows (plain exp softmax in the
@@ -317,9 +325,9 @@ def pack_swin_qkv_stream(qkv_w: Tensor, qkv_b: Optional[Tensor], C: int, heads: 
     b = qkv_b.reshape(3, heads, hd).clone()
     M[0] *= hd ** -0.5
     b[0] *= hd ** -0.5
-    b_hi, b_lo = _bf16_hi_lo(b)
+    b_hi, b_lo = (_split16 if x3 else _bf16_hi_lo)(b)
     M[:, :, :hd, C] = b_hi
     M[:, :, :hd, C + 1] = b_lo
     # M[t, head = 2p + hh, d = 16 half + i, k = 32 c + 8 g + j] -> [p, c, 3 (2 hh + half) + t, 16 g + i, j]
     out = M.reshape(3, 3, 2, 2, 16, 6, 4, 8).permute(1, 5, 2, 3, 0, 6, 4, 7).reshape(3, 6, 12, 64, 8)
-    return out.to(torch.bfloat16).reshape(-1).contiguous()
+    return (_hi_lo_cat(out) if x3 else out.to(torch.bfloat16)).reshape(-1).contiguous()

@@ -593,17 +593,18 @@ def test_rgb_tail_conv_persistent_kernel_against_conv2d(cin, shape):
     assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("ws", [8, 16])
-def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launches(ws, monkeypatch):
+@pytest.mark.parametrize("ws,prec", [(8, "bf16"), (16, "bf16"), (8, "fp32x3"), (16, "fp32x3")])
+def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launches(ws, prec, monkeypatch):
     """run_window_msa + MLP of one packed HAT block on a stream tensor, with the stream-form kernels (sr_swin_qkv, sr_swin_tail) and with the
     launches they replace (sr_gemm SR_EPI_QKV, sr_gemm projection, sr_mlp_fused): windows of 8 x 8 (one 64-token part) and 16 x 16 (four
-    parts), shifted and unshifted, separate skip tensor (so that the one-kernel attention half of the 8 x 8 geometry is not taken)."""
+    parts), shifted and unshifted, separate skip tensor (so that the one-kernel attention half of the 8 x 8 geometry is not taken); bf16 operands and
+    the split-operand instantiations of precision "fp32x3" (fp32 q / k / v^T / o; agreement at fp32 level)."""
     from studiosr_amd.models import swinir as SW
-    from studiosr_amd.runtime import Workspace
+    from studiosr_amd.runtime import Workspace, x3_mode
 
     torch.manual_seed(31)
-    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=31).to(DEV).eval().set_precision("bf16")
-    cdt = torch.bfloat16
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6], window_size=ws), seed=31).to(DEV).eval().set_precision(prec)
+    cdt = torch.bfloat16 if prec == "bf16" else torch.float32
     lp = m._get_packed(cdt)["layers"][0]
     geo = lp["geo"]
     B, H, W = 2, 3 * ws, 2 * ws
@@ -618,17 +619,19 @@ def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launche
             monkeypatch.setenv("SR_SWIN_TAIL", flag)
             S.runtime.reset_knobs()  # (the switches are read once per forward; this test drives the block helpers directly)
             out = torch.full_like(t_in, float("nan"))
-            used = SW.run_window_msa(bp, bp["ln1"], geo, t_in, out, skip, Workspace(DEV), cdt, bp["shift"], name=f"t{flag}", with_mlp=True)
-            assert (used == "tail") == (flag == "1")
-            if used != "tail":
-                SW.run_mlp(bp, bp["ln2"], geo, out, Workspace(DEV), cdt)
+            with x3_mode(prec == "fp32x3"):
+                used = SW.run_window_msa(bp, bp["ln1"], geo, t_in, out, skip, Workspace(DEV), cdt, bp["shift"], name=f"t{flag}", with_mlp=True)
+                assert (used == "tail") == (flag == "1")
+                if used != "tail":
+                    SW.run_mlp(bp, bp["ln2"], geo, out, Workspace(DEV), cdt)
             torch.cuda.synchronize()
             outs.append(out.clone())
         new, old = outs
         assert not torch.isnan(new).any() and float(new[..., geo.C:].abs().max()) == 0.0
         scale = float(old.abs().max())
-        assert float((new - old).abs().max()) <= 1.0e-2 * scale, f"shift {bp['shift']}"
-        assert float((new - old).pow(2).mean().sqrt()) <= 1.5e-3 * scale
+        tol, rms = (1.0e-2, 1.5e-3) if prec == "bf16" else (3.0e-5, 5.0e-6)
+        assert float((new - old).abs().max()) <= tol * scale, (f"shift {bp['shift']}", float((new - old).abs().max()) / scale)
+        assert float((new - old).pow(2).mean().sqrt()) <= rms * scale
 
 
 @pytest.mark.parametrize("ws", [8, 16])
