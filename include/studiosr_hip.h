@@ -530,7 +530,8 @@ typedef struct SrTrAttnBwd {
      * lse, delta [bwin][head][Nq] fp32 (written, then read by the second pass).  The relative_position_bias_table gradient leaves as
      * dtab_part [heads * groups * Nq / 64][Tpad] fp32: workgroup (head, group, 64 queries) sums dS over the group's windows and folds it through
      * rpi [Nq * Nk] (int32, negative entries wrap by T rows) into one table-sized partial; dtable[t][h] = sum of head h's groups * Nq / 64
-     * consecutive partials (sr_tr_finalize). */
+     * consecutive partials (sr_tr_finalize).  Nk = 256 with toeplitz16 and groups * 4 == n_bwin (one partial per (head, window)): ONE launch with every operand
+     * of the inner loops in LDS (csrc/sr_tr_attn_lds.hip) instead of the two register-only passes; same outputs. */
     const void* q; const void* qT; const void* k; const void* kT; const void* v;
     const void* o; const void* dO; const void* dOT;
     const float* bias; const float* biasT;

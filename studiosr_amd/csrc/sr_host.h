@@ -67,3 +67,8 @@ int sr_oca_attention_flash(const SrOcaAttn& o, hipStream_t st);
 struct SrSwinAttn;
 bool sr_swin_block_v2_enabled();
 int sr_swin_block_v2(const SrSwinAttn& a, hipStream_t st);
+
+// LDS form of the window-attention backward for 16 x 16 windows (sr_tr_attn_lds.hip): one launch instead of sr_tr_attn.hip's two passes
+struct SrTrAttnBwd;
+bool sr_tr_attn_bwd_lds_usable(const SrTrAttnBwd& a);
+int sr_tr_attn_bwd_lds(const SrTrAttnBwd& a, hipStream_t st);

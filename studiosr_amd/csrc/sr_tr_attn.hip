@@ -493,7 +493,8 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
         b.H = b.W = 16;
     }
     SR_REQUIRE(a.T > 0 && a.T <= 1536 && a.Tpad >= a.T, "sr_tr_attn_bwd: the bias table has at most 1536 rows");
-    const int items_q = a.groups * a.heads * (a.Nq / 16), items_kv = a.n_bwin * a.heads * (a.Nk / 32);
+    if (sr_tr_attn_bwd_lds_usable(b)) return sr_tr_attn_bwd_lds(b, st);  // 16 x 16 windows, one table partial per (head, window): everything in LDS, one launch
+    const int items_q = a.groups * a.heads * (a.Nq / 16);
     static const int var = getenv("SR_TR_QVAR") ? atoi(getenv("SR_TR_QVAR")) : 1;  // 0: the generic index-map fold (A/B knob)
     if (a.Nk == 256) {
         if (var == 1 && a.toeplitz16)

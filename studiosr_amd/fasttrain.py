@@ -844,9 +844,12 @@ class HatPlan:
         dev = self.fp.P.device
         fp, fm, m = self.fp, self.fm, self.model
         nbw = B * H * W // 256
-        groups = max(1, min(nbw, 16))
-        while nbw % groups:
-            groups -= 1
+        if nbw % 4 == 0 and os.environ.get("SR_TR_ATTN_LDS", "1") != "0":
+            groups = nbw // 4  # one bias-table partial per (head, window): the LDS form of the attention backward (csrc/sr_tr_attn_lds.hip)
+        else:
+            groups = max(1, min(nbw, 16))
+            while nbw % groups:
+                groups -= 1
         self.scratch = Scratch(B, H, W, dev, groups)
         for s in self.stages:
             s.prepare(B, H, W, dev, self.scratch)

@@ -500,3 +500,52 @@ dist.barrier(); dist.destroy_process_group(); print("DDP_OK", worst)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29627", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.count("DDP_OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass")])
+def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
+    """sr_tr_attn_bwd (swinir.py:83-102 / hat.py:90-107 under loss.backward()) on 16 x 16 windows against torch autograd of softmax(q k^T + table[rpi] + mask) v on
+    the same bf16-rounded operands: dq, dk, dv and the relative_position_bias_table gradient.  "lds" = the one-launch LDS form (csrc/sr_tr_attn_lds.hip, taken when
+    groups * 4 == n_bwin: one table partial per (head, window)), "two-pass" = the register-only passes of csrc/sr_tr_attn.hip; masked windows included."""
+    from studiosr_amd import _lib as L, autograd as A, fasttrain as FT
+    from studiosr_amd.models.hat import rpi_sa
+
+    bf = torch.bfloat16
+    torch.manual_seed(1)
+    Bn, H, W = 2, 32, 48
+    nb, h, N = Bn * (H // 16) * (W // 16), 6, 256
+    q, k = torch.randn(nb, h, N, 32, device=DEV) * 0.3, torch.randn(nb, h, N, 32, device=DEV) * 0.3
+    v = torch.randn(nb, h, N, 32, device=DEV)
+    for t in (q, k, v):
+        t[..., 30:] = 0
+    rpi = rpi_sa(16).to(DEV)
+    table = (torch.randn(961, h, device=DEV) * 0.2).requires_grad_(True)
+    dO = torch.randn(nb, N, h * 32, device=DEV)
+    qb, kb, vb, dOb = (t.to(bf) for t in (q, k, v, dO))
+    mask = A.shift_mask(H, W, 16, shift, DEV).repeat(Bn, 1, 1) if shift else None
+    q_, k_, v_ = (t.float().clone().requires_grad_(True) for t in (qb, kb, vb))
+    s = q_ @ k_.transpose(-1, -2) + table[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1)[None]
+    if mask is not None:
+        s = s + mask[:, None]
+    o = torch.softmax(s, -1) @ v_
+    o_rows = o.permute(0, 2, 1, 3).reshape(nb, N, h * 32)
+    o_rows.backward(dOb.float())
+    bias = table.detach()[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1).contiguous()
+    groups = nb // 4 if form == "lds" else 4
+    assert (groups * 4 == nb) == (form == "lds")
+    dq, dk, dv = (torch.full((nb, h, N, 32), float("nan"), device=DEV).to(bf) for _ in range(3))
+    lse, delta = torch.zeros(nb, h, N, device=DEV), torch.zeros(nb, h, N, device=DEV)
+    dtp = torch.full((h * groups * 4, 1024), float("nan"), device=DEV)
+    qT, kT = qb.transpose(-1, -2).contiguous(), kb.transpose(-1, -2).contiguous()
+    dOT = dOb.reshape(nb, N, h, 32).permute(0, 2, 3, 1).contiguous()
+    ob = o_rows.detach().to(bf).contiguous()
+    rpi32 = rpi.to(torch.int32).contiguous()
+    FT._call(L.lib().sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=qb.data_ptr(), qT=qT.data_ptr(), k=kb.data_ptr(), kT=kT.data_ptr(), v=vb.data_ptr(), o=ob.data_ptr(),
+             dO=dOb.data_ptr(), dOT=dOT.data_ptr(), bias=bias.data_ptr(), biasT=bias.transpose(1, 2).contiguous().data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(),
+             dv=dv.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), dtab_part=dtp.data_ptr(), rpi=rpi32.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N,
+             ldo=h * 32, groups=groups, T=961, Tpad=1024, toeplitz16=1, H=H, W=W, ws=16, shift=shift)
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    assert rel(dq, q_.grad) <= 8e-3 and rel(dk, k_.grad) <= 8e-3 and rel(dv, v_.grad) <= 8e-3, (rel(dq, q_.grad), rel(dk, k_.grad), rel(dv, v_.grad))
+    dtab = dtp.reshape(h, groups * 4, 1024).sum(1)[:, :961].t()
+    assert rel(dtab, table.grad) <= 2e-3, rel(dtab, table.grad)
