@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
     }
     __syncthreads();
 
+#if defined(SR_AL_EXP) && SR_AL_EXP == 1  // experiment: staging only
+    if (a.n_bwin > 0) return;
+#endif
     // ---- phase A: this wave's 64 queries
     f32x4 dbacc[19];  // bias-gradient tiles by e = t - kt + 15 (t = sub-pass)
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b4[r] = trow[-kt * 31 - r];
                 s[kt] = al_mma(R0[kt * 64 + lane], qf, b4);  // S^T[key 16 kt + 4 lg + r][query lr]
-                if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             if (masked) {
                 asm volatile("" ::: "memory");  // a real branch
@@ -187,12 +190,18 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
             __builtin_amdgcn_sched_barrier(0);
             // dS^T = P o (V dO^T - delta)
 #pragma unroll
-            for (int kt = 0; kt < 16; ++kt) {
-                const f32x4 dp = al_mma(R1[kt * 64 + lane], dof, (f32x4)(0.0f));
+            for (int k4 = 0; k4 < 16; k4 += 4) {  // four dP tiles in flight before their consumers (an MFMA result read right behind its issue stalls the wave)
+                f32x4 dp[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * (dp[r] - dl);
-                dbacc[t - kt + 15] += s[kt];
-                if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 4; ++j) dp[j] = al_mma(R1[(k4 + j) * 64 + lane], dof, (f32x4)(0.0f));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kt = k4 + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * (dp[j][r] - dl);
+                    dbacc[t - kt + 15] += s[kt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // dQ[q][d] = sum_key dS[q][key] K[key][d]: the dS accumulators are the operand (keys 32 ks + 4 lg + r | + 16)
             f32x4 dq[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
@@ -209,6 +218,14 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if defined(SR_AL_EXP) && SR_AL_EXP == 2  // experiment: phase A without the fold
+    if (a.n_bwin > 0) {
+        f32x4 t_ = dbacc[0];
+        for (int e = 1; e < 19; ++e) t_ += dbacc[e];
+        if (t_[0] == 1.2345f) DTAB[lane] = t_[1] + t_[2] + t_[3];
+        return;
+    }
+#endif
     // fold the bias-gradient tiles along their diagonals into the table partial: tile e holds (query tile 4 w + t, key tile kt) pairs with t - kt + 15 = e,
     // i.e. table rows (4 w + e) * 31 ..; rotate every key column so that lane = (xq - xk) mod 16, split wrapped / unwrapped, reduce over the lane groups
 #pragma unroll
@@ -233,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
         }
     }
 
+#if defined(SR_AL_EXP) && SR_AL_EXP == 3  // experiment: phase A with the fold
+    if (a.n_bwin > 0) return;
+#endif
     // ---- phase B: this wave's 64 keys.  Its K / V fragments and the next operands' global loads are issued before the barrier
     __builtin_amdgcn_sched_barrier(0);  // (after the fold: the 19 gradient tiles are dead)
     Frag<bf16> kf[4], vf[4];
@@ -264,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
 #pragma unroll
         for (int u = 0; u < 4; ++u) dk[u][0] = dk[u][1] = dv[u][0] = dv[u][1] = (f32x4)(0.0f);
         const bool kcol = last_col && lr >= edge;  // this lane's key column
+        f32x4 cmB;  // column term of the mask: this lane's key column lr against its 4 query columns 4 lg + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmB[r] = (last_col && 4 * lg + r >= edge) != kcol ? -100.0f : 0.0f;
         // logits S[query 16 qt + 4 lg + r][key lr]: table entries x = (4 lg + r) - lr + 15, ascending with r
         const float* trow = TAB + 15 * 31 + 15 + 4 * lg - lr;
 #pragma unroll 2
@@ -284,10 +307,8 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_lds_kernel(SrTrAttnBwd 
                     f32x4 s = al_mma(qf, kf[u], b4);
                     const f32x4 dp = al_mma(dof, vf[u], (f32x4)(0.0f));
                     if (masked) {
-                        const bool rdiff = qrow != (last_row && kt >= edge);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (rdiff || ((last_col && 4 * lg + r >= edge) != kcol)) s[r] += -100.0f;
+                        asm volatile("" ::: "memory");  // a real branch (most windows carry no mask)
+                        s += qrow != (last_row && kt >= edge) ? (f32x4)(-100.0f) : cmB;
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
