@@ -211,6 +211,8 @@ extern "C" int sr_window_attention(const SrWindowAttn* p, void* stream) {
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_window_attention: n_bwin");
     SR_REQUIRE(!a.qkv_frag || (a.dtype == SR_BF16 && a.ntok == 256 && a.hd_p == 32 && a.bias_frag && a.ws % 4 == 0), "sr_window_attention: qkv_frag needs bf16, 16 x 16 windows, hd_p 32 and bias_frag");
     SR_REQUIRE(!a.bias_tiles || (a.dtype == SR_BF16 && a.ntok == 256 && a.ws == 16 && a.hd_p == 32 && a.bias_frag), "sr_window_attention: bias_tiles needs bf16, 16 x 16 windows, hd_p 32 (and bias_frag for the fallback contract)");
+    SR_REQUIRE(!a.bias_tiles || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
+               "sr_window_attention: the LDS form stages 16-byte pieces (q, k, vt, bias_tiles must be 16-byte aligned)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return a.dtype == SR_BF16 ? dispatch_attn<bf16>(a, st) : dispatch_attn<float>(a, st);
 }

@@ -44,6 +44,8 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
     SR_REQUIRE(sr_hab_mid_supported(a.ntok, a.hd_p, a.ws, a.dtype, c.Cin_p, c.Cmid_p, c.Cout_p, c.dtype), "sr_hab_mid: unsupported geometry (16 x 16 windows, head_dim <= 32, bf16)");
     SR_REQUIRE(a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.heads > 0, "sr_hab_mid: bad attention geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_hab_mid: n_bwin");
+    SR_REQUIRE(!a.bias_tiles || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
+               "sr_hab_mid: the LDS form of the attention stages 16-byte pieces (q, k, vt, bias_tiles must be 16-byte aligned)");
     const long n_cab = (long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B;
     const bool lds_form = a.bias_tiles != nullptr;
     const long items = (long)a.n_bwin * a.heads * 8;  // flash form: (window, head, block of 32 queries), four per workgroup

@@ -31,6 +31,7 @@ from . import ops
 Tensor = torch.Tensor
 CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
+ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
 HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
 WG_KS = int(os.environ.get("SR_WG_KS", "8"))  # token slices of the weight-gradient GEMMs (A/B knob)
@@ -428,7 +429,10 @@ class BlockPlan:
     def prepare(self, B: int, H: int, W: int, dev, groups: int) -> None:
         """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images; static activations."""
         fp, fm = self.fp, self.fm
-        self.groups = groups
+        nbw_ = B * H * W // 256
+        # HAB with the LDS form of the attention backward (csrc/sr_tr_attn_lds.hip): one bias-table partial per (head, window), i.e. groups * 4 == windows;
+        # OCAB (and HABs without it): `groups` window groups whose pass-Q workgroups walk their windows with the gradient tiles in registers
+        self.groups = nbw_ // 4 if (not self.oca and nbw_ % 4 == 0 and ATTN_BWD_LDS) else groups
         nwg = B * H * W // 64
         self.f_ln1, self.f_ln2 = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
         for f, norm in ((self.f_ln1, self.blk.norm1), (self.f_ln2, self.blk.norm2)):
@@ -535,7 +539,7 @@ class BlockPlan:
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
               dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // 256,
-              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=sc.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift)
+              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift)
         jobs = []
         ks = WG_KS
         if self.oca:
@@ -844,12 +848,9 @@ class HatPlan:
         dev = self.fp.P.device
         fp, fm, m = self.fp, self.fm, self.model
         nbw = B * H * W // 256
-        if nbw % 4 == 0 and os.environ.get("SR_TR_ATTN_LDS", "1") != "0":
-            groups = nbw // 4  # one bias-table partial per (head, window): the LDS form of the attention backward (csrc/sr_tr_attn_lds.hip)
-        else:
-            groups = max(1, min(nbw, 16))
-            while nbw % groups:
-                groups -= 1
+        groups = max(1, min(nbw, 16))
+        while nbw % groups:
+            groups -= 1
         self.scratch = Scratch(B, H, W, dev, groups)
         for s in self.stages:
             s.prepare(B, H, W, dev, self.scratch)
