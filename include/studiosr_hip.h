@@ -360,6 +360,11 @@ typedef struct SrOcaAttn {
     const float* bias_frag; /* optional: the bias in accumulator-fragment order [heads][qt][nk_frag/16][lane][4] with the key dimension
                              * padded to nk_frag (multiple of 64) by -1e30 columns; selects the flash-form kernel */
     int nk_frag;
+    const float* bias_rel;  /* optional (ABI v8; bf16, ws 16, pad == border == 4): the bias as its relative-position TABLE, [heads][1521] with
+                             * bias[h][q][k] = bias_rel[h][(ky - qy + 15) * 39 + (kx - qx + 15)] (q = 16 qy + qx, k = 24 ky + kx) -- the reference's table rotated by 880
+                             * entries, which is where its python-style negative indices land (hat.py:494-517, 276-279); packing.oca_bias_rel builds it from the
+                             * gathered bias and verifies every entry.  Selects the LDS form: one (window, head) per workgroup with K, V^T and this table staged in
+                             * LDS once (csrc/sr_oca_lds.hip) */
 } SrOcaAttn;
 int sr_oca_attention(const SrOcaAttn* a, void* stream);
 
@@ -549,6 +554,8 @@ typedef struct SrTrAttnFwd {
      * vT [bwin][head][32][Nk] bf16, bias [heads][Nq][Nk] fp32.  Nq 256, Nk 576. */
     const void* q; const void* k; const void* vT; const float* bias; void* out;
     int n_bwin, heads, hd_p, Nq, Nk, ldo;
+    const float* bias_rel;  /* optional (ABI v8): as SrOcaAttn.bias_rel; selects the LDS form (csrc/sr_oca_lds.hip) */
+    float* lse;             /* optional (ABI v8, LDS form only): log-sum-exp of every query row [bwin][head][Nq] */
 } SrTrAttnFwd;
 int sr_tr_attn_fwd(const SrTrAttnFwd* a, void* stream);
 

@@ -133,7 +133,7 @@ class SrOcaAttn(C.Structure):
     _fields_ = [
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("pad", _i), ("border", _i), ("nk_pad", _i), ("dtype", _i),
-        ("bias_frag", _vp), ("nk_frag", _i),
+        ("bias_frag", _vp), ("nk_frag", _i), ("bias_rel", _vp),
     ]
 
 
@@ -175,7 +175,8 @@ class SrTrAttnBwd(C.Structure):
 
 
 class SrTrAttnFwd(C.Structure):
-    _fields_ = [("q", _vp), ("k", _vp), ("vT", _vp), ("bias", _vp), ("out", _vp), ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i)]
+    _fields_ = [("q", _vp), ("k", _vp), ("vT", _vp), ("bias", _vp), ("out", _vp), ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i),
+                ("bias_rel", _vp), ("lse", _vp)]
 
 
 class SrTrOcaFold(C.Structure):

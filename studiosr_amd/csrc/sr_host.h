@@ -68,6 +68,13 @@ struct SrSwinAttn;
 bool sr_swin_block_v2_enabled();
 int sr_swin_block_v2(const SrSwinAttn& a, hipStream_t st);
 
+// LDS form of the overlapping cross attention (sr_oca_lds.hip): inference (zero-bordered k / v^T) and the training forward (unfolded k / v^T)
+struct SrTrAttnFwd;
+bool sr_oca_attention_lds_supported(const SrOcaAttn& o);
+int sr_oca_attention_lds(const SrOcaAttn& o, hipStream_t st);
+bool sr_tr_attn_fwd_lds_supported(const SrTrAttnFwd& f);
+int sr_tr_attn_fwd_lds(const SrTrAttnFwd& f, hipStream_t st);
+
 // LDS form of the window-attention backward for 16 x 16 windows (sr_tr_attn_lds.hip): one launch instead of sr_tr_attn.hip's two passes
 struct SrTrAttnBwd;
 bool sr_tr_attn_bwd_lds_usable(const SrTrAttnBwd& a);

@@ -456,6 +456,7 @@ extern "C" int sr_tr_attn_fwd(const SrTrAttnFwd* p, void* stream) {
     SR_REQUIRE(p && p->q && p->k && p->vT && p->bias && p->out, "sr_tr_attn_fwd: null pointer");
     const SrTrAttnFwd& a = *p;
     SR_REQUIRE(a.hd_p == 32 && a.Nq == 256 && a.Nk == 576 && a.heads > 0 && a.n_bwin > 0 && a.ldo >= a.heads * 32 && a.ldo % 4 == 0, "sr_tr_attn_fwd: unsupported geometry (Nq 256, Nk 576)");
+    if (sr_tr_attn_fwd_lds_supported(a)) return sr_tr_attn_fwd_lds(a, reinterpret_cast<hipStream_t>(stream));
     const int items = a.n_bwin * a.heads * (a.Nq / 16);
     hipLaunchKernelGGL(sr_tr_attn_fwd_kernel<36>, dim3((items + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_tr_attn_fwd");

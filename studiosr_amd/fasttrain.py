@@ -366,6 +366,22 @@ def pack_bias(fp: FlatParams, table: Tensor, rpi: np.ndarray, nq: int, nk: int) 
     return b, bt, bf, b31
 
 
+def pack_bias_rel(b: IM, rpi: np.ndarray, T: int) -> Optional[IM]:
+    """The OCAB's gathered bias [heads][256][576] as its rotated relative-position table [heads][1521] (SrTrAttnFwd.bias_rel, packing.oca_bias_rel),
+    or None when rpi is not a function of the (row, column) differences."""
+    from . import packing
+
+    J = packing.oca_rel_index().numpy()  # [256, 576] -> position in the table
+    qrep, krep = np.zeros(1521, dtype=np.int64), np.zeros(1521, dtype=np.int64)
+    qq, kk = np.meshgrid(np.arange(256), np.arange(576), indexing="ij")
+    qrep[J.reshape(-1)], krep[J.reshape(-1)] = qq.reshape(-1), kk.reshape(-1)
+    r = np.asarray(rpi, dtype=np.int64).reshape(256, 576)
+    r = np.where(r < 0, r + T, r)
+    if not np.array_equal(r[qrep, krep][J], r):
+        return None
+    return b.map(lambda a: np.ascontiguousarray(a[:, qrep, krep]).reshape(-1))
+
+
 # --------------------------------------------------------------------------- one block (HAB or OCAB)
 class BlockPlan:
     """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195) or OCAB (hat.py:107-118,239-293; oca = True: no CAB, no shift,
@@ -390,6 +406,8 @@ class BlockPlan:
         self.o_bias, self.o_biasT = fa.add(b), fa.add(bt)
         self.o_biasF = None if oca else fa.add(bf)
         self.o_bias31 = None if (oca or b31 is None or not ATTN_LDS) else fa.add(b31)
+        rel = pack_bias_rel(b, rpi, self.table.shape[0]) if oca else None
+        self.o_bias_rel = None if rel is None else fa.add(rel)
         self.cab = None
         if not oca:
             cab = blk.conv_block.cab
@@ -495,7 +513,8 @@ class BlockPlan:
             a.B, a.nwy, a.nwx, a.heads, a.wse, a.pad = B, H // 16, W // 16, HEADS, 24, 4
             L.check(lib.sr_tr_oca_fold(C.byref(a), 1, _st()), "sr_tr_oca_fold")
             _call(lib.sr_tr_attn_fwd, L.SrTrAttnFwd, "sr_tr_attn_fwd", q=self.q.data_ptr(), k=self.k.data_ptr(), vT=sc.vwinT.data_ptr(), bias=fa[self.o_bias:].data_ptr(),
-                  out=self.o.data_ptr(), n_bwin=nbw, heads=HEADS, hd_p=HDP, Nq=256, Nk=576, ldo=CP)
+                  out=self.o.data_ptr(), n_bwin=nbw, heads=HEADS, hd_p=HDP, Nq=256, Nk=576, ldo=CP,
+                  bias_rel=None if self.o_bias_rel is None else fa[self.o_bias_rel:].data_ptr())
         else:
             _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
                   wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),

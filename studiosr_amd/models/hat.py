@@ -250,6 +250,10 @@ class HAT(Model):
             obf = torch.full((ob.shape[0], ob.shape[1], nk_frag), -1.0e30, dtype=torch.float32, device=ob.device)
             obf[:, :, :nk] = ob
             o["oca_bias_frag"], o["oca_nk_frag"] = packing.bias_fragments(obf), nk_frag
+            if ws == 16 and wse == 24 and dt == torch.bfloat16:  # the bias as its relative-position table: selects the LDS form of the attention (ABI v8)
+                rel = packing.oca_bias_rel(ob)
+                if rel is not None:
+                    o["oca_bias_rel"] = rel
             o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
             o.update(pack_tail_stream(oc.proj, oc.mlp, oc.norm2, geo, dt))
             o.update(pack_qkv_stream(oc, oc.norm1, geo, dt))
@@ -409,7 +413,7 @@ class HAT(Model):
         ops.oca_attention(
             q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=op["oca_bias"].data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=geo.heads,
             hd_p=geo.hd_p, ws=geo.ws, pad=P["pad"], border=e, nk_pad=P["nk_pad"], dtype=sdt, bias_frag=op["oca_bias_frag"].data_ptr(),
-            nk_frag=op["oca_nk_frag"],
+            nk_frag=op["oca_nk_frag"], bias_rel=op["oca_bias_rel"].data_ptr() if ("oca_bias_rel" in op and sdt == L.SR_BF16) else None,
         )
         if swin_tail_usable(op, geo, Cp, cdt):
             run_swin_tail(op, geo, o, t, t, 0)

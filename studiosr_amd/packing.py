@@ -159,6 +159,29 @@ def bias_distinct_tiles(bias: Tensor) -> Optional[Tensor]:
     return first.reshape(heads, 31, 16, 4, 4).permute(0, 1, 3, 2, 4).contiguous().reshape(-1)  # [h, d, g, i, r] -> lane = g * 16 + i
 
 
+def oca_rel_index(ws: int = 16, wse: int = 24) -> Tensor:
+    """[ws*ws, wse*wse] int64: position of bias[q][k] in the rotated relative-position table of SrOcaAttn.bias_rel,
+    (ky - qy + ws - 1) * (ws + wse - 1) + (kx - qx + ws - 1)."""
+    n = ws + wse - 1
+    qy, qx = torch.div(torch.arange(ws * ws), ws, rounding_mode="floor"), torch.arange(ws * ws) % ws
+    ky, kx = torch.div(torch.arange(wse * wse), wse, rounding_mode="floor"), torch.arange(wse * wse) % wse
+    return (ky[None, :] - qy[:, None] + ws - 1) * n + (kx[None, :] - qx[:, None] + ws - 1)
+
+
+def oca_bias_rel(bias: Tensor) -> Optional[Tensor]:
+    """[heads, 256, >= 576] fp32 gathered bias of HAT's overlapping cross attention (16 x 16 queries, 24 x 24 keys; hat.py:494-517, 276-279) ->
+    its relative-position table [heads][1521] in the order of SrOcaAttn.bias_rel (ABI v8), or None when the bias is not a function of the (row, column)
+    differences.  Every entry of the gathered bias is checked against the table."""
+    if bias.shape[1] != 256 or bias.shape[2] < 576:
+        return None
+    J = oca_rel_index().to(bias.device)                      # [256, 576]
+    rel = torch.zeros(bias.shape[0], 39 * 39, dtype=torch.float32, device=bias.device)
+    rel[:, J.reshape(-1)] = bias[:, :, :576].reshape(bias.shape[0], -1)  # any representative (duplicates carry the same value when the structure holds)
+    if not torch.equal(rel[:, J], bias[:, :, :576]):
+        return None
+    return rel.contiguous()
+
+
 # --------------------------------------------------------------------------- Swin block weight stream (C ABI v5, sr_swin_block)
 LOG2E = 1.4426950408889634
 SWIN_STREAM_SLOTS = 48

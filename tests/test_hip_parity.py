@@ -904,6 +904,55 @@ def test_window_attention_lds_form_equals_the_flash_form(frag, shift, y_mode):
             assert float((new - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+def test_overlapping_cross_attention_lds_form_against_the_flash_form_and_torch():
+    """sr_oca_attention with SrOcaAttn.bias_rel (ABI v8: K / V^T of the 24 x 24 neighbourhood and the head's relative-position table staged in LDS once per
+    (window, head), csrc/sr_oca_lds.hip) against the flash form on the same zero-bordered operands and against torch on the unfolded keys (hat.py:239-283); the bias is
+    table[rpi_oca] with the reference's wrapping negative indices; a bias without that structure is refused by the packer."""
+    from studiosr_amd.models.hat import rpi_oca
+
+    torch.manual_seed(47)
+    B, H, W, heads, hd_p, ws, pad, e = 2, 32, 48, 6, 32, 16, 4, 4
+    wse, ntok, nk = ws + 2 * pad, ws * ws, (ws + 2 * pad) ** 2
+    nb = B * (H // ws) * (W // ws)
+    q = (torch.randn(nb, heads, ntok, hd_p, device=DEV) * 0.4).to(torch.bfloat16)
+    kimg = torch.zeros(B, H + 2 * e, W + 2 * e, heads, hd_p, device=DEV)
+    kimg[:, e:-e, e:-e] = torch.randn(B, H, W, heads, hd_p, device=DEV)
+    vpl = torch.zeros(B, heads, hd_p, H + 2 * e, W + 2 * e, device=DEV)
+    vpl[..., e:-e, e:-e] = torch.randn(B, heads, hd_p, H, W, device=DEV)
+    kimg, vpl = kimg.to(torch.bfloat16), vpl.to(torch.bfloat16)
+    table = torch.randn((ws + wse - 1) ** 2, heads, device=DEV)
+    bias = packing.gather_bias(table, rpi_oca(ws, 0.5), ntok, nk)  # [heads, 256, 576]
+    rel = packing.oca_bias_rel(bias)
+    assert rel is not None and rel.shape == (heads, 1521)
+    assert packing.oca_bias_rel(torch.randn(heads, ntok, nk, device=DEV)) is None
+    bias_frag = packing.bias_fragments(bias)  # 576 keys: a multiple of 64, no padding columns
+
+    def run(lds):
+        o = torch.full((nb * ntok, heads * hd_p), float("nan"), device=DEV).to(torch.bfloat16)
+        ops.oca_attention(q=q.data_ptr(), k=kimg.data_ptr(), vt=vpl.data_ptr(), bias=bias.data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=heads, hd_p=hd_p, ws=ws,
+                          pad=pad, border=e, nk_pad=nk, dtype=L.SR_BF16, bias_frag=bias_frag.data_ptr(), nk_frag=nk, bias_rel=rel.data_ptr() if lds else None)
+        torch.cuda.synchronize()
+        return o.float()
+
+    new, old = run(True), run(False)
+    assert not torch.isnan(new).any()
+    scale = float(old.abs().max())
+    assert float((new - old).abs().max()) <= 8e-3 * scale and float((new - old).pow(2).mean().sqrt()) <= 5e-4 * scale
+    # torch: unfold the neighbourhoods (nn.Unfold(kernel 24, stride 16, padding 4) of the un-bordered image = windows of the bordered one)
+    kf = kimg.float()[:, e - pad : e - pad + H + 2 * pad, e - pad : e - pad + W + 2 * pad]  # [B, H + 8, W + 8, heads, 32]
+    vf = vpl.float()[..., e - pad : e - pad + H + 2 * pad, e - pad : e - pad + W + 2 * pad]
+    outs = []
+    for b in range(B):
+        for wy in range(H // ws):
+            for wx in range(W // ws):
+                kw = kf[b, wy * ws : wy * ws + wse, wx * ws : wx * ws + wse].reshape(nk, heads, hd_p).permute(1, 0, 2)      # [heads, 576, 32]
+                vw = vf[b, :, :, wy * ws : wy * ws + wse, wx * ws : wx * ws + wse].reshape(heads, hd_p, nk).transpose(1, 2)  # [heads, 576, 32]
+                qq = q[(b * (H // ws) + wy) * (W // ws) + wx].float()
+                outs.append((torch.softmax(qq @ kw.transpose(1, 2) + bias, -1) @ vw).permute(1, 0, 2).reshape(ntok, heads * hd_p))
+    ref = torch.cat(outs)
+    assert float((new - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(monkeypatch):
     """A default-width HAT forward (shifted and unshifted HABs, OCAB) with sr_hab_mid (default) and with the two-stream attention || CAB launches."""
     torch.manual_seed(5)

@@ -325,6 +325,18 @@ def test_index_form_packers_equal_the_value_packers():
     tiles = packing.bias_distinct_tiles(packing.gather_bias(table, rpi, 256, 256))  # the 31 distinct tiles of the LDS-form window attention (ABI v8)
     assert tiles is not None and b31 is not None and torch.equal(emulate(fp3, b31, torch.float32), tiles)
     assert packing.bias_distinct_tiles(torch.randn(F.HEADS, 256, 256)) is None
+    from studiosr_amd.models.hat import rpi_oca  # the OCAB's bias as its rotated relative-position table (SrOcaAttn.bias_rel / SrTrAttnFwd.bias_rel, ABI v8)
+
+    table_o = torch.randn(39 * 39, 6)
+    fp5 = FakeFP([table_o])
+    ro = rpi_oca(16, 0.5)
+    bo = packing.gather_bias(table_o, ro, 256, 576)
+    rel = packing.oca_bias_rel(bo)
+    assert rel is not None and torch.equal(rel[:, packing.oca_rel_index()], bo)
+    bo_im = F.pack_bias(fp5, table_o, ro.numpy(), 256, 576)[0]
+    rel_im = F.pack_bias_rel(bo_im, ro.numpy(), 39 * 39)
+    assert rel_im is not None and torch.equal(emulate(fp5, rel_im, torch.float32).reshape(6, 1521), rel)
+    assert packing.oca_bias_rel(torch.randn(6, 256, 576)) is None
     assert torch.equal(emulate(fp3, b_, torch.float32).reshape(6, 256, 256), ref)
     assert torch.equal(emulate(fp3, bt, torch.float32).reshape(6, 256, 256), ref.transpose(1, 2))
     assert torch.equal(emulate(fp3, bfr, torch.float32), packing.bias_fragments(ref))
