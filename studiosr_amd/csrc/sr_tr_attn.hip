@@ -39,8 +39,16 @@ struct Geo {
 };
 
 // ---- pass Q.  KT = key tiles; Nq = 16 * QT_ALL query rows per (window, head)
-template <int KT, int VAR>
+// LDSK (round 4, the 576-key neighbourhoods of the overlapping cross attention): the four waves of a workgroup work on the same (head, window) at the same
+// time, so K and V (as operand fragments) and K^T (in the accumulator-as-operand key order) of the window are staged in LDS once per window walk step
+// (3 x KT KiB, two barriers per window) instead of being fetched from L2 by every wave -- at one wave per SIMD (288 registers of logits and gradient tiles)
+// those 108 fragment loads per window were exposed L2 round trips: 436 -> see profiles/r04_train_trace_HAT.txt.
+template <int KT, int VAR, bool LDSK = false>
 __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(SrTrAttnBwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];  // LDSK: K | V | K^T fragments
+    const Frag<bf16>* KL = reinterpret_cast<const Frag<bf16>*>(smem_q);
+    const Frag<bf16>* VL = KL + KT * 64;
+    const Frag<bf16>* KTL = VL + KT * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int NK = KT * 16;
@@ -69,6 +77,39 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         const bf16* k = reinterpret_cast<const bf16*>(a.k) + bh * NK * 32;
         const bf16* kT = reinterpret_cast<const bf16*>(a.kT) + bh * NK * 32;
         const bf16* v = reinterpret_cast<const bf16*>(a.v) + bh * NK * 32;
+        if constexpr (LDSK) {
+            constexpr int PIECES = KT * 64, PER = PIECES / 256;  // 16-byte pieces per array, per thread
+            static_assert(PIECES % 256 == 0, "whole rounds of 256 pieces");
+            __syncthreads();  // the previous window's fragments have been read by every wave
+            Frag<bf16> r[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) r[i] = *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(i * 256 + threadIdx.x) * 8);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = i * 256 + threadIdx.x, key = c >> 2, g = c & 3;
+                *reinterpret_cast<Frag<bf16>*>(smem_q + ((key >> 4) * 64 + g * 16 + (key & 15)) * 16) = r[i];
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) r[i] = *reinterpret_cast<const Frag<bf16>*>(v + (size_t)(i * 256 + threadIdx.x) * 8);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = i * 256 + threadIdx.x, key = c >> 2, g = c & 3;
+                *reinterpret_cast<Frag<bf16>*>(smem_q + (KT * 64 + (key >> 4) * 64 + g * 16 + (key & 15)) * 16) = r[i];
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) r[i] = *reinterpret_cast<const Frag<bf16>*>(kT + (size_t)(i * 256 + threadIdx.x) * 8);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = i * 256 + threadIdx.x;
+                const int d = c / (NK / 8), k0 = (c - d * (NK / 8)) * 8;  // keys k0 .. k0 + 7 of feature row d: two groups of 4
+                const int st = k0 >> 5, e_hi = (k0 >> 4) & 1, g0 = (k0 >> 2) & 3;
+                char* cell = smem_q + (2 * KT * 64 + ((d >> 4) * (KT / 2) + st) * 64 + g0 * 16 + (d & 15)) * 16 + e_hi * 8;
+                const bf16x8 v8 = r[i].v;
+                *reinterpret_cast<bf16x4*>(cell) = __builtin_shufflevector(v8, v8, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(cell + 16 * 16) = __builtin_shufflevector(v8, v8, 4, 5, 6, 7);
+            }
+            __syncthreads();
+        }
         const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(q + (size_t)qi * 32 + lg * 8);
         const size_t orow = ((size_t)bwin * a.Nq + qi) * a.ldo + head * 32 + lg * 8;
         const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
@@ -77,7 +118,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         f32x4 s[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+            const Frag<bf16> kf = LDSK ? KL[kt * 64 + lane] : *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
             s[kt] = mma_z(kf, qf);  // S^T[key 16 kt + 4 lg + r][query lr]
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps hipcc from hoisting every operand load of the pass at once (spills)
         }
@@ -131,7 +172,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         // dS^T = P o (V dO^T - delta)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const Frag<bf16> vf = *reinterpret_cast<const Frag<bf16>*>(v + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+            const Frag<bf16> vf = LDSK ? VL[kt * 64 + lane] : *reinterpret_cast<const Frag<bf16>*>(v + (size_t)(kt * 16 + lr) * 32 + lg * 8);
             const f32x4 dp = mma_z(vf, dof);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * (dp[r] - dl);
@@ -146,7 +187,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const bf16* kp = kT + (size_t)(dt * 16 + lr) * NK + ks * 32 + lg * 4;
-                mma(load_2x4(kp, kp + 16), pf, dq[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
+                mma(LDSK ? KTL[(dt * (KT / 2) + ks) * 64 + lane] : load_2x4(kp, kp + 16), pf, dq[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
             }
             if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -504,8 +545,17 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 2>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
         else
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
-    } else
-        hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<36, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    } else {
+        static const bool ldsk = !(getenv("SR_TR_OCA_LDS") && atoi(getenv("SR_TR_OCA_LDS")) == 0);  // A/B knob
+        if (ldsk) {
+            constexpr int lds = 3 * 36 * 1024;
+            static SrDeviceOnce once;
+            const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_tr_attn_bwd_q_kernel<36, 0, true>, lds); });
+            SR_REQUIRE(e == hipSuccess, "sr_tr_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<36, 0, true>), dim3((items_q + 3) / 4), dim3(256), lds, st, b);
+        } else
+            hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<36, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
+    }
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (q)");
 #ifndef SR_KV_KPW
 #define SR_KV_KPW 2
