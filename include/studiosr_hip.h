@@ -545,6 +545,9 @@ typedef struct SrTrAttnBwd {
     int n_bwin, heads, hd_p, Nq, Nk, ldo, groups, T, Tpad;
     int toeplitz16;        /* 1: rpi is the 16 x 16 self-attention index (yq - yk + 15) * 31 + (xq - xk + 15) (hat.py:480-492): the fold runs on lane rotations */
     int H, W, ws, shift;   /* mask geometry (shift == 0: no mask) */
+    int oca_rel;           /* 1 (ABI v8; Nk = 576): bias[q][k] is a function of (ky - qy, kx - qx) only and rpi the overlapping-cross-attention index
+                            * (ky - qy - 7) * 39 + (kx - qx - 7) with wrapping negatives (hat.py:494-517): pass Q then keeps the head's table in LDS beside the window's
+                            * K / V / K^T fragments and folds the gradient through the index arithmetic instead of reading bias rows and rpi from memory */
 } SrTrAttnBwd;
 int sr_tr_attn_bwd(const SrTrAttnBwd* a, void* stream);
 

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
     const Frag<bf16>* KL = reinterpret_cast<const Frag<bf16>*>(smem_q);
     const Frag<bf16>* VL = KL + KT * 64;
     const Frag<bf16>* KTL = VL + KT * 64;
+    float* REL = reinterpret_cast<float*>(smem_q + 3 * KT * 1024);  // LDSK: the head's relative-position table [39 * 39] (SrTrAttnBwd.oca_rel)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int NK = KT * 16;
@@ -69,6 +70,18 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
     for (int kt = 0; kt < KT; ++kt) dbacc[kt] = (f32x4)(0.0f);
 
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+    // LDSK: rel index of this lane's logits of tile kt = (ky - qt + 15) * 39 + (kx0 - lr + 15) + r with (ky, kx0) the key row / column of key 16 kt + 4 lg
+    // (a group of 4 keys never crosses a key row: 24 = 6 x 4; 16 kt mod 24 cycles through 0, 16, 8: only tiles with kt % 3 == 1 straddle two rows)
+    const int off_k[3] = {4 * lg, lg < 2 ? 16 + 4 * lg : 39 + 4 * lg - 8, 8 + 4 * lg};
+    const int rel0 = (15 - qt) * 39 + 15 - lr;
+    if constexpr (LDSK) {
+        const float* bh_ = a.bias + (size_t)head * a.Nq * NK;
+        for (int j = threadIdx.x; j < 39 * 39; j += 256) {  // any (q, k) pair with the row / column differences of entry j
+            const int dyp = j / 39, dxp = j - dyp * 39;
+            const int qy = dyp >= 15 ? 0 : 15 - dyp, ky = dyp >= 15 ? dyp - 15 : 0, qx = dxp >= 15 ? 0 : 15 - dxp, kx = dxp >= 15 ? dxp - 15 : 0;
+            REL[j] = bh_[(size_t)(qy * 16 + qx) * NK + ky * 24 + kx];
+        }
+    }
     for (int wi = 0; wi < wpg; ++wi) {
         const int bwin = grp * wpg + wi;
         if (bwin >= a.n_bwin) break;
@@ -118,7 +131,16 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         f32x4 s[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const Frag<bf16> kf = LDSK ? KL[kt * 64 + lane] : *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
+            if constexpr (LDSK) {  // the four table entries of this lane are consecutive: the C operand of the MFMA
+                const float* tr = REL + rel0 + ((16 * kt) / 24) * 39 + off_k[kt % 3];
+                f32x4 b4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[r] = tr[r];
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KL[kt * 64 + lane].v, qf.v, b4, 0, 0, 0);
+                if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
+            const Frag<bf16> kf = *reinterpret_cast<const Frag<bf16>*>(k + (size_t)(kt * 16 + lr) * 32 + lg * 8);
             s[kt] = mma_z(kf, qf);  // S^T[key 16 kt + 4 lg + r][query lr]
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps hipcc from hoisting every operand load of the pass at once (spills)
         }
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
         for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != qcol;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            s[kt] += *reinterpret_cast<const f32x4*>(bias + kt * 16 + lg * 4);
+            if constexpr (!LDSK) s[kt] += *reinterpret_cast<const f32x4*>(bias + kt * 16 + lg * 4);
             if (masked) {
                 const bool rdiff = region(wy * 16 + kt, a.H, 16, a.shift) != qrow;
 #pragma unroll
@@ -230,8 +252,15 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
     } else {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const int4 t4 = *reinterpret_cast<const int4*>(rp + kt * 16 + lg * 4);
-            const int tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            int tt[4];
+            if constexpr (LDSK) {  // table row of rel entry j: j - 880, negative entries wrap (hat.py:276-279)
+                const int j0 = rel0 + ((16 * kt) / 24) * 39 + off_k[kt % 3] - 880;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tt[r] = j0 + r;
+            } else {
+                const int4 t4 = *reinterpret_cast<const int4*>(rp + kt * 16 + lg * 4);
+                tt[0] = t4.x; tt[1] = t4.y; tt[2] = t4.z; tt[3] = t4.w;
+            }
             if (VAR == 2) {  // one lane group at a time: no two lanes of an instruction on one address
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -547,8 +576,8 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
     } else {
         static const bool ldsk = !(getenv("SR_TR_OCA_LDS") && atoi(getenv("SR_TR_OCA_LDS")) == 0);  // A/B knob
-        if (ldsk) {
-            constexpr int lds = 3 * 36 * 1024;
+        if (ldsk && a.oca_rel && a.T == 39 * 39 && a.ws == 16) {
+            constexpr int lds = 3 * 36 * 1024 + 6144;
             static SrDeviceOnce once;
             const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_tr_attn_bwd_q_kernel<36, 0, true>, lds); });
             SR_REQUIRE(e == hipSuccess, "sr_tr_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -558,7 +558,8 @@ class BlockPlan:
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
               dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // 256,
-              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift)
+              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift,
+              oca_rel=int(self.oca and self.o_bias_rel is not None))
         jobs = []
         ks = WG_KS
         if self.oca:
