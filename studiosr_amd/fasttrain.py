@@ -868,7 +868,9 @@ class HatPlan:
         dev = self.fp.P.device
         fp, fm, m = self.fp, self.fm, self.model
         nbw = B * H * W // 256
-        groups = max(1, min(nbw, 16))
+        # window groups of the OCAB's pass Q (one 4-wave workgroup per (group, head, 64 queries), one workgroup per CU): the largest divisor of the window count
+        # that keeps the launch within one residency round of the 256 CUs (HAT x4 step at groups 8 / 16 / 32 / 64: 20.07 / 20.46 / 20.61 / 21.58 ms; SR_TR_GROUPS: A/B knob)
+        groups = max(1, min(nbw, int(os.environ.get("SR_TR_GROUPS", str(max(1, 256 // (HEADS * 4)))))))
         while nbw % groups:
             groups -= 1
         self.scratch = Scratch(B, H, W, dev, groups)
