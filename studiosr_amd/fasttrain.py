@@ -34,7 +34,7 @@ C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
 HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
-WG_KS = int(os.environ.get("SR_WG_KS", "8"))  # token slices of the weight-gradient GEMMs (A/B knob)
+WG_KS = int(os.environ.get("SR_WG_KS", "16"))  # token slices of the weight-gradient GEMMs (A/B knob)
 
 
 def _st():
