@@ -29,6 +29,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 2 : 1) void sr_swin_qk
     constexpr bool X3 = sizeof(Frag<T>) == 32;
     using TO = typename std::conditional<X3, float, bf16>::type;  // element type of q / k / v^T
     auto put4 = [](TO* dst, const f32x4& v) {
+#ifdef SR_EXP_NOSTORE
+        if (v[0] != 1.2345f) return;
+#endif
         if constexpr (X3)
             *reinterpret_cast<f32x4*>(dst) = v;
         else
