@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, packing
-from ..runtime import compute_dtype, knob, sr_dtype
+from ..runtime import capturing_or_warming_up, compute_dtype, knob, sr_dtype
 from .common import Model, Upsampler, conv_call, pack_upsampler, run_upsampler
 from .rcan import pack_ca, run_channel_attention
 from .swinir import (
@@ -435,6 +435,40 @@ class HAT(Model):
         P = self._get_packed(cdt)
         ws_ = self._workspace(x.device)
         B, _, H, W = x.shape
+        s = self.scale
+        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
+        # Inside a HIP-graph capture a large batch runs as two half batches on two streams (as SwinIR's SR_SWIN_PARTS / RCAN's quarter batches): every launch
+        # of this model is one or two residency rounds of latency-chain workgroups, and two out-of-phase chains fill each other's rounds (HAT x4 b16 7.61 ->
+        # 7.19 ms as two batches of 8 in flight; no gain at b4: 2.62 vs 2.56).  bf16 path only (one queue per half: the other precisions fork a side stream per block).
+        parts = int(knob("SR_HAT_PARTS", "2"))
+        if parts > 1 and cdt == torch.bfloat16 and B >= 8 * parts // 2 and B % parts == 0 and x.is_cuda and capturing_or_warming_up():
+            from ..runtime import WorkspaceView
+
+            main = torch.cuda.current_stream(x.device)
+            h = B // parts
+            sides = [self._part_stream(x.device, i) for i in range(parts - 1)]
+            for i, side in enumerate(sides):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._forward_into(P, x[(i + 1) * h:(i + 2) * h], out[(i + 1) * h:(i + 2) * h], WorkspaceView(ws_, f"p{i + 1}."), cdt)
+            self._forward_into(P, x[:h], out[:h], WorkspaceView(ws_, "p0."), cdt)
+            for side in sides:
+                main.wait_stream(side)
+        else:
+            self._forward_into(P, x, out, ws_, cdt)
+        return out
+
+    def _part_stream(self, device, i: int) -> "torch.cuda.Stream":
+        sts = getattr(self, "_part_streams", None)
+        if not isinstance(sts, dict) or sts.get("device") != torch.device(device):
+            sts = {"device": torch.device(device)}
+            object.__setattr__(self, "_part_streams", sts)
+        if i not in sts:
+            sts[i] = torch.cuda.Stream(device=device)
+        return sts[i]
+
+    def _forward_into(self, P: Dict, x: Tensor, out: Tensor, ws_, cdt) -> None:
+        B, _, H, W = x.shape
         w = self.window_size
         Hp, Wp = H + (w - H % w) % w, W + (w - W % w) % w  # check_image_size: reflect pad (hat.py:544)
         if Hp - H >= H or Wp - W >= W:
@@ -469,9 +503,7 @@ class HAT(Model):
         conv_call(body, *P["before_up"], feat, cdt, act=L.ACT_LRELU)
         up = run_upsampler(P["up"], feat, ws_, cdt, "hat")
         s = self.scale
-        out = torch.empty(B, self.n_colors, H * s, W * s, dtype=f32, device=x.device)
         conv_call(up, *P["last"], out, cdt, out_mode=L.OUT_FINAL_NCHW, fin=(*P["fin"], self.n_colors, H * s, W * s), cout_p=16)
-        return out
 
     # ------------------------------------------------------------------ reference API
     def get_model_config(self) -> Dict:

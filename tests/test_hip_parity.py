@@ -953,6 +953,22 @@ def test_overlapping_cross_attention_lds_form_against_the_flash_form_and_torch()
     assert float((new - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+def test_hat_graph_replay_with_half_batches_equals_the_eager_forward():
+    """Inside a HIP-graph capture a HAT batch of >= 8 runs as two half batches on two streams (models/hat.py forward, SR_HAT_PARTS): same kernels on the same
+    per-image data, so the replayed output is bit-identical to the eager one-sequence forward, image by image."""
+    from studiosr_amd.runtime import GraphedForward
+
+    torch.manual_seed(9)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6]), seed=9).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(8, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        eager = m(x).clone()
+        g = GraphedForward(lambda t: m(t), x)
+        replayed = g(x).clone()
+        torch.cuda.synchronize()
+    assert torch.equal(replayed, eager)
+
+
 def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(monkeypatch):
     """A default-width HAT forward (shifted and unshifted HABs, OCAB) with sr_hab_mid (default) and with the two-stream attention || CAB launches."""
     torch.manual_seed(5)
