@@ -175,6 +175,10 @@ typedef struct SrSwinQkv {
     int frag_order;        /* 1: q, k, vt in the fragment order of SrWindowAttn.qkv_frag (oca_pad == 0, ws 16 only) */
     int oca_pad;           /* 0: k / vt in window order (above).  > 0 (HAT OCAB, hat.py:247-264; as sr_gemm's SR_EPI_QKV_OCA): k -> zero-bordered image order
                             * [B][H+2p][W+2p][heads][hd_p], vt -> transposed zero-bordered planes [B][heads][hd_p][(H+2p)(W+2p)], p = oca_pad (multiple of 4), shift 0 */
+    void* n1;              /* optional side output (ABI v8; HAT: the input of the block's CAB convolutions, hat.py:165-170): LayerNorm1(x) * n1_gamma + n1_beta in image
+                            * order [B,H,W,ldn], bf16 (SR_BF16) or fp32 (SR_BF16X3) -- saves the stand-alone sr_layernorm launch of a group's first block */
+    const float* n1_gamma; const float* n1_beta;  /* [Cp], pads 0 */
+    int ldn;
 } SrSwinQkv;
 int sr_swin_qkv_supported(int C, int Cp, int heads, int hd_p, int ws, int compute_dtype);
 int sr_swin_qkv(const SrSwinQkv* a, void* stream);

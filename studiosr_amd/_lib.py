@@ -79,6 +79,7 @@ class SrSwinQkv(C.Structure):
         ("x", _vp), ("q", _vp), ("k", _vp), ("vt", _vp), ("wstream", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
         ("eps", _f), ("y_mode", _i), ("compute_dtype", _i), ("frag_order", _i), ("oca_pad", _i),
+        ("n1", _vp), ("n1_gamma", _vp), ("n1_beta", _vp), ("ldn", _i),
     ]
 
 

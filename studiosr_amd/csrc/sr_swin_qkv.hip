@@ -111,12 +111,33 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 2 : 1) void sr_swin_qk
         BLOCK_SYNC();  // (also: every wave has read its part of the x tile, which the image overwrites)
         const bool one_lane = (w == ONE_C / 48) && (ag == (ONE_C % 16) / 4);
         const float inv = 1.0f / (float)a.C;
+        f32x4 gm[3], bt[3];
+        if (a.n1) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                gm[n] = *reinterpret_cast<const f32x4*>(a.n1_gamma + w * 48 + ag * 4 + n * 16);
+                bt[n] = *reinterpret_cast<const f32x4*>(a.n1_beta + w * 48 + ag * 4 + n * 16);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
             const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
             const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
             const float nmr = -mean * rstd;
+            if (a.n1) {  // LayerNorm1 with its affine as a side output in image order (the CAB's input: no sr_layernorm launch for a group's first block)
+                const size_t noff = (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    f32x4 nv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean) * rstd, gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
+                    if constexpr (X3)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.n1) + noff + n * 16) = nv;
+                    else
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.n1) + noff + n * 16) = cvt4(nv);
+                }
+            }
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
                 f32x4 nv;
@@ -229,6 +250,7 @@ extern "C" int sr_swin_qkv(const SrSwinQkv* p, void* stream) {
     SR_REQUIRE(!a.frag_order || (a.ws == 16 && a.oca_pad == 0 && a.hd_p == 32 && a.compute_dtype == SR_BF16), "sr_swin_qkv: frag_order needs 16 x 16 windows, oca_pad == 0 and SR_BF16");
     SR_REQUIRE(a.oca_pad == 0 || (a.oca_pad > 0 && a.oca_pad % 4 == 0 && a.shift == 0 && a.y_mode == SR_Y_ROLL), "sr_swin_qkv: OCA layouts need shift 0 and a border that is a multiple of 4");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_qkv: more than 2^31 tokens");
+    SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0 && a.oca_pad == 0), "sr_swin_qkv: the LayerNorm side output needs n1_gamma, n1_beta, ldn (and oca_pad == 0)");
     SwinQkvDev dv;
     dv.a = a;
     const int nwx = a.W / a.ws, nwy = a.H / a.ws, parts = a.ws * a.ws / 64;

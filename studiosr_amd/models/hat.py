@@ -316,10 +316,14 @@ class HAT(Model):
         # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
         mid_fused = (unfused and cab_fused and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
                      and ops.hab_mid_supported(geo.ntok, geo.hd_p, geo.ws, L.SR_BF16, Cp, P["c3p"], Cp, L.SR_BF16))
+        qkv_n1 = None
         if mid_fused:
             side = main
             if not n1_ready:
-                ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+                if not qkv_ready and knob("SR_QKV_N1", "1") != "0":  # a group's first block: LayerNorm1 leaves sr_swin_qkv as a side output (one launch less)
+                    qkv_n1 = (n1, *bp["ln1"])
+                else:
+                    ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         cab_kw = dict(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(), b2=bp["cab2"][1].data_ptr(),
                       y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=L.SR_BF16)
 
@@ -376,7 +380,7 @@ class HAT(Model):
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
         used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready,
-                              attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None)
+                              attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None, qkv_n1=qkv_n1)
         if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
             return next_ln is not None, fuse_next_qkv
         if not used:

@@ -300,7 +300,7 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False, attn_launch=None):
+                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False, attn_launch=None, qkv_n1=None):
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
     before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
@@ -308,7 +308,8 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     with_mlp: the caller's next step is run_mlp(p, ...) on t_out; when sr_swin_tail covers the geometry the projection AND that MLP run as
     one launch and the function returns "tail" (the caller must then skip run_mlp).
     qkv_ready: q / k / v^T of this block are already in the workspace (written by the previous block's sr_swin_tail): no QKV launch.
-    attn_launch (HAT): called with the fields of ops.window_attention INSTEAD of that launch (sr_hab_mid: attention + CAB as one launch)."""
+    attn_launch (HAT): called with the fields of ops.window_attention INSTEAD of that launch (sr_hab_mid: attention + CAB as one launch).
+    qkv_n1 (HAT): (n1, gamma, beta): sr_swin_qkv also writes LayerNorm(t_in) * gamma + beta to n1 (the caller guarantees that sr_swin_qkv runs)."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -325,12 +326,13 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
     frag = qkv_frag_order(p, geo, Cp, cdt)  # (a qkv_ready producer decides with the same predicate)
+    assert qkv_n1 is None or (not qkv_ready and swin_qkv_usable(p, geo, Cp, cdt))
     if qkv_ready:
         pass
     elif swin_qkv_usable(p, geo, Cp, cdt):
         ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
                      Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=p["qkv_dtype"],
-                     frag_order=int(frag))
+                     frag_order=int(frag), **({} if qkv_n1 is None else dict(n1=qkv_n1[0].data_ptr(), n1_gamma=qkv_n1[1].data_ptr(), n1_beta=qkv_n1[2].data_ptr(), ldn=Cp)))
     else:
         ops.gemm(
             A=t_in.data_ptr(), Wp=p["qkv_w"].data_ptr(), bias=p["qkv_b"].data_ptr(), ln_gamma=None if fold_ln(cdt) else ln[0].data_ptr(),
