@@ -314,6 +314,8 @@ typedef struct SrCab {
     float* pool_partial;  /* optional [B, sr_cab_pool_tiles(H, W), Cout_p] */
     int B, H, W, Cin_p, Cmid_p, Cout_p;  /* 192, 64, 192 */
     int dtype;            /* SR_BF16 */
+    void* mid_pre;        /* optional side output (ABI v8; training): conv1(x) + b1 BEFORE the GELU, NHWC [B,H,W,Cmid_p] bf16 -- what the backward needs for GELU' and for conv2's
+                           * weight gradient, so that it does not run conv1 again (trainer.py:104 loss.backward() through hat.py:41-49) */
 } SrCab;
 int sr_cab_supported(int Cin_p, int Cmid_p, int Cout_p, int dtype);
 int sr_cab_pool_tiles(int H, int W);

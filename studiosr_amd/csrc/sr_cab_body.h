@@ -153,6 +153,12 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+                if (c.mid_pre && inside && iy >= 1 && iy <= TOH && ar >= 1 && ar <= TOW) {  // the tile's own pixels (every pixel once): the pre-activation for the backward
+                    bf16x4 pre;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[r] = (bf16)v[r];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(c.mid_pre) + ((size_t)(b * c.H + gy) * c.W + gx) * CM + (wn * 2 + n) * 16 + ag * 4) = pre;
+                }
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? gelu_fast(v[r]) : 0.0f);

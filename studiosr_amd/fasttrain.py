@@ -33,6 +33,7 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
+CAB_MIDPRE = os.environ.get("SR_TR_MIDPRE", "1") != "0"  # A/B knob: the CAB's conv1 pre-activation kept by the forward (SrCab.mid_pre) instead of a conv1 launch in the backward
 HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
 WG_KS = int(os.environ.get("SR_WG_KS", "16"))  # token slices of the weight-gradient GEMMs (A/B knob)
 
@@ -493,6 +494,7 @@ class BlockPlan:
         else:
             self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(4))
             self.n1, self.y = e(T, CP), e(T, CP)
+            self.mid_pre = e(T, 64) if CAB_MIDPRE else None  # conv1's pre-activation, kept by the forward (2 MB per block at 4 x 64 x 64) instead of being recomputed
             self.n_tiles = ops.cab_pool_tiles(H, W)
             self.pool = e(B, self.n_tiles, CP, dt=f32)
             self.gate = e(B, CP, dt=f32)
@@ -523,7 +525,8 @@ class BlockPlan:
                        heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
                        bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0, bias_tiles=None if self.o_bias31 is None else fa[self.o_bias31:].data_ptr())
             ckw = dict(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
-                       y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16)
+                       y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16,
+                       mid_pre=None if self.mid_pre is None else self.mid_pre.data_ptr())
             if HAB_MID:  # the two independent launches as one (sr_hab_mid, ABI v8)
                 ops.hab_mid(akw, ckw)
             else:
@@ -569,12 +572,15 @@ class BlockPlan:
             L.check(lib.sr_tr_oca_fold(C.byref(a), 0, _st()), "sr_tr_oca_fold")
         else:  # ---- CAB backward (hat.py:41-52)
             w1, b1, w2, b2 = self.ca
-            _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], sc.mid_pre, B, H, W, CP, 64)
+            mid_pre = self.mid_pre
+            if mid_pre is None:  # (SR_TR_MIDPRE=0: conv1 again)
+                mid_pre = sc.mid_pre
+                _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], mid_pre, B, H, W, CP, 64)
             _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
                   w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
                   parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
             _conv(sc.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
-            L.check(lib.sr_tr_gelu(sc.mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
+            L.check(lib.sr_tr_gelu(mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
             _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
             jobs += [
                 dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
