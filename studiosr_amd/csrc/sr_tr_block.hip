@@ -882,10 +882,24 @@ __global__ __launch_bounds__(256) void sr_tr_ca_bwd_kernel(SrTrCaBwd a) {
         }
     }
     __syncthreads();
-    if (tid < a.Cr) {
-        float dh = 0.f;
-        for (int c = 0; c < a.C; ++c) dh += dz2[c] * a.w2[c * a.Cr + tid];
-        dz1[tid] = hid[tid] > 0.f ? dh : 0.f;
+    {   // dh[j] = sum_c dz2[c] W2[c][j]: one channel per thread (its Cr weights are contiguous), wave sums by butterfly, the four wave sums through LDS
+        // (six threads walking 180 dependent L2 loads each was the longest piece of this prologue, which every workgroup of the image repeats)
+        __shared__ float wsum[64];  // [4 waves][16]
+        float ph[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ph[j] = (tid < a.C && j < a.Cr) ? dz2[tid] * a.w2[tid * a.Cr + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = ph[j];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0) wsum[(tid >> 6) * 16 + j] = v;
+        }
+        __syncthreads();
+        if (tid < a.Cr) {
+            const float dh = (wsum[tid] + wsum[16 + tid]) + (wsum[32 + tid] + wsum[48 + tid]);
+            dz1[tid] = hid[tid] > 0.f ? dh : 0.f;
+        }
     }
     __syncthreads();
     if (tid < a.Cp) {
