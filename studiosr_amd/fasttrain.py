@@ -33,6 +33,17 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
+BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
+_SIDE = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 CAB_MIDPRE = os.environ.get("SR_TR_MIDPRE", "1") != "0"  # A/B knob: the CAB's conv1 pre-activation kept by the forward (SrCab.mid_pre) instead of a conv1 launch in the backward
 HAB_MID = os.environ.get("SR_HAB_MID", "1") != "0"  # A/B knob: window attention + CAB forward as one launch (sr_hab_mid)
 WG_KS = int(os.environ.get("SR_WG_KS", "16"))  # token slices of the weight-gradient GEMMs (A/B knob)
@@ -390,6 +401,7 @@ class BlockPlan:
 
     def __init__(self, fp: FlatParams, blk, rpi: np.ndarray, rpi_dev: Tensor, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: "FinalMap", oca: bool = False) -> None:
         self.shift, self.conv_scale, self.oca = shift, float(conv_scale), oca
+        self._ev = None  # (fork, join) events of the backward's side stream
         self.fp, self.blk, self.fm, self.rpi_dev = fp, blk, fm, rpi_dev
         at = blk if oca else blk.attn  # OCAB holds qkv / proj / table itself
         mlp = blk.mlp
@@ -557,6 +569,19 @@ class BlockPlan:
         _call(lib.sr_tr_tail_bwd, L.SrTrTailBwd, "sr_tr_tail_bwd", dout=d.data_ptr(), x1=self.x1.data_ptr(), gamma=fa[self.o_g2:].data_ptr(), beta=fa[self.o_b2:].data_ptr(),
               wstream=wa[self.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(), n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(),
               dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=sc.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
+        # HAB: the CAB branch of the backward (channel attention, the two data-gradient convs, GELU') only shares sr_tr_tail_bwd's outputs with the attention
+        # backward and joins it in sr_tr_qkv_bwd: it runs on a side stream beside sr_tr_attn_bwd (two event edges per block; SR_TR_BWD_DUAL=0: one stream)
+        dual = BWD_DUAL and not self.oca
+        if dual:
+            main = torch.cuda.current_stream()
+            side = _side_stream(main.device)
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(), torch.cuda.Event())
+            self._ev[0].record(main)
+            side.wait_event(self._ev[0])
+            with torch.cuda.stream(side):
+                jobs_cab = self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp)
+                self._ev[1].record(side)
         dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
@@ -570,22 +595,11 @@ class BlockPlan:
             a.k, a.v, a.kwin, a.vwin = sc.dk.data_ptr(), sc.dv.data_ptr(), sc.dkwin.data_ptr(), sc.dvwin.data_ptr()
             a.B, a.nwy, a.nwx, a.heads, a.wse, a.pad = B, H // 16, W // 16, HEADS, 24, 4
             L.check(lib.sr_tr_oca_fold(C.byref(a), 0, _st()), "sr_tr_oca_fold")
-        else:  # ---- CAB backward (hat.py:41-52)
-            w1, b1, w2, b2 = self.ca
-            mid_pre = self.mid_pre
-            if mid_pre is None:  # (SR_TR_MIDPRE=0: conv1 again)
-                mid_pre = sc.mid_pre
-                _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], mid_pre, B, H, W, CP, 64)
-            _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
-                  w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
-                  parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
-            _conv(sc.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
-            L.check(lib.sr_tr_gelu(mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
-            _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
-            jobs += [
-                dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
-                dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
-            ]
+        elif dual:
+            main.wait_event(self._ev[1])
+            jobs += jobs_cab
+        else:
+            jobs += self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp)
         _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
               dn1c=None if self.oca else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
               n1w=sc.n1w.data_ptr(), dqkvw=sc.dqkvw.data_ptr(), ln_part=pp(self.f_ln1), ldn=CP, shift=self.shift, **g)
@@ -595,6 +609,25 @@ class BlockPlan:
             dict(A=sc.dhw.data_ptr(), B=sc.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
             dict(A=sc.doutw.data_ptr(), B=sc.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
         ] + jobs)
+
+
+    def _cab_backward(self, st: "Stage", B: int, H: int, W: int, T: int, lib, wa, fa, sc, pp) -> List[dict]:
+        """CAB backward (hat.py:41-52): launches on the current stream; returns its two weight-gradient jobs."""
+        w1, b1, w2, b2 = self.ca
+        mid_pre = self.mid_pre
+        if mid_pre is None:  # (SR_TR_MIDPRE=0: conv1 again)
+            mid_pre = sc.mid_pre
+            _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], mid_pre, B, H, W, CP, 64)
+        _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
+              w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
+              parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
+        _conv(sc.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
+        L.check(lib.sr_tr_gelu(mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
+        _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
+        return [
+            dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
+            dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
+        ]
 
 
 class Scratch:
