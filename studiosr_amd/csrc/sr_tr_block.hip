@@ -922,13 +922,27 @@ __global__ __launch_bounds__(256) void sr_tr_ca_bwd_kernel(SrTrCaBwd a) {
     const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
     const int quads = a.Cp >> 2;
     bf16* dy = reinterpret_cast<bf16*>(a.dy) + (size_t)b * hw * a.ld;
-    for (int i = p0 * quads + tid; i < p1 * quads; i += 256) {
-        const int px = i / quads, q = i - px * quads;
-        bf16x4* p = reinterpret_cast<bf16x4*>(dy + (size_t)px * a.ld + 4 * q);
-        f32x4 v = widen4(*p);
+    // four independent items in flight per thread (the in-place update had been one dependent load -> add -> store at a time: 48 round trips per thread with 16 slabs)
+    for (int i0 = p0 * quads + tid; i0 < p1 * quads; i0 += 4 * 256) {
+        bf16x4* pt[4];
+        bf16x4 raw[4];
+        int qq[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += dmean[4 * q + r];
-        *p = cvt4(v);
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 256, p1 * quads - 1);
+            const int px = i / quads;
+            qq[u] = i - px * quads;
+            pt[u] = reinterpret_cast<bf16x4*>(dy + (size_t)px * a.ld + 4 * qq[u]);
+            raw[u] = *pt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * 256 >= p1 * quads) continue;
+            f32x4 v = widen4(raw[u]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += dmean[4 * qq[u] + r];
+            *pt[u] = cvt4(v);
+        }
     }
 }
 
@@ -1083,7 +1097,7 @@ extern "C" int sr_tr_ca_bwd(const SrTrCaBwd* p, void* stream) {
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= a.Cp && a.Cp <= 256 && a.Cp % 4 == 0 && a.Cr > 0 && a.Cr <= 8 && a.n_tiles > 0 && a.parts > 0 && a.ld >= a.Cp &&
                    a.ld % 4 == 0 && a.dparam_stride >= 2 * a.Cr * a.C + a.Cr + a.C && a.y_scale != 0.f,
                "sr_tr_ca_bwd: bad geometry");
-    const int slabs = 16;
+    const int slabs = 64;  // (16: 36 us per launch at 4 x 64 x 64 -- 48 dependent in-place round trips per thread; every slab repeats the squeeze prologue)
     hipLaunchKernelGGL(sr_tr_ca_bwd_kernel, dim3(slabs, a.B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     SR_CHECK_LAUNCH("sr_tr_ca_bwd");
     return SR_OK;
