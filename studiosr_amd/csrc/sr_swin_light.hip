@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int L_CP = 64, L_HEADS = 6, L_HDP = 16, L_HP = 128, L_QKV = 3 * L_HEADS * L_HDP;  // 288
+constexpr int L_HEADS = 6;  // padded sizes: 64 channels, head features 10 -> 16, hidden 128
 constexpr int L_VT_LD = 144;  // bytes per V^T row (64 keys bf16 + 16 B): 16 rows hit 16 different 4-bank groups
 // LDS (bytes): [A image [8][64] cells, later the O image [12][64]] | Q [6][2][64] | K [6][2][64] | V^T [6][16] rows | partial sums; the hidden image
 // [16][64] reuses Q | K.  52 KB: three workgroups per CU, i.e. all 648 windows of the 8-tile bench shape resident at once.
