@@ -342,6 +342,12 @@ typedef struct SrWindowAttn {
                               * accumulator-fragment order of bias_frag -- valid when bias[h][q][k] depends on (q >> 4) - (k >> 4) and the in-row offsets only, as
                               * every relative-position bias does (tile d = (q >> 4) - (k >> 4) + 15).  Selects the LDS form: one (window, head) per workgroup with K,
                               * V^T and these tiles staged in LDS once (csrc/sr_wattn_lds_body.h) */
+    const float* x;          /* optional (ABI v8; bf16, 16 x 16 windows, hd_p 32, heads 6, C 180 in 192 padded channels, bias_tiles set): the fp32 stream [B,H,W,ldx] -- the
+                              * workgroup of a (window, head) then computes q, k, v ITSELF as qkv_h(LayerNorm1(x)) from wqkv (q / k / vt are not read; roll + window_partition
+                              * = the row gather, shift / y_mode as SrSwinQkv) and keeps them in LDS (csrc/sr_wattn_qkv_body.h) */
+    const void* wqkv;        /* sr_swin_qkv's 18-slot weight stream (packing.pack_swin_qkv_stream) */
+    int ldx, C;
+    float eps;
 } SrWindowAttn;
 int sr_window_attention(const SrWindowAttn* a, void* stream);
 

@@ -127,7 +127,7 @@ class SrWindowAttn(C.Structure):
         ("q", _vp), ("k", _vp), ("vt", _vp), ("bias", _vp), ("out", _vp),
         ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
         ("H", _i), ("W", _i), ("ws", _i), ("shift", _i), ("dtype", _i), ("y_mode", _i), ("bias_frag", _vp), ("qkv_frag", _i),
-        ("bias_tiles", _vp),
+        ("bias_tiles", _vp), ("x", _vp), ("wqkv", _vp), ("ldx", _i), ("C", _i), ("eps", _f),
     ]
 
 

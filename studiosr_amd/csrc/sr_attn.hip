@@ -12,6 +12,7 @@
 // The -100 shift mask is recomputed from window coordinates (same labels as the reference's
 // calculate_mask) instead of being read from memory.
 #include "sr_wattn_lds_body.h"
+#include "sr_wattn_qkv_body.h"
 
 namespace {
 
@@ -153,6 +154,20 @@ __global__ __launch_bounds__(256, 2) void sr_window_attn_lds_kernel(SrWindowAttn
     wattn_lds_block<FR>(a, blockIdx.x, smem);
 }
 
+__global__ __launch_bounds__(256, 2) void sr_window_attn_qkv_kernel(SrWindowAttn a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wattn_qkv_block(a, blockIdx.x, smem);
+}
+
+int launch_qkv_lds(const SrWindowAttn& a, hipStream_t st) {
+    static SrDeviceOnce once;
+    const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_window_attn_qkv_kernel, WQ_LDS); });
+    SR_REQUIRE(e == hipSuccess, "sr_window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(sr_window_attn_qkv_kernel, dim3(a.n_bwin * a.heads), dim3(256), WQ_LDS, st, a);
+    SR_CHECK_LAUNCH("sr_window_attention");
+    return SR_OK;
+}
+
 template <bool FR>
 int launch_lds(const SrWindowAttn& a, hipStream_t st) {
     static SrDeviceOnce once;
@@ -204,15 +219,21 @@ int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int sr_window_attention(const SrWindowAttn* p, void* stream) {
-    SR_REQUIRE(p && p->q && p->k && p->vt && p->bias && p->out, "sr_window_attention: null pointer");
+    SR_REQUIRE(p && ((p->q && p->k && p->vt) || p->x) && p->bias && p->out, "sr_window_attention: null pointer");
     const SrWindowAttn& a = *p;
     SR_REQUIRE(a.ws > 0 && a.ntok == a.ws * a.ws && a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws,
                "sr_window_attention: bad geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_window_attention: n_bwin");
     SR_REQUIRE(!a.qkv_frag || (a.dtype == SR_BF16 && a.ntok == 256 && a.hd_p == 32 && a.bias_frag && a.ws % 4 == 0), "sr_window_attention: qkv_frag needs bf16, 16 x 16 windows, hd_p 32 and bias_frag");
     SR_REQUIRE(!a.bias_tiles || (a.dtype == SR_BF16 && a.ntok == 256 && a.ws == 16 && a.hd_p == 32 && a.bias_frag), "sr_window_attention: bias_tiles needs bf16, 16 x 16 windows, hd_p 32 (and bias_frag for the fallback contract)");
-    SR_REQUIRE(!a.bias_tiles || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
+    SR_REQUIRE(!a.bias_tiles || a.x || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
                "sr_window_attention: the LDS form stages 16-byte pieces (q, k, vt, bias_tiles must be 16-byte aligned)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.x) {
+        SR_REQUIRE(a.wqkv && a.bias_tiles && a.dtype == SR_BF16 && a.ntok == 256 && a.ws == 16 && a.hd_p == 32 && a.heads == 6 && a.C == 180 && a.ldx >= 192 && a.ldx % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.wqkv)) & 15) == 0,
+                   "sr_window_attention: the fused QKV form needs x, wqkv, bias_tiles, bf16, 16 x 16 windows, 6 heads of <= 32, C = 180 in >= 192 padded channels");
+        return launch_qkv_lds(a, st);
+    }
     return a.dtype == SR_BF16 ? dispatch_attn<bf16>(a, st) : dispatch_attn<float>(a, st);
 }

@@ -13,6 +13,7 @@
 #define SR_CAB_PH 2
 #include "sr_cab_body.h"
 #include "sr_wattn_lds_body.h"
+#include "sr_wattn_qkv_body.h"
 
 namespace {
 
@@ -24,6 +25,8 @@ __global__ __launch_bounds__(256, 2) void sr_hab_mid_kernel(SrWindowAttn a, SrCa
     const int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
     if (block < n_cab)
         cab_block(c, block, smem);
+    else if constexpr ((MODE & 4) != 0)
+        wattn_qkv_block(a, block - n_cab, smem);  // LayerNorm1 + the head's QKV projection + attention (SrWindowAttn.x)
     else if constexpr ((MODE & 2) != 0)
         wattn_lds_block<(MODE & 1) != 0>(a, block - n_cab, smem);
     else
@@ -37,14 +40,17 @@ extern "C" int sr_hab_mid_supported(int ntok, int hd_p, int ws, int attn_dtype, 
 }
 
 extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream) {
-    SR_REQUIRE(pa && pa->q && pa->k && pa->vt && pa->bias_frag && pa->out, "sr_hab_mid: null pointer (attention operands; bias_frag is required)");
+    SR_REQUIRE(pa && ((pa->q && pa->k && pa->vt) || pa->x) && pa->bias_frag && pa->out, "sr_hab_mid: null pointer (attention operands; bias_frag is required)");
+    SR_REQUIRE(!pa->x || (pa->wqkv && pa->bias && pa->bias_tiles && pa->heads == 6 && pa->C == 180 && pa->ldx >= 192 && pa->ldx % 4 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(pa->x) | reinterpret_cast<uintptr_t>(pa->wqkv)) & 15) == 0),
+               "sr_hab_mid: the fused QKV form needs x, wqkv, bias, bias_tiles, 6 heads, C = 180 in >= 192 padded channels, 16-byte aligned rows");
     if (const int rc = cab_check(pc, "sr_hab_mid")) return rc;
     const SrWindowAttn& a = *pa;
     const SrCab& c = *pc;
     SR_REQUIRE(sr_hab_mid_supported(a.ntok, a.hd_p, a.ws, a.dtype, c.Cin_p, c.Cmid_p, c.Cout_p, c.dtype), "sr_hab_mid: unsupported geometry (16 x 16 windows, head_dim <= 32, bf16)");
     SR_REQUIRE(a.H % a.ws == 0 && a.W % a.ws == 0 && a.shift >= 0 && a.shift < a.ws && a.heads > 0, "sr_hab_mid: bad attention geometry");
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_hab_mid: n_bwin");
-    SR_REQUIRE(!a.bias_tiles || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
+    SR_REQUIRE(!a.bias_tiles || a.x || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
                "sr_hab_mid: the LDS form of the attention stages 16-byte pieces (q, k, vt, bias_tiles must be 16-byte aligned)");
     const long n_cab = (long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B;
     const bool lds_form = a.bias_tiles != nullptr;
@@ -52,7 +58,7 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
     const long blocks = n_cab + (lds_form ? (long)a.n_bwin * a.heads : (items + 3) / 4);
     SR_REQUIRE(blocks < (1l << 31), "sr_hab_mid: too many workgroups");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static SrDeviceOnce once[4];
+    static SrDeviceOnce once[5];
     auto launch = [&](auto kernel, SrDeviceOnce& o, int lds) -> int {
         const hipError_t e = sr_once_per_device(o, [&] { return sr_allow_lds(kernel, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_hab_mid: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -61,7 +67,9 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
         return SR_OK;
     };
     constexpr int LDS_BOTH = LDS_BYTES > WL_LDS ? LDS_BYTES : WL_LDS;
-    static_assert(2 * LDS_BOTH <= 160 * 1024, "two workgroups per CU");
+    constexpr int LDS_QKV = LDS_BYTES > WQ_LDS ? LDS_BYTES : WQ_LDS;
+    static_assert(2 * LDS_BOTH <= 160 * 1024 && 2 * LDS_QKV <= 160 * 1024, "two workgroups per CU");
+    if (a.x) return launch(sr_hab_mid_kernel<4>, once[4], LDS_QKV);
     if (lds_form) return a.qkv_frag ? launch(sr_hab_mid_kernel<3>, once[3], LDS_BOTH) : launch(sr_hab_mid_kernel<2>, once[2], LDS_BOTH);
     return a.qkv_frag ? launch(sr_hab_mid_kernel<1>, once[1], LDS_BYTES) : launch(sr_hab_mid_kernel<0>, once[0], LDS_BYTES);
 }

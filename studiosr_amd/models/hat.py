@@ -316,11 +316,19 @@ class HAT(Model):
         # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
         mid_fused = (unfused and cab_fused and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
                      and ops.hab_mid_supported(geo.ntok, geo.hd_p, geo.ws, L.SR_BF16, Cp, P["c3p"], Cp, L.SR_BF16))
+        # the attention workgroups of sr_hab_mid project their own head from the stream (LayerNorm1 + QKV inside the attention role: no QKV stage on the tail's chain)
+        qkv_in_attn = (mid_fused and not qkv_ready and "bias_tiles" in bp and bp.get("qkv_dtype") == L.SR_BF16 and geo.heads == 6 and geo.C == 180
+                       and knob("SR_ATTN_LDS", "1") != "0"
+                       # every head's workgroup re-reads and re-normalises its window's rows (6 x the stream through L2: 75 MB per launch at 4 x 64 x 64): it pays while the
+                       # launch is a latency chain (a single tile: 2.10 -> 1.97 ms) and costs above (b4 2.54 -> 2.92 ms, b16 7.00 -> 7.52); SR_ATTN_QKV=1 / 0 forces it
+                       and (knob("SR_ATTN_QKV", "auto") == "1" or (knob("SR_ATTN_QKV", "auto") == "auto" and (getattr(self, "_total_B", B) * H * W // geo.ntok) * geo.heads <= 128)))
+        if qkv_in_attn:
+            fuse_next_qkv = False
         qkv_n1 = None
         if mid_fused:
             side = main
             if not n1_ready:
-                if not qkv_ready and knob("SR_QKV_N1", "1") != "0":  # a group's first block: LayerNorm1 leaves sr_swin_qkv as a side output (one launch less)
+                if not qkv_ready and not qkv_in_attn and knob("SR_QKV_N1", "1") != "0":  # a group's first block: LayerNorm1 leaves sr_swin_qkv as a side output (one launch less)
                     qkv_n1 = (n1, *bp["ln1"])
                 else:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
@@ -380,7 +388,7 @@ class HAT(Model):
 
         # attention branch + shortcut (+ conv_scale * CA(cab) in the projection's epilogue) -> t   (hat.py:172-192)
         used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready,
-                              attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None, qkv_n1=qkv_n1)
+                              attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None, qkv_n1=qkv_n1, qkv_in_attn=qkv_in_attn)
         if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
             return next_ln is not None, fuse_next_qkv
         if not used:
@@ -441,6 +449,7 @@ class HAT(Model):
         B, _, H, W = x.shape
         s = self.scale
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
+        object.__setattr__(self, "_total_B", B)  # (launch-form heuristics look at the whole batch, so that half batches take the forms of the one-sequence forward)
         # Inside a HIP-graph capture a large batch runs as two half batches on two streams (as SwinIR's SR_SWIN_PARTS / RCAN's quarter batches): every launch
         # of this model is one or two residency rounds of latency-chain workgroups, and two out-of-phase chains fill each other's rounds (HAT x4 b16 7.61 ->
         # 7.19 ms as two batches of 8 in flight; no gain at b4: 2.62 vs 2.56).  bf16 path only (one queue per half: the other precisions fork a side stream per block).

@@ -300,7 +300,7 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
 
 def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, skip: Tensor, ws_, cdt: torch.dtype, shift: int, name: str = "msa",
-                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False, attn_launch=None, qkv_n1=None):
+                   y_mode: int = L.Y_ROLL, before_proj=None, with_mlp: bool = False, qkv_ready: bool = False, attn_launch=None, qkv_n1=None, qkv_in_attn: bool = False):
     """t_out = skip + proj(attention(qkv(LN(t_in))))  with window partition / shift folded into addressing.
     t_in, t_out, skip: fp32 [B, H, W, Cp] (t_out may alias skip).
     before_proj (HAT): called right before the projection GEMM of the un-fused path; returns extra sr_gemm fields for it (the gated
@@ -309,7 +309,8 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     one launch and the function returns "tail" (the caller must then skip run_mlp).
     qkv_ready: q / k / v^T of this block are already in the workspace (written by the previous block's sr_swin_tail): no QKV launch.
     attn_launch (HAT): called with the fields of ops.window_attention INSTEAD of that launch (sr_hab_mid: attention + CAB as one launch).
-    qkv_n1 (HAT): (n1, gamma, beta): sr_swin_qkv also writes LayerNorm(t_in) * gamma + beta to n1 (the caller guarantees that sr_swin_qkv runs)."""
+    qkv_n1 (HAT): (n1, gamma, beta): sr_swin_qkv also writes LayerNorm(t_in) * gamma + beta to n1 (the caller guarantees that sr_swin_qkv runs).
+    qkv_in_attn (HAT): no QKV launch at all -- the attention workgroups project their own head from t_in (SrWindowAttn.x / wqkv, csrc/sr_wattn_qkv_body.h)."""
     B, H, W, Cp = t_in.shape
     M = B * H * W
     nb = M // geo.ntok
@@ -327,7 +328,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     o = ws_.get(name + ".o", (M, geo.HP), cdt)
     frag = qkv_frag_order(p, geo, Cp, cdt)  # (a qkv_ready producer decides with the same predicate)
     assert qkv_n1 is None or (not qkv_ready and swin_qkv_usable(p, geo, Cp, cdt))
-    if qkv_ready:
+    if qkv_ready or qkv_in_attn:
         pass
     elif swin_qkv_usable(p, geo, Cp, cdt):
         ops.swin_qkv(x=t_in.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=p["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C,
@@ -345,6 +346,8 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
                qkv_frag=int(frag))
     if "bias_tiles" in p and sdt == L.SR_BF16 and knob("SR_ATTN_LDS", "1") != "0":  # K / V^T / distinct bias tiles staged in LDS once per (window, head)
         akw["bias_tiles"] = p["bias_tiles"].data_ptr()
+    if qkv_in_attn:
+        akw.update(x=t_in.data_ptr(), wqkv=p["qkv_stream"].data_ptr(), ldx=Cp, C=geo.C, eps=1e-5, qkv_frag=0)
     if attn_launch is not None:
         attn_launch(akw)
     else:

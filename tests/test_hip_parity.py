@@ -969,6 +969,37 @@ def test_hat_graph_replay_with_half_batches_equals_the_eager_forward():
     assert torch.equal(replayed, eager)
 
 
+@pytest.mark.parametrize("shift", [0, 8])
+def test_window_attention_with_its_own_qkv_projection_equals_qkv_launch_then_attention(shift):
+    """sr_window_attention with SrWindowAttn.x / wqkv (ABI v8, csrc/sr_wattn_qkv_body.h: every (window, head) workgroup normalises the window's rows and projects its
+    own q, k, v from sr_swin_qkv's weight stream, keeps them in LDS and runs the attention) against sr_swin_qkv followed by the LDS-form attention on the same packed
+    block (hat.py:164-176, 85-110): same products and the same bf16 rounding of q / k / v; LayerNorm statistics are summed in another order."""
+    torch.manual_seed(53)
+    m = _randomised(S.HAT(scale=2, depths=[2], num_heads=[6]), seed=53).to(DEV).eval().set_precision("bf16")
+    lp = m._get_packed(torch.bfloat16)["layers"][0]
+    geo = lp["geo"]
+    bp = lp["blocks"][0]
+    B, H, W, Cp = 2, 32, 48, geo.Cp
+    nb = B * (H // 16) * (W // 16)
+    t = torch.randn(B, H, W, Cp, device=DEV)
+    t[..., geo.C:] = 0
+    assert "bias_tiles" in bp and bp["qkv_dtype"] == L.SR_BF16
+    q, k, vt = (torch.empty(nb, 6, 256, 32, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    ops.swin_qkv(x=t.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=bp["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=6,
+                 hd_p=32, ws=16, shift=shift, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, frag_order=1)
+    common = dict(bias=bp["bias"].data_ptr(), n_bwin=nb, heads=6, hd_p=32, ntok=256, H=H, W=W, ws=16, shift=shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
+                  bias_frag=bp["bias_frag"].data_ptr(), bias_tiles=bp["bias_tiles"].data_ptr())
+    o_ref = torch.full((nb * 256, 192), float("nan"), device=DEV).to(torch.bfloat16)
+    ops.window_attention(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), out=o_ref.data_ptr(), qkv_frag=1, **common)
+    o_new = torch.full((nb * 256, 192), float("nan"), device=DEV).to(torch.bfloat16)
+    ops.window_attention(out=o_new.data_ptr(), x=t.data_ptr(), wqkv=bp["qkv_stream"].data_ptr(), ldx=Cp, C=geo.C, eps=1e-5, qkv_frag=0, **common)
+    torch.cuda.synchronize()
+    a, b = o_new.float(), o_ref.float()
+    assert not torch.isnan(a).any()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1.6e-2 * scale and float((a - b).pow(2).mean().sqrt()) <= 1e-3 * scale, (float((a - b).abs().max()) / scale)
+
+
 def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(monkeypatch):
     """A default-width HAT forward (shifted and unshifted HABs, OCAB) with sr_hab_mid (default) and with the two-stream attention || CAB launches."""
     torch.manual_seed(5)
