@@ -36,7 +36,7 @@ __device__ unsigned long long sr_dbg_tail[32];
 #define TSTAMP(i)                                                                                 \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (blockIdx.x == 7 && threadIdx.x == 0) sr_dbg_tail[i] = __builtin_amdgcn_s_memtime();   \
+        if (QKV && blockIdx.x == 7 && threadIdx.x == 0) sr_dbg_tail[i] = __builtin_amdgcn_s_memtime();   \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 #else
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(26);
     if (a.y && a.pool_partial) {
         // the channel-attention squeeze of this image (hat.py:25-38: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid, times conv_scale), recomputed per
         // workgroup from the pool partials of the CAB convolution while the loads above fly: replaces the sr_channel_gate launch at the end of
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         ca.pool_partial = a.pool_partial; ca.w1 = a.ca_w1; ca.b1 = a.ca_b1; ca.w2 = a.ca_w2; ca.b2 = a.ca_b2;
         ca.B = a.B; ca.H = a.H; ca.W = a.W; ca.C = a.C; ca.C_p = a.Cp; ca.Cr = a.ca_Cr; ca.n_tiles = a.ca_n_tiles; ca.y_scale = a.y_scale;
         const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + (X3 ? LDS_X : NTOK * OSTRIDE)));
+        TSTAMP(27);
 #pragma unroll
         for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
     }
@@ -265,6 +267,14 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     BLOCK_SYNC();
     TSTAMP(4);
 
+    // the LayerNorm side output leaves from the row tile at the end; its affine is requested here, a whole MLP ahead (full rows, adjacent lanes on adjacent addresses), not from the accumulator layout (a quad of
+    // lanes = four pixels = four cache lines per store: 12 such stores were 2 k cycles of vector-memory issue per wave)
+    f32x4 n1g = (f32x4)(0.0f), n1b = (f32x4)(0.0f);
+    if (a.n1) {
+        const int c4 = (lane0 < 48 ? lane0 : 0) * 4;
+        n1g = *reinterpret_cast<const f32x4*>(a.n1_gamma + c4);
+        n1b = *reinterpret_cast<const f32x4*>(a.n1_beta + c4);
+    }
     // ---- MLP in two hidden halves of 192 columns (sr_swin_block3.hip, same slots)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -349,37 +359,45 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             rstd[m] = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean[m] * mean[m], 0.f) + a.eps);
         }
     }
-    if (a.n1) {
-        f32x4 gm[3], bt[3];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            gm[n] = *reinterpret_cast<const f32x4*>(a.n1_gamma + w * 48 + ag * 4 + n * 16);
-            bt[n] = *reinterpret_cast<const f32x4*>(a.n1_beta + w * 48 + ag * 4 + n * 16);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const size_t noff = (size_t)pixel_row(m * 16 + ar) * a.ldn + w * 48 + ag * 4;
-#pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                f32x4 nv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((x1[m][n][r] - mean[m]) * rstd[m], gm[n][r], bt[n][r]);  // pad channels: gamma = beta = 0
-                if constexpr (X3)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.n1) + noff + n * 16) = nv;
-                else
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.n1) + noff + n * 16) = cvt4(nv);
-            }
-        }
-    }
+    TSTAMP(17);
     BLOCK_SYNC();
     {
         f32x4 rowv[16];
         const int l48 = lane < 48 ? lane : 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
+        float mr = 0.f, rs = 0.f;  // lane j < 16: the statistics of row 16 w + j (the same expression as mean[] / rstd[] above: the same bits)
+        if (a.n1) {
+            const float inv = 1.0f / (float)a.C;
+            const int rr = 16 * w + (lane & 15);
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(red + rr * 8), pb = *reinterpret_cast<const f32x4*>(red + rr * 8 + 4);
+            mr = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
+            rs = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mr * mr, 0.f) + a.eps);
+            asm volatile("" : "+v"(n1g), "+v"(n1b));  // the affine has landed HERE, on every path: no vmcnt(0) behind each row's stores below
+        }
+        if (a.n1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
+            for (int i = 0; i < 16; ++i) {
+                const int prow = pixel_row(16 * w + i);
+                store_row48(a.out + (size_t)prow * a.ldx, rowv[i], lane);
+                const float mi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mr), i));
+                const float ri = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), i));
+                f32x4 nv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nv[r] = __builtin_fmaf((rowv[i][r] - mi) * ri, n1g[r], n1b[r]);  // pad channels: gamma = beta = 0
+                if (lane < 48) {
+                    if constexpr (X3)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.n1) + (size_t)prow * a.ldn + l48 * 4) = nv;
+                    else
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.n1) + (size_t)prow * a.ldn + l48 * 4) = cvt4(nv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
+        }
     }
+    TSTAMP(18);
     if constexpr (QKV) {
         // ---- the next block's LayerNorm1 + QKV on the same tokens (its LayerNorm affine, attention scale and biases are in the weight slots)
         relane();
@@ -420,6 +438,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             dest(m * 16 + 4 * ag, vbw[m], vtok[m]);   // v^T: registers = tokens 16 m + 4 ag .. + 3 (they stay adjacent: shifts are multiples of 4)
         }
         BLOCK_SYNC();
+        TSTAMP(19);
         const int hh = w >> 1, half = w & 1;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -438,6 +457,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
                     }
                 }
             });
+            TSTAMP(20 + 2 * p);
             const int head = 2 * p + hh;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -456,6 +476,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt2) + vo) = cvt4(acc[m][2]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            TSTAMP(21 + 2 * p);
         }
     }
     TSTAMP(14);
