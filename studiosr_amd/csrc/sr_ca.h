@@ -2,93 +2,130 @@
 // sr_channel_gate) and sr_swin_tail.hip (gate recomputed in the tail kernel's prologue).  Included inside an anonymous namespace user.
 #pragma once
 #include "sr_common.h"
+#include <type_traits>
 
 namespace {
 
 // The squeeze half (pool partials -> mean -> 2-layer MLP -> sigmoid) for image b; leaves y_scale * gate in sm + C_p + Cr (C_p floats).
 // Recomputed by every workgroup that needs it, so it must be short: every step spreads its (independent) loads over all 256 threads
-// instead of walking n_tiles / C / Cr dependent loads in a few of them.
-SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
+// instead of walking n_tiles / C / Cr dependent loads in a few of them.  Three pieces, so that a caller can request the MLP operands early and
+// hand the partial sums over from LDS (sr_swin_tail.hip); ca_squeeze() below is their plain composition.
+constexpr int CA_SLICES = 8;
+SR_DEV bool ca_small(const SrChannelAttn& a) { return a.Cr <= 8 && a.C <= 256 && a.C_p <= 256; }  // every model here
+
+struct CaOps {  // the MLP operands of one thread (ca_small geometries)
+    float w1v[2][4], b1v[2], w2v[8], b2v;
+};
+// The MLP operands do not depend on the pool sums: they are requested together with the partials instead of one exposed L2 round trip per
+// phase (this prologue is the whole of sr_channel_gate: 14 -> 8 us).
+SR_DEV void ca_load_ops(const SrChannelAttn& a, CaOps& o) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    o.b2v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = wave + 4 * u;
+        o.b1v[u] = j < a.Cr ? a.b1[j] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = lane + 64 * v;
+            o.w1v[u][v] = (j < a.Cr && c < a.C) ? a.w1[j * a.C + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.w2v[j] = (tid < a.C && j < a.Cr) ? a.w2[tid * a.Cr + j] : 0.f;
+    if (tid < a.C) o.b2v = a.b2[tid];
+}
+
+// slice sums of one image's partials pool_img[n_tiles][C_p] (global memory, or an LDS copy of the same floats) -> part[CA_SLICES][C_p]: work item =
+// (slice, channel quad); 16-byte loads, 8 partials in flight per item (unconditional loads from clamped addresses, added in slot order: the
+// same sums as one scalar load at a time, which made this prologue 12 us per 32 slots)
+template <typename P>
+SR_DEV void ca_slice_sums(const SrChannelAttn& a, P pool_img, float* part) {
+    const int tid = threadIdx.x;
+    const int quads = a.C_p >> 2;
+    for (int idx = tid; idx < CA_SLICES * quads; idx += 256) {
+        const int sl = idx / quads, q = idx - sl * quads;
+        f32x4 s = (f32x4)(0.0f);
+        for (int t0 = sl; t0 < a.n_tiles; t0 += 8 * CA_SLICES) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pool_img + (size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (t0 + k * CA_SLICES < a.n_tiles) s += v[k];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[sl * a.C_p + 4 * q + r] = (4 * q + r < a.C) ? s[r] : 0.f;
+    }
+}
+
+// sum over the 64 lanes of a wave without LDS traffic (four DPP steps inside each row of 16 lanes, then the four row sums): every lane returns the same bits
+SR_DEV float ca_wave_sum(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// part -> mean -> hidden -> gate; `o` is read when ca_small(a).  Starts with the barrier behind the slice sums.  Leaves mean [C_p] | hid [Cr] | gate [C_p]
+// in sm (sr_tr_ca_bwd reads all three).  Called with 256 threads, all lanes active.
+SR_DEV float* ca_finish(const SrChannelAttn& a, const CaOps& o, float* sm) {
     float* mean = sm;                 // [C_p]
     float* hid = sm + a.C_p;          // [Cr]
     float* gate = hid + a.Cr;         // [C_p]
     float* part = gate + a.C_p;       // [CA_SLICES][C_p] partial channel sums
-    constexpr int CA_SLICES = 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / (float)(a.H * a.W);
-    // The MLP operands do not depend on the pool sums: with Cr <= 8 and C <= 256 (every model here) they are requested now, together
-    // with the partials, instead of one exposed L2 round trip per phase (this prologue is the whole of sr_channel_gate: 14 -> 8 us).
-    const bool small = a.Cr <= 8 && a.C <= 256 && a.C_p <= 256;
-    float w1v[2][4], b1v[2], w2v[8], b2v = 0.f;
+    const bool small = ca_small(a);
+    __syncthreads();
     if (small) {
+        // Three barriers instead of five and no ds_bpermute chains (this runs in the prologue of every sr_swin_tail workgroup): every wave forms the
+        // channel means it needs itself (channels lane + 64 v), its two hidden units by DPP sums, and only hid / gate cross waves through LDS.
+        float mv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = lane + 64 * v;
+            float s = 0.f;
+            if (c < a.C_p) {
+#pragma unroll
+                for (int sl = 0; sl < CA_SLICES; ++sl) s += part[sl * a.C_p + c];
+                if (wave == 0) mean[c] = s * inv;
+            }
+            mv[v] = s * inv;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int j = wave + 4 * u;
-            b1v[u] = j < a.Cr ? a.b1[j] : 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = lane + 64 * v;
-                w1v[u][v] = (j < a.Cr && c < a.C) ? a.w1[j * a.C + c] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w2v[j] = (tid < a.C && j < a.Cr) ? a.w2[tid * a.Cr + j] : 0.f;
-        if (tid < a.C) b2v = a.b2[tid];
-    }
-    // slice sums: work item = (slice, channel quad); 16-byte loads, 8 partials in flight per item (unconditional loads from clamped
-    // addresses, added in slot order: the same sums as one scalar load at a time, which made this prologue 12 us per 32 slots)
-    {
-        const int quads = a.C_p >> 2;
-        for (int idx = tid; idx < CA_SLICES * quads; idx += 256) {
-            const int sl = idx / quads, q = idx - sl * quads;
-            f32x4 s = (f32x4)(0.0f);
-            const float* pp = a.pool_partial + (size_t)b * a.n_tiles * a.C_p + 4 * q;
-            for (int t0 = sl; t0 < a.n_tiles; t0 += 8 * CA_SLICES) {
-                f32x4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (t0 + k * CA_SLICES < a.n_tiles) s += v[k];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[sl * a.C_p + 4 * q + r] = (4 * q + r < a.C) ? s[r] : 0.f;
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < a.C_p; c += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < CA_SLICES; ++sl) s += part[sl * a.C_p + c];
-        mean[c] = s * inv;
-    }
-    __syncthreads();
-    if (small) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = wave + 4 * u;
-            if (j < a.Cr) {  // one wave per hidden unit: lanes split the channels (same order of additions as the loop form below)
+            if (j < a.Cr) {  // one wave per hidden unit: lanes split the channels (the operands of channels >= C are 0)
                 float s = 0.f;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c = lane + 64 * v;
-                    if (c < a.C) s += w1v[u][v] * mean[c];
-                }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (lane == 0) {
-                    s += b1v[u];
-                    hid[j] = s > 0.f ? s : 0.f;
-                }
+                for (int v = 0; v < 4; ++v) s += o.w1v[u][v] * mv[v];
+                s = ca_wave_sum(s) + o.b1v[u];
+                if (lane == 0) hid[j] = s > 0.f ? s : 0.f;
             }
         }
     } else {
+        for (int c = tid; c < a.C_p; c += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < CA_SLICES; ++sl) s += part[sl * a.C_p + c];
+            mean[c] = s * inv;
+        }
+        __syncthreads();
         for (int j = wave; j < a.Cr; j += 4) {
             float s = 0.f;
             for (int c = lane; c < a.C; c += 64) s += a.w1[j * a.C + c] * mean[c];
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            for (int of = 32; of >= 1; of >>= 1) s += __shfl_xor(s, of, 64);
             if (lane == 0) {
                 s += a.b1[j];
                 hid[j] = s > 0.f ? s : 0.f;
@@ -100,10 +137,10 @@ SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
         float s = 0.f;
         if (c < a.C) {
             if (small) {
-                s = b2v;
+                s = o.b2v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (j < a.Cr) s += w2v[j] * hid[j];
+                    if (j < a.Cr) s += o.w2v[j] * hid[j];
             } else {
                 s = a.b2[c];
                 for (int j = 0; j < a.Cr; ++j) s += a.w2[c * a.Cr + j] * hid[j];
@@ -114,6 +151,14 @@ SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
     }
     __syncthreads();
     return gate;
+}
+constexpr int ca_scratch_floats(int C_p, int Cr) { return C_p + Cr + C_p + CA_SLICES * C_p; }
+
+SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
+    CaOps o = {};
+    if (ca_small(a)) ca_load_ops(a, o);
+    ca_slice_sums(a, a.pool_partial + (size_t)b * a.n_tiles * a.C_p, sm + a.C_p + a.Cr + a.C_p);
+    return ca_finish(a, o, sm);
 }
 
 }  // namespace

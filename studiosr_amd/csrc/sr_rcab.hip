@@ -16,6 +16,7 @@
 // one launch per block; only the last block of a residual group still needs the standalone sr_channel_attention.
 #include "sr_common.h"
 #include "sr_host.h"
+#include "sr_ca.h"
 
 namespace {
 
@@ -188,8 +189,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
                     const int j = wave + 4 * u;
                     if (j < Cr) {
                         float sum = lane < C ? w1v[u] * mean[lane] : 0.f;
-        #pragma unroll
-                        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                        sum = ca_wave_sum(sum);  // (sr_ca.h: the same order of additions as sr_channel_attention, DPP steps instead of a ds_bpermute chain)
                         if (lane == 0) {
                             sum += b1v[u];
                             hid[j] = sum > 0.f ? sum : 0.f;

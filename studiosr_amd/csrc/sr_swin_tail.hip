@@ -47,7 +47,15 @@ struct SwinTailDev {
     SrSwinTail a;
     FastDiv div_parts_img, div_parts_win, div_nwx;  // 64-token parts per image, per window; windows per row
     int ws_log2, nw;                                // windows per image
+    int pool_lds;                                   // the image's pool partials travel to LDS by DMA at kernel entry (see POOL_OFF)
 };
+
+// The channel-attention squeeze of the gated second residual (hat.py:25-38) reads the image's pool partials ([n_tiles][Cp] floats, 42 KB at 64 x 64) in every
+// workgroup.  As loads inside ca_squeeze they queued behind every other load of the prologue and cost 9.4 k of the kernel's 56 k cycles; now they travel
+// to LDS by DMA at kernel entry (no registers, in flight under the x / y loads), behind the O image -- the region up to the 80 KiB that two workgroups
+// per CU leave each is free until LayerNorm2 -- with the squeeze scratch behind them.  Launches whose partials do not fit keep the loads.
+constexpr int POOL_OFF = NTOK * OSTRIDE;
+constexpr int TAIL_LDS_MAX = 80 * 1024;
 
 // 16 B per lane from base + lane_off to LDS at lds_dst + 16 lane
 SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
@@ -123,6 +131,15 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             }
         }
     }
+    if (!X3 && dv.pool_lds) {
+        const unsigned pool_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + POOL_OFF;
+        const char* pbase = reinterpret_cast<const char*>(a.pool_partial + (size_t)bimg * a.ca_n_tiles * a.Cp);
+        const int pbytes = a.ca_n_tiles * a.Cp * 4;
+        for (int j = w; j * 1024 < pbytes; j += 4) {
+            const int off = j * 1024 + lane * 16;
+            if (off < pbytes) dma_gather16(pbase, off, __builtin_amdgcn_readfirstlane(pool_lds + j * 1024));
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(15);
     constexpr int NSL = QKV ? TAIL_SLOTS + QKV_SLOTS : TAIL_SLOTS;
@@ -165,23 +182,38 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     }
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(26);
-    if (a.y && a.pool_partial) {
+    SrChannelAttn ca;
+    CaOps cops = {};
+    const bool squeeze = a.y && a.pool_partial;
+    const bool squeeze_lds = !X3 && squeeze && dv.pool_lds;
+    if (squeeze) {
         // the channel-attention squeeze of this image (hat.py:25-38: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid, times conv_scale), recomputed per
-        // workgroup from the pool partials of the CAB convolution while the loads above fly: replaces the sr_channel_gate launch at the end of
-        // the conv branch.  Scratch behind the O image, in the hidden-half region (unused until the MLP).
-        SrChannelAttn ca;
+        // workgroup from the pool partials of the CAB convolution: replaces the sr_channel_gate launch at the end of the conv branch.
         ca.pool_partial = a.pool_partial; ca.w1 = a.ca_w1; ca.b1 = a.ca_b1; ca.w2 = a.ca_w2; ca.b2 = a.ca_b2;
         ca.B = a.B; ca.H = a.H; ca.W = a.W; ca.C = a.C; ca.C_p = a.Cp; ca.Cr = a.ca_Cr; ca.n_tiles = a.ca_n_tiles; ca.y_scale = a.y_scale;
-        const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + (X3 ? LDS_X : NTOK * OSTRIDE)));
-        TSTAMP(27);
+        if (squeeze_lds) {
+            ca_load_ops(ca, cops);  // its MLP operands fly with everything else; the sums wait for the DMA below
+        } else {
+            // partials from global memory while the loads above fly.  Scratch behind the O image, in the hidden-half region (unused until the MLP).
+            const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + (X3 ? LDS_X : NTOK * OSTRIDE)));
 #pragma unroll
-        for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
+            for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
+        }
+        TSTAMP(27);
     }
     // everything was issued together (one latency); the O image must be complete before the barrier, x and slot 0 are needed right behind it
     TSTAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BLOCK_SYNC();
     TSTAMP(2);
+    if (squeeze_lds) {
+        float* scratch = reinterpret_cast<float*>(smem + POOL_OFF + a.ca_n_tiles * a.Cp * 4);
+        ca_slice_sums(ca, reinterpret_cast<const float*>(smem + POOL_OFF), scratch + a.Cp + a.ca_Cr + a.Cp);
+        const float* gate = ca_finish(ca, cops, scratch);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
+        TSTAMP(28);
+    }
 
     auto loada_img = [&](const Frag<T>* img) {
         return [&, img](int c, int h, Frag<T> (&av)[2]) {
@@ -521,6 +553,17 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
     dv.ws_log2 = a.ws == 8 ? 3 : 4;
     dv.nw = nwx * nwy;
+    // pool partials by DMA into LDS (POOL_OFF): bf16 instantiations, squeeze geometries with register-resident MLP operands, partials + scratch within 80 KiB
+    int lds16 = Lds<bf16>::TOTAL;
+    dv.pool_lds = 0;
+    static const bool pool_global = getenv("SR_TAIL_POOL_LDS") && getenv("SR_TAIL_POOL_LDS")[0] == '0';  // A/B knob: SR_TAIL_POOL_LDS=0 keeps the loads
+    if (a.compute_dtype == SR_BF16 && a.y && a.pool_partial && a.ca_Cr <= 8 && a.C <= 256 && a.Cp <= 256 && !pool_global) {
+        const int need = POOL_OFF + a.ca_n_tiles * a.Cp * 4 + ca_scratch_floats(a.Cp, a.ca_Cr) * 4;
+        if (need <= TAIL_LDS_MAX && (reinterpret_cast<uintptr_t>(a.pool_partial) & 15) == 0) {
+            dv.pool_lds = 1;
+            lds16 = need > lds16 ? (need + 15) & ~15 : lds16;
+        }
+    }
     const dim3 grid(a.B * nwx * nwy * parts);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (a.compute_dtype == SR_BF16X3) {
@@ -530,14 +573,14 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
         hipLaunchKernelGGL((sr_swin_tail_kernel<bf3, false>), grid, dim3(256), Lds<bf3>::TOTAL, st, dv);
     } else if (a.q2) {
         static SrDeviceOnce attr_once;
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true>, Lds<bf16>::TOTAL); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true>, TAIL_LDS_MAX); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, true>), grid, dim3(256), Lds<bf16>::TOTAL, st, dv);
+        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, true>), grid, dim3(256), lds16, st, dv);
     } else {
         static SrDeviceOnce attr_once;
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, false>, Lds<bf16>::TOTAL); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, false>, TAIL_LDS_MAX); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, false>), grid, dim3(256), Lds<bf16>::TOTAL, st, dv);
+        hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, false>), grid, dim3(256), lds16, st, dv);
     }
     SR_CHECK_LAUNCH("sr_swin_tail");
     return SR_OK;

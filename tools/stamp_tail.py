@@ -12,7 +12,7 @@ import studiosr_amd._lib as L
 
 NAMES = {15: "O gather DMAs issued", 16: "ring loads issued", 1: "x (y, gate) loads issued", 2: "wait loads + bar", 3: "proj (6 steps)", 4: "bias/y + LN2 + bar", 5: "fc1 h0", 6: "gelu h0", 7: "bar", 8: "fc2 h0",
          9: "fc1 h1", 10: "bar + gelu h1", 11: "bar", 12: "fc2 h1", 13: "-", 17: "LN stats + tile + n1 side output", 18: "bar + row store", 19: "LN1 image + dest + 2 bar", 20: "qkv p0 (6 steps)", 21: "stores p0", 22: "qkv p1", 23: "stores p1",
-         24: "qkv p2", 25: "stores p2", 14: "end", 26: "x / y loads issued", 27: "ca_squeeze"}
+         24: "qkv p2", 25: "stores p2", 14: "end", 26: "x / y loads issued", 27: "ca_squeeze (global) / operand loads (LDS form)", 28: "ca_squeeze from LDS"}
 dev = torch.device("cuda")
 lib = L.lib()
 f = lib.sr_debug_tail_stamps
