@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 8
+#define SR_ABI_VERSION 9
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -221,6 +221,8 @@ typedef struct SrSwinTail {
     void* q2; void* k2; void* vt2;
     int shift2;
     int frag_order;        /* as SrSwinQkv.frag_order, for q2 / k2 / vt2 */
+    int oca_pad2;          /* (ABI v9) > 0: the fused stage is the LayerNorm1 + QKV of the group's overlapping cross attention (hat.py:247-264): q2 in window order
+                            * (shift2 = 0, row-major), k2 / vt2 in the zero-bordered layouts of SrSwinQkv.oca_pad = oca_pad2 (a multiple of 4) */
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);

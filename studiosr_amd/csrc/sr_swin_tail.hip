@@ -451,6 +451,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         }
         // destinations in the NEXT block's window order (shift2): token t of this workgroup sits at pixel (py, px) of the image
         const int nwx = (int)dv.div_nwx.d, ntok_log2 = 2 * wsl;
+        // (oca_pad2 > 0: the stage is the group's overlapping cross attention's -- k / v^T go to the zero-bordered image / plane layouts, addressed by the
+        //  bordered pixel index (y + e) (W + 2 e) + x + e, and shift2 is 0)
+        const int oe = a.oca_pad2, oWb = a.W + 2 * oe;
         auto dest = [&](int t, int& bw, int& tok) {
             const int tw = (int)part * NTOK + t;
             int y = ((int)wy << wsl) + (tw >> wsl) + a.shift, x = ((int)wx << wsl) + (tw & wsm) + a.shift;  // (y_mode == SR_Y_ROLL only)
@@ -462,13 +465,15 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             if (x < 0) x += a.W;
             bw = ((int)bimg * dv.nw + (y >> wsl) * nwx + (x >> wsl)) * a.heads;
             tok = ((y & wsm) << wsl) + (x & wsm);
+            return (y + oe) * oWb + x + oe;
         };
-        int qbw[4], qtok[4], vbw[4], vtok[4];
+        int qbw[4], qtok[4], vbw[4], vtok[4], kpix[4], vpix[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            dest(m * 16 + ar, qbw[m], qtok[m]);       // q, k: lane = token 16 m + ar
-            dest(m * 16 + 4 * ag, vbw[m], vtok[m]);   // v^T: registers = tokens 16 m + 4 ag .. + 3 (they stay adjacent: shifts are multiples of 4)
+            kpix[m] = dest(m * 16 + ar, qbw[m], qtok[m]);       // q, k: lane = token 16 m + ar
+            vpix[m] = dest(m * 16 + 4 * ag, vbw[m], vtok[m]);   // v^T: registers = tokens 16 m + 4 ag .. + 3 (they stay adjacent: shifts are multiples of 4)
         }
+        const size_t oplane = (size_t)(a.H + 2 * oe) * oWb;
         BLOCK_SYNC();
         TSTAMP(19);
         const int hh = w >> 1, half = w & 1;
@@ -503,8 +508,13 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
                     qo = ((((size_t)(qbw[m] + head)) << ntok_log2) + qtok[m]) * a.hd_p + 16 * half + 4 * ag;
                     vo = (((size_t)(vbw[m] + head) * a.hd_p + 16 * half + ar) << ntok_log2) + vtok[m];
                 }
+                size_t ko = qo;
+                if (oe > 0) {  // as sr_swin_qkv.hip's oca_pad branch
+                    ko = (((size_t)bimg * oplane + kpix[m]) * a.heads + head) * a.hd_p + 16 * half + 4 * ag;
+                    vo = (((size_t)bimg * a.heads + head) * a.hd_p + 16 * half + ar) * oplane + vpix[m];
+                }
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.q2) + qo) = cvt4(acc[m][0]);
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k2) + qo) = cvt4(acc[m][1]);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.k2) + ko) = cvt4(acc[m][1]);
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.vt2) + vo) = cvt4(acc[m][2]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -543,6 +553,8 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(!a.q2 || (a.k2 && a.vt2 && a.shift2 >= 0 && a.shift2 < a.ws && a.shift2 % 4 == 0 && a.shift % 4 == 0 && a.y_mode == SR_Y_ROLL),
                "sr_swin_tail: the fused next-block QKV needs q2 / k2 / vt2, shifts that are multiples of 4 and y_mode SR_Y_ROLL");
     SR_REQUIRE(!a.frag_order || (a.q2 && a.ws == 16), "sr_swin_tail: frag_order is a layout of q2 / k2 / vt2 for 16 x 16 windows");
+    SR_REQUIRE(a.oca_pad2 == 0 || (a.q2 && a.oca_pad2 > 0 && a.oca_pad2 % 4 == 0 && a.shift2 == 0 && !a.frag_order),
+               "sr_swin_tail: oca_pad2 needs q2 / k2 / vt2, a border that is a multiple of 4, shift2 == 0 and row-major q2");
     SR_REQUIRE(a.compute_dtype == SR_BF16 || !a.q2, "sr_swin_tail: the fused next-block QKV exists for SR_BF16 only");
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;

@@ -257,6 +257,8 @@ class HAT(Model):
             o.update(pack_mlp(oc.mlp, geo, dt, norm=oc.norm2))
             o.update(pack_tail_stream(oc.proj, oc.mlp, oc.norm2, geo, dt))
             o.update(pack_qkv_stream(oc, oc.norm1, geo, dt))
+            if blocks and blocks[-1].get("tail_dtype") == L.SR_BF16 and o.get("qkv_dtype") == L.SR_BF16:  # the last HAB's sr_swin_tail continues with the OCAB's LayerNorm1 + QKV
+                blocks[-1]["tail_oca_stream"] = torch.cat([blocks[-1]["tail_stream"], o["qkv_stream"]]).contiguous()
             conv = packing.pack_conv3x3(layer.conv.weight, layer.conv.bias, Cp, ident, dt)
             P["layers"].append(dict(blocks=blocks, ocab=o, conv=conv, geo=geo))
         P["norm"] = pack_ln(self.norm, Cp)
@@ -280,10 +282,10 @@ class HAT(Model):
         return st
 
     def _run_hab(self, bp: Dict, geo: SwinGeometry, P: Dict, t_in: Tensor, t: Tensor, ws_, cdt, n1_ready: bool = False, next_ln=None,
-                 qkv_ready: bool = False, next_bp=None):
+                 qkv_ready: bool = False, next_bp=None, next_oca=None):
         """t = HAB(t_in); t_in may be t (in place).
         n1_ready / qkv_ready: "hab.n1" already holds LayerNorm1(t_in) / "hab.q", "hab.k", "hab.vt" already hold this block's q, k, v^T (written by
-        the previous block's sr_swin_tail).  next_ln: norm1 (gamma, beta) of the block that follows, next_bp: its packed entry.  Returns
+        the previous block's sr_swin_tail).  next_ln: norm1 (gamma, beta) of the block that follows, next_bp: its packed entry (next_oca: the group's OCAB, for the last block).  Returns
         (n1 written for the next block, q / k / v^T written for the next block)."""
         B, H, W, Cp = t_in.shape
         f32 = torch.float32
@@ -312,6 +314,10 @@ class HAT(Model):
         # the tail kernel goes on with the next block's LayerNorm1 + QKV (its attention kernel is the next launch of the chain)
         fuse_next_qkv = (unfused and cdt == torch.bfloat16 and next_bp is not None and "tail_qkv_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt) and swin_qkv_usable(next_bp, geo, Cp, cdt)
                          and knob("SR_TAIL_QKV", "1") != "0" and bp["shift"] % 4 == 0 and next_bp["shift"] % 4 == 0)
+
+        # the group's last block: the tail goes on with the OCAB's LayerNorm1 + QKV instead (q in window order, k / v^T in the zero-bordered layouts; ABI v9, SR_TAIL_OCA=0)
+        fuse_oca = (unfused and cdt == torch.bfloat16 and next_bp is None and next_oca is not None and "tail_oca_stream" in bp and swin_tail_usable(bp, geo, Cp, cdt)
+                    and swin_qkv_usable(next_oca, geo, Cp, cdt) and P["border"] % 4 == 0 and knob("SR_TAIL_OCA", "1") != "0" and bp["shift"] % 4 == 0)
 
         # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
         mid_fused = (unfused and cab_fused and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
@@ -379,6 +385,11 @@ class HAT(Model):
                 d.update(qkv_next=dict(q=ws_.get("hab.q", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt), k=ws_.get("hab.k", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt),
                                        vt=ws_.get("hab.vt", (nb_, geo.heads, geo.hd_p, geo.ntok), cdt), shift=next_bp["shift"],
                                        frag=qkv_frag_order(next_bp, geo, Cp, cdt)))
+            if fuse_oca:
+                nb_, e_ = B * H * W // geo.ntok, P["border"]
+                d.update(qkv_next=dict(q=ws_.get("oca.q", (nb_, geo.heads, geo.ntok, geo.hd_p), cdt), k=ws_.get("oca.k", (B, H + 2 * e_, W + 2 * e_, geo.heads, geo.hd_p), cdt),
+                                       vt=ws_.get("oca.vt", (B, geo.heads, geo.hd_p, H + 2 * e_, W + 2 * e_), cdt), shift=0, frag=False, oca_pad=e_,
+                                       stream=bp["tail_oca_stream"]))
             if gate_in_tail:
                 d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
                                  ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))
@@ -390,7 +401,7 @@ class HAT(Model):
         used = run_window_msa(bp, bp["ln1"], geo, t_in, t, t_in, ws_, cdt, bp["shift"], name="hab", before_proj=join, with_mlp=True, qkv_ready=qkv_ready,
                               attn_launch=(lambda akw: ops.hab_mid(akw, cab_kw)) if mid_fused else None, qkv_n1=qkv_n1, qkv_in_attn=qkv_in_attn)
         if used == "tail":  # projection + both residuals + LayerNorm2 + MLP (+ the next block's LayerNorm1 and QKV) ran as one launch (sr_swin_tail)
-            return next_ln is not None, fuse_next_qkv
+            return next_ln is not None, fuse_next_qkv or fuse_oca
         if not used:
             # one-kernel attention half (ws 8 geometries): the combine stays a separate pass over the stream
             if side is not main:
@@ -399,8 +410,8 @@ class HAT(Model):
         run_mlp(bp, bp["ln2"], geo, t, ws_, cdt, name="hab")
         return False, False
 
-    def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt) -> None:
-        """t = OCAB(t) in place (hat.py:239-293)."""
+    def _run_ocab(self, op: Dict, geo: SwinGeometry, P: Dict, t: Tensor, ws_, cdt, qkv_ready: bool = False) -> None:
+        """t = OCAB(t) in place (hat.py:239-293).  qkv_ready: "oca.q" / "oca.k" / "oca.vt" were written by the last HAB's sr_swin_tail."""
         B, H, W, Cp = t.shape
         M = B * H * W
         nb = M // geo.ntok
@@ -411,7 +422,9 @@ class HAT(Model):
         vt = ws_.get("oca.vt", (B, geo.heads, geo.hd_p, H + 2 * e, W + 2 * e), cdt)  # 5-D key: the zero border must never alias another geometry
         o = ws_.get("oca.o", (M, geo.HP), cdt)
         fold = fold_ln(cdt)
-        if swin_qkv_usable(op, geo, Cp, cdt) and e % 4 == 0:  # stream form: LayerNorm1 + QKV with k / v^T in the zero-bordered layouts
+        if qkv_ready:
+            pass
+        elif swin_qkv_usable(op, geo, Cp, cdt) and e % 4 == 0:  # stream form: LayerNorm1 + QKV with k / v^T in the zero-bordered layouts
             ops.swin_qkv(x=t.data_ptr(), q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), wstream=op["qkv_stream"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp,
                          ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=0, eps=1e-5, y_mode=L.Y_ROLL, compute_dtype=op["qkv_dtype"], oca_pad=e)
         else:
@@ -502,11 +515,12 @@ class HAT(Model):
             for i, bp in enumerate(lp["blocks"]):
                 nbp = lp["blocks"][i + 1] if i + 1 < len(lp["blocks"]) else None
                 ready, qready = self._run_hab(bp, geo, P, cur, tb, ws_, cdt, n1_ready=ready, next_ln=None if nbp is None else nbp["ln1"],
-                                              qkv_ready=qready, next_bp=nbp)
+                                              qkv_ready=qready, next_bp=nbp, next_oca=lp["ocab"] if nbp is None else None)
                 cur = tb
             if cur is ta:
                 tb.copy_(ta)
-            self._run_ocab(lp["ocab"], geo, P, tb, ws_, cdt)
+                qready = False
+            self._run_ocab(lp["ocab"], geo, P, tb, ws_, cdt, qkv_ready=qready and bool(lp["blocks"]))
             conv_call(tb, *lp["conv"], ta, cdt, skip=ta)  # ta = conv(group(ta)) + ta  (hat.py:385)
         normed = ws_.get("normed", (B, Hp, Wp, Cp), cdt)  # read only by the conv, which rounds to the compute dtype anyway
         ops.layernorm(ta, normed, *P["norm"], self.embed_dim)

@@ -245,9 +245,11 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     qkv_next = extra.pop("qkv_next", None)    # the next block's LayerNorm1 + QKV as the kernel's last stage (stream: tail + that block's QKV slots)
     wstream = p["tail_stream"]
     if qkv_next is not None:
-        wstream = p["tail_qkv_stream"]
+        wstream = qkv_next.get("stream", None)
+        if wstream is None:
+            wstream = p["tail_qkv_stream"]
         kw.update(q2=qkv_next["q"].data_ptr(), k2=qkv_next["k"].data_ptr(), vt2=qkv_next["vt"].data_ptr(), shift2=int(qkv_next["shift"]),
-                  frag_order=int(bool(qkv_next.get("frag"))))
+                  frag_order=int(bool(qkv_next.get("frag"))), oca_pad2=int(qkv_next.get("oca_pad", 0)))
     x3 = p["tail_dtype"] == L.SR_BF16X3  # split operands: o, y and the LayerNorm side output are fp32 tensors
     if n1 is not None:
         assert n1.dtype == (torch.float32 if x3 else torch.bfloat16) and n1.shape == skip.shape

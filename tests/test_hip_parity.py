@@ -1016,6 +1016,23 @@ def test_hat_forward_with_the_one_launch_mid_stage_matches_the_two_stream_form(m
     assert float((new - old).abs().max()) <= 5e-3 * max(1.0, float(old.abs().max()))
 
 
+def test_hat_last_block_tail_with_the_ocab_qkv_stage_equals_the_separate_qkv_launch(monkeypatch):
+    """The last HAB of a group: sr_swin_tail goes on with the OCAB's LayerNorm1 + QKV (q in window order, k / v^T in the zero-bordered layouts; SrSwinTail.oca_pad2,
+    default) against the sr_swin_qkv launch with oca_pad (SR_TAIL_OCA=0): the same weights and the same arithmetic on the same rows -> the same bits."""
+    torch.manual_seed(6)
+    m = _randomised(S.HAT(scale=2, depths=[2, 2], num_heads=[6, 6]), seed=11).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(2, 3, 48, 32, device=DEV)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SR_TAIL_OCA", flag)
+        with torch.no_grad():
+            outs.append(m(x).clone())
+    torch.cuda.synchronize()
+    new, old = outs
+    assert not torch.isnan(new).any()
+    assert torch.equal(new, old), float((new - old).abs().max())
+
+
 def test_gated_second_residual_of_the_projection_gemm_equals_channel_attention():
     """HAT's combine x = shortcut + attn + conv_scale * CA(cab) (hat.py:192): sr_channel_gate + sr_gemm's gated second residual against the
     two-pass form (projection GEMM with the shortcut, then sr_channel_attention over the stream)."""
