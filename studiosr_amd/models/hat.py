@@ -466,7 +466,8 @@ class HAT(Model):
         # Inside a HIP-graph capture a large batch runs as two half batches on two streams (as SwinIR's SR_SWIN_PARTS / RCAN's quarter batches): every launch
         # of this model is one or two residency rounds of latency-chain workgroups, and two out-of-phase chains fill each other's rounds (HAT x4 b16 7.61 ->
         # 7.19 ms as two batches of 8 in flight; no gain at b4: 2.62 vs 2.56).  bf16 path only (one queue per half: the other precisions fork a side stream per block).
-        parts = int(knob("SR_HAT_PARTS", "2"))
+        # (four quarter batches from 16 images on: b16 6.80 -> 6.64 ms, 64 tiles 27.9 -> 27.6; eight: no further gain)
+        parts = int(knob("SR_HAT_PARTS", "0")) or (4 if (B >= 16 and B % 4 == 0) else 2)
         if parts > 1 and cdt == torch.bfloat16 and B >= 8 * parts // 2 and B % parts == 0 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
