@@ -223,6 +223,8 @@ typedef struct SrSwinTail {
     int frag_order;        /* as SrSwinQkv.frag_order, for q2 / k2 / vt2 */
     int oca_pad2;          /* (ABI v9) > 0: the fused stage is the LayerNorm1 + QKV of the group's overlapping cross attention (hat.py:247-264): q2 in window order
                             * (shift2 = 0, row-major), k2 / vt2 in the zero-bordered layouts of SrSwinQkv.oca_pad = oca_pad2 (a multiple of 4) */
+    int wg_tokens;         /* (ABI v9) tokens per workgroup: 64, 32 (SR_BF16 only: twice the workgroups of half the rows each -- for launches that would leave the chip at
+                            * one 64-token workgroup per CU or less, where the kernel is one latency chain per CU), or 0 = the launcher decides (32 up to 128 workgroups of 64) */
 } SrSwinTail;
 int sr_swin_tail_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_tail(const SrSwinTail* a, void* stream);

@@ -91,7 +91,7 @@ class SrSwinTail(C.Structure):
         ("shift", _i), ("Hp", _i), ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
         ("n1", _vp), ("n1_gamma", _vp), ("n1_beta", _vp), ("ldn", _i),
         ("pool_partial", _vp), ("ca_w1", _vp), ("ca_b1", _vp), ("ca_w2", _vp), ("ca_b2", _vp), ("ca_Cr", _i), ("ca_n_tiles", _i), ("y_scale", _f),
-        ("q2", _vp), ("k2", _vp), ("vt2", _vp), ("shift2", _i), ("frag_order", _i), ("oca_pad2", _i),
+        ("q2", _vp), ("k2", _vp), ("vt2", _vp), ("shift2", _i), ("frag_order", _i), ("oca_pad2", _i), ("wg_tokens", _i),
     ]
 
 

@@ -201,10 +201,22 @@ struct WStream {
     }
     // NST uniform steps starting at slot s0: loada(c, h, a) reads the two activation fragments (m-tiles 2h, 2h+1) of the stage's K-chunk c,
     // compute(c, h, b, a) issues their 6 MFMAs.  Half 1 of chunk c and half 0 of chunk c + 1 are read under the MFMAs before them.
-    template <int NST, typename LoadA, typename Compute>
+    // HV = 1 (32-token workgroups, sr_swin_tail.hip): only half 0 exists; chunk c + 1's fragments are read under chunk c's MFMAs.
+    template <int NST, int HV = 2, typename LoadA, typename Compute>
     SR_DEV void run(int s0, int lane, LoadA&& loada, Compute&& compute) {
         Frag<T> a0[2], a1[2];
         loada(0, 0, a0);
+        if constexpr (HV == 1) {
+#pragma unroll
+            for (int c = 0; c < NST; ++c) {
+                const int s = s0 + c;
+                if (s + DIST < NS) load(s + DIST, lane);
+                if (c + 1 < NST) loada(c + 1, 0, (c & 1) ? a0 : a1);
+                compute(c, 0, r[s % RING], (c & 1) ? a1 : a0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #ifdef SR_EXP_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif

@@ -12,6 +12,7 @@
 //     fc1 / fc2 biases ride on the constant-one pad channels exactly as in sr_swin_block (same slots 24..47 of that stream);
 //   * x1 never leaves the registers; the result leaves through the LDS row tile as full 768-B rows.
 #include <type_traits>
+#include <cstdlib>
 #include "sr_swin_stream.h"
 #include "sr_ca.h"
 
@@ -72,10 +73,15 @@ SR_DEV void dma_gather16(const char* base, int lane_off, unsigned lds_dst) {
 // T = bf3 (compute type SR_BF16X3, precision "fp32x3" = what inference() runs): split operands as in sr_swin_block3.hip; O, y and the LayerNorm side output are
 // fp32 tensors (the fp32 attention kernel / the split-operand convs write and read those), O passes through LDS as fp32 rows (the x-tile geometry) and is
 // split into hi | lo fragments as it is read; 98 KiB of LDS, one workgroup per CU; no fused next-block QKV.
-template <typename T, bool QKV>
+// MT = row tiles of 16 tokens per workgroup: 4 (64 tokens), or 2 (32 tokens; bf16) for launches that would leave the chip with one workgroup per CU or less --
+// twice the workgroups of half the rows each: the kernel is a latency chain at one wave per SIMD (57 k cycles for 9 k cycles of MFMAs), and two half-size chains
+// per CU overlap.  The LDS images keep their 64-token strides (half of each is unused).
+template <typename T, bool QKV, int MT = 4>
 __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void sr_swin_tail_kernel(SwinTailDev dv) {
     constexpr bool X3 = sizeof(Frag<T>) == 32;
+    constexpr int NT_ = 16 * MT, RW = NT_ / 4;  // tokens per workgroup; rows per wave in the row-tile passes
     static_assert(!(X3 && QKV), "the fused next-block QKV exists for bf16 operands only");
+    static_assert(MT == 4 || (MT == 2 && !X3), "32-token workgroups: bf16 instantiations only");
     const SrSwinTail& a = dv.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag<T>* Aimg = reinterpret_cast<Frag<T>*>(smem);  // O image (token-major, 400-B rows) first, then the LayerNorm2 image [24 k-groups][64 tokens]
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;
     const int wsl = dv.ws_log2, wsm = a.ws - 1;
     auto pixel_row = [&](int t) {  // image-order row of token t of this workgroup (window_reverse + roll back as one gather)
-        const int tw = (int)part * NTOK + t;
+        const int tw = (int)part * NT_ + t;
         int y = ((int)wy << wsl) + (tw >> wsl) + shift_y;
         int x = ((int)wx << wsl) + (tw & wsm) + a.shift;
         if (y >= a.H) y -= a.H;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         // O: 64 rows of 384 B, contiguous in memory -> token-major LDS image with a 400-B row stride (conflict-free fragment reads): 25
         // coalesced 1-KiB LDS-DMA pieces; cell q = 64 j + lane of piece j is 16-B column q % 25 of row q / 25 (column 24 = padding, masked)
         const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-        const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NTOK * OROW;
+        const char* orow = reinterpret_cast<const char*>(a.o) + (size_t)blockIdx.x * NT_ * OROW;
         if constexpr (X3) {  // fp32 rows of 768 B -> the x-tile geometry (XS stride), 16 rows per wave
             const float* of = reinterpret_cast<const float*>(a.o) + (size_t)blockIdx.x * NTOK * 192;
 #pragma unroll
@@ -123,11 +129,11 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int j = w + 4 * i;
-            if (j < 25) {
+            if (j * 64 < NT_ * 25) {
                 const int q = j * 64 + lane;
                 const int row = (q * 1311) >> 15;  // q / 25 for q < 1600
                 const int cc = q - row * 25;
-                if (cc < 24) dma_gather16(orow, row * OROW + cc * 16, __builtin_amdgcn_readfirstlane(img_lds + j * 1024));
+                if (cc < 24 && row < NT_) dma_gather16(orow, row * OROW + cc * 16, __builtin_amdgcn_readfirstlane(img_lds + j * 1024));
             }
         }
     }
@@ -150,16 +156,16 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     for (int s0 = 0; s0 < SR_TAIL_DIST; ++s0) ws.load(s0, lane);
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(16);
-    f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
+    f32x4 x1[MT][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3
     f32x4 gt[3], bp[3];
-    typename std::conditional<X3, f32x4, bf16x4>::type yv[4][3];  // y: fp32 on the split-operand path
+    typename std::conditional<X3, f32x4, bf16x4>::type yv[MT][3];  // y: fp32 on the split-operand path
     const int ch0 = w * 48 + ag * 4;
     {
-        int prow[4];
+        int prow[MT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) prow[m] = pixel_row(m * 16 + ar);
+        for (int m = 0; m < MT; ++m) prow[m] = pixel_row(m * 16 + ar);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) x1[m][n] = *reinterpret_cast<const f32x4*>(a.x + (size_t)prow[m] * a.ldx + ch0 + n * 16);
 #pragma unroll
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
                 for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)bimg * a.ld_gate + ch0 + n * 16);
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 3; ++n) {
                     if constexpr (X3)
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             av[1] = *reinterpret_cast<const Frag<T>*>(ob + 16 * OSTRIDE);
         }
     };
-    ws.template run<6>(0, lane, loada_o, [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
+    ws.template run<6, MT / 2>(0, lane, loada_o, [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&ov)[2]) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     relane();
     {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
                 x1[m][n] += bp[n];
@@ -261,9 +267,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     const bool one_lane = (w == ONE_C / 48) && (ag == (ONE_C % 16) / 4);
     {
         {
-            float q1[4], q2[4];
+            float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};  // (MT = 2: row tiles 2, 3 do not exist -- their sums are zeros nobody reads)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];
                 f32x4 t2 = x1[m][0] * x1[m][0];
 #pragma unroll
@@ -273,12 +279,12 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             }
             const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);
             const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
-            *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);
+            if (MT == 4 || ag < MT) *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);
         }
         BLOCK_SYNC();
         const float inv = 1.0f / (float)a.C;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
             const float mean = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
             const float rstd = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean * mean, 0.f) + a.eps);
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         relane();
-        f32x4 acc[4][3];
-        ws.template run<6>(6 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
+        f32x4 acc[MT][3];
+        ws.template run<6, MT / 2>(6 + 12 * hf, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
 #pragma unroll
         for (int n = 0; n < 3; ++n)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 f32x4 g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[r] = gelu_op<T>(acc[m][n][r]);
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         TSTAMP(6 + 4 * hf);
         BLOCK_SYNC();
         TSTAMP(7 + 4 * hf);
-        ws.template run<6>(12 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&hv)[2]) {
+        ws.template run<6, MT / 2>(12 + 12 * hf, lane, loada_img(Himg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&hv)[2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -360,9 +366,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     relane();
     const bool want_ln = QKV || a.n1;
     if (want_ln) {
-        float q1[4], q2[4];
+        float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             f32x4 t1 = x1[m][0] + x1[m][1] + x1[m][2];
             f32x4 t2 = x1[m][0] * x1[m][0];
 #pragma unroll
@@ -372,20 +378,20 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         }
         const float s1 = rows_reduce_scatter4(q1[0], q1[1], q1[2], q1[3]);
         const float s2 = rows_reduce_scatter4(q2[0], q2[1], q2[2], q2[3]);
-        *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);  // (LayerNorm2's partials were consumed many barriers ago)
+        if (MT == 4 || ag < MT) *reinterpret_cast<float2*>(red + ((ag * 16 + ar) * 4 + w) * 2) = make_float2(s1, s2);  // (LayerNorm2's partials were consumed many barriers ago)
     }
     BLOCK_SYNC();  // every wave has read its last hidden fragments: the tile region is free
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         char* xm = smem + (m * 16 + ar) * XS + (w * 48 + ag * 4) * 4;
 #pragma unroll
         for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xm + n * 64) = x1[m][n];
     }
-    float mean[4], rstd[4];
+    float mean[MT], rstd[MT];
     if (want_ln) {
         const float inv = 1.0f / (float)a.C;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const f32x4 pa = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8), pb = *reinterpret_cast<const f32x4*>(red + (m * 16 + ar) * 8 + 4);
             mean[m] = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
             rstd[m] = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mean[m] * mean[m], 0.f) + a.eps);
@@ -394,14 +400,14 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     TSTAMP(17);
     BLOCK_SYNC();
     {
-        f32x4 rowv[16];
+        f32x4 rowv[RW];
         const int l48 = lane < 48 ? lane : 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
+        for (int i = 0; i < RW; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (RW * w + i) * XS + l48 * 16);
         float mr = 0.f, rs = 0.f;  // lane j < 16: the statistics of row 16 w + j (the same expression as mean[] / rstd[] above: the same bits)
         if (a.n1) {
             const float inv = 1.0f / (float)a.C;
-            const int rr = 16 * w + (lane & 15);
+            const int rr = RW * w + (lane & (RW - 1));
             const f32x4 pa = *reinterpret_cast<const f32x4*>(red + rr * 8), pb = *reinterpret_cast<const f32x4*>(red + rr * 8 + 4);
             mr = (pa[0] + pa[2] + pb[0] + pb[2]) * inv;
             rs = rsqrtf(fmaxf((pa[1] + pa[3] + pb[1] + pb[3]) * inv - mr * mr, 0.f) + a.eps);
@@ -409,8 +415,8 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         }
         if (a.n1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int prow = pixel_row(16 * w + i);
+            for (int i = 0; i < RW; ++i) {
+                const int prow = __builtin_amdgcn_readfirstlane(pixel_row(RW * w + i));  // (wave-uniform: the row pointer of store_row48 is a scalar operand)
                 store_row48(a.out + (size_t)prow * a.ldx, rowv[i], lane);
                 const float mi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mr), i));
                 const float ri = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), i));
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
+            for (int i = 0; i < RW; ++i) store_row48(a.out + (size_t)__builtin_amdgcn_readfirstlane(pixel_row(RW * w + i)) * a.ldx, rowv[i], lane);
         }
     }
     TSTAMP(18);
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         relane();
         BLOCK_SYNC();  // every wave has read its rows of the tile: the image region is free again
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const float nmr = -mean[m] * rstd[m];
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         //  bordered pixel index (y + e) (W + 2 e) + x + e, and shift2 is 0)
         const int oe = a.oca_pad2, oWb = a.W + 2 * oe;
         auto dest = [&](int t, int& bw, int& tok) {
-            const int tw = (int)part * NTOK + t;
+            const int tw = (int)part * NT_ + t;
             int y = ((int)wy << wsl) + (tw >> wsl) + a.shift, x = ((int)wx << wsl) + (tw & wsm) + a.shift;  // (y_mode == SR_Y_ROLL only)
             if (y >= a.H) y -= a.H;
             if (x >= a.W) x -= a.W;
@@ -467,9 +473,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             tok = ((y & wsm) << wsl) + (x & wsm);
             return (y + oe) * oWb + x + oe;
         };
-        int qbw[4], qtok[4], vbw[4], vtok[4], kpix[4], vpix[4];
+        int qbw[MT], qtok[MT], vbw[MT], vtok[MT], kpix[MT], vpix[MT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             kpix[m] = dest(m * 16 + ar, qbw[m], qtok[m]);       // q, k: lane = token 16 m + ar
             vpix[m] = dest(m * 16 + 4 * ag, vbw[m], vtok[m]);   // v^T: registers = tokens 16 m + 4 ag .. + 3 (they stay adjacent: shifts are multiples of 4)
         }
@@ -479,8 +485,8 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         const int hh = w >> 1, half = w & 1;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            f32x4 acc[4][3];
-            ws.template run<6>(TAIL_SLOTS + 6 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
+            f32x4 acc[MT][3];
+            ws.template run<6, MT / 2>(TAIL_SLOTS + 6 * p, lane, loada_img(Aimg), [&](int c, int h, Frag<T> (&b)[3], Frag<T> (&av)[2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     if (c == 0) {
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
             TSTAMP(20 + 2 * p);
             const int head = 2 * p + hh;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 size_t qo, vo;
                 if (a.frag_order) {  // fragment order of SrWindowAttn.qkv_frag (see sr_swin_qkv.hip); token = qtok / vtok of the next block's window
                     qo = (((size_t)(qbw[m] + head)) << ntok_log2) * a.hd_p + (size_t)(((qtok[m] >> 4) * 4 + 2 * half + (ag >> 1)) * 16 + (qtok[m] & 15)) * 8 + 4 * (ag & 1);
@@ -559,7 +565,12 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE((long long)a.B * a.H * a.W < (1ll << 31), "sr_swin_tail: more than 2^31 tokens");
     SwinTailDev dv;
     dv.a = a;
-    const int nwx = a.W / a.ws, nwy = a.H / a.ws, parts = a.ws * a.ws / 64;
+    // 32-token workgroups (SrSwinTail.wg_tokens; 0: up to 128 workgroups of 64 tokens -- SR_TAIL_MT2_BELOW overrides that bound, read per call so that one process
+    // can run both forms)
+    SR_REQUIRE(a.wg_tokens == 0 || a.wg_tokens == 64 || (a.wg_tokens == 32 && a.compute_dtype == SR_BF16), "sr_swin_tail: wg_tokens is 0, 64, or 32 with SR_BF16");
+    const char* mt2_env = getenv("SR_TAIL_MT2_BELOW");
+    const bool mt2 = a.compute_dtype == SR_BF16 && (a.wg_tokens == 32 || (a.wg_tokens == 0 && (long long)a.B * a.H * a.W / 64 < (mt2_env ? atoi(mt2_env) : 129)));
+    const int nwx = a.W / a.ws, nwy = a.H / a.ws, parts = a.ws * a.ws / (mt2 ? 32 : 64);
     dv.div_parts_img = make_fastdiv((uint32_t)(nwx * nwy * parts));
     dv.div_parts_win = make_fastdiv((uint32_t)parts);
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
@@ -583,6 +594,17 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf3, false>, Lds<bf3>::TOTAL); });
         SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL((sr_swin_tail_kernel<bf3, false>), grid, dim3(256), Lds<bf3>::TOTAL, st, dv);
+    } else if (mt2) {
+        static SrDeviceOnce attr_once[2];
+        if (a.q2) {
+            const hipError_t e = sr_once_per_device(attr_once[1], [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true, 2>, TAIL_LDS_MAX); });
+            SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, true, 2>), grid, dim3(256), lds16, st, dv);
+        } else {
+            const hipError_t e = sr_once_per_device(attr_once[0], [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, false, 2>, TAIL_LDS_MAX); });
+            SR_REQUIRE(e == hipSuccess, "sr_swin_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL((sr_swin_tail_kernel<bf16, false, 2>), grid, dim3(256), lds16, st, dv);
+        }
     } else if (a.q2) {
         static SrDeviceOnce attr_once;
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_swin_tail_kernel<bf16, true>, TAIL_LDS_MAX); });

@@ -393,6 +393,12 @@ class HAT(Model):
             if gate_in_tail:
                 d.update(ca=dict(pool_partial=pool.data_ptr(), ca_w1=w1.data_ptr(), ca_b1=b1.data_ptr(), ca_w2=w2.data_ptr(), ca_b2=b2.data_ptr(),
                                  ca_Cr=w1.shape[0], ca_n_tiles=n_tiles, y_scale=float(self.conv_scale)))
+            # 32-token workgroups while the WHOLE forward (all part batches) is at most one 64-token workgroup per CU: single tile 1.89 -> 1.67 ms, b2 2.22 -> 1.96,
+            # b4 2.59 -> 2.55; two parts of four images each (b8) would put 1,024 of them on 512 places: 3.90 -> 4.12 ms
+            if getattr(self, "_total_B", B) * H * W // 64 <= int(knob("SR_TAIL_WG32_UPTO", "256")):
+                d.update(wg_tokens=32)
+            else:
+                d.update(wg_tokens=64)
             if next_ln is not None:  # n1's last reader (this block's first conv) has joined: the tail may overwrite it (bf16; fp32 on the split-operand path)
                 d.update(n1=n1, n1_ln=next_ln)
             return d
@@ -441,7 +447,7 @@ class HAT(Model):
             nk_frag=op["oca_nk_frag"], bias_rel=op["oca_bias_rel"].data_ptr() if ("oca_bias_rel" in op and sdt == L.SR_BF16) else None,
         )
         if swin_tail_usable(op, geo, Cp, cdt):
-            run_swin_tail(op, geo, o, t, t, 0)
+            run_swin_tail(op, geo, o, t, t, 0, extra=dict(wg_tokens=32 if getattr(self, "_total_B", B) * H * W // 64 <= int(knob("SR_TAIL_WG32_UPTO", "256")) else 64))
             return
         ops.gemm(
             A=o.data_ptr(), Wp=op["proj_w"].data_ptr(), bias=op["proj_b"].data_ptr(), out=t.data_ptr(), skip=t.data_ptr(), M=M, K=geo.HP, N=Cp,

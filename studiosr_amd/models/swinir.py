@@ -242,6 +242,7 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     extra = dict(extra or {})
     n1, n1_ln = extra.pop("n1", None), extra.pop("n1_ln", None)
     kw.update(extra.pop("ca", None) or {})  # in-kernel channel-attention gate (pool partials + squeeze weights)
+    wg_tokens = int(extra.pop("wg_tokens", 0))  # 32 / 64 / 0 = the launcher's own rule (the caller may know that other part batches share the chip)
     qkv_next = extra.pop("qkv_next", None)    # the next block's LayerNorm1 + QKV as the kernel's last stage (stream: tail + that block's QKV slots)
     wstream = p["tail_stream"]
     if qkv_next is not None:
@@ -260,7 +261,7 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     ops.swin_tail(
         x=skip.data_ptr(), out=t_out.data_ptr(), o=o.data_ptr(), wstream=wstream.data_ptr(), bproj=p["proj_b"].data_ptr(), B=B, H=H, W=W,
         C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode,
-        compute_dtype=p["tail_dtype"], **kw,
+        compute_dtype=p["tail_dtype"], wg_tokens=0 if x3 else wg_tokens, **kw,
     )
 
 
@@ -358,7 +359,7 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     if with_mlp and swin_tail_usable(p, geo, Cp, cdt):
         run_swin_tail(p, geo, o, skip, t_out, shift, y_mode, extra)
         return "tail"
-    for k_ in ("n1", "n1_ln", "ca", "qkv_next"):  # the LayerNorm side output / in-kernel gate / fused next QKV exist only in sr_swin_tail
+    for k_ in ("n1", "n1_ln", "ca", "qkv_next", "wg_tokens"):  # the LayerNorm side output / in-kernel gate / fused next QKV exist only in sr_swin_tail
         extra.pop(k_, None)
     ops.gemm(
         A=o.data_ptr(), Wp=p["proj_w"].data_ptr(), bias=p["proj_b"].data_ptr(), out=t_out.data_ptr(), skip=skip.data_ptr(),

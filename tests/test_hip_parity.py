@@ -634,8 +634,8 @@ def test_swin_qkv_and_tail_kernels_at_both_window_sizes_against_the_gemm_launche
         assert float((new - old).pow(2).mean().sqrt()) <= rms * scale
 
 
-@pytest.mark.parametrize("ws", [8, 16])
-def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
+@pytest.mark.parametrize("ws,wg_tokens", [(8, 64), (16, 64), (8, 32), (16, 32)])
+def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws, wg_tokens):
     """sr_swin_tail's optional last stage (LayerNorm1 + QKV of the NEXT block on the same tokens, scattered into that block's window order:
     q2 / k2 / vt2, shift2) against sr_swin_qkv run on the tail's output with the next block's stream: same bits, both shift orders."""
     from studiosr_amd.models import swinir as SW
@@ -660,7 +660,7 @@ def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
         k2, vt2 = torch.full_like(q2, float("nan")), torch.full((nb, geo.heads, geo.hd_p, geo.ntok), float("nan"), device=DEV).to(cdt)
         ops.swin_tail(x=skip.data_ptr(), out=out.data_ptr(), o=o.data_ptr(), wstream=stream.data_ptr(), bproj=cur["proj_b"].data_ptr(), B=B, H=H, W=W,
                       C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=cur["shift"], Hp=geo.hid_p, eps=1e-5,
-                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, q2=q2.data_ptr(), k2=k2.data_ptr(), vt2=vt2.data_ptr(), shift2=nxt["shift"])
+                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, q2=q2.data_ptr(), k2=k2.data_ptr(), vt2=vt2.data_ptr(), shift2=nxt["shift"], wg_tokens=wg_tokens)
         want = [torch.full_like(q2, float("nan")), torch.full_like(k2, float("nan")), torch.full_like(vt2, float("nan"))]
         ops.swin_qkv(x=out.data_ptr(), q=want[0].data_ptr(), k=want[1].data_ptr(), vt=want[2].data_ptr(), wstream=nxt["qkv_stream"].data_ptr(), B=B, H=H, W=W,
                      C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=nxt["shift"], eps=1e-5, y_mode=L.Y_ROLL,
@@ -669,7 +669,7 @@ def test_swin_tail_fused_next_block_qkv_equals_a_separate_qkv_launch(ws):
         plain = torch.full_like(skip, float("nan"))  # and the stream output itself does not depend on the fused stage
         ops.swin_tail(x=skip.data_ptr(), out=plain.data_ptr(), o=o.data_ptr(), wstream=cur["tail_stream"].data_ptr(), bproj=cur["proj_b"].data_ptr(), B=B, H=H,
                       W=W, C=geo.C, Cp=geo.Cp, ldx=geo.Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=cur["shift"], Hp=geo.hid_p, eps=1e-5,
-                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16)
+                      y_mode=L.Y_ROLL, compute_dtype=L.SR_BF16, wg_tokens=64)
         assert torch.equal(out, plain) and not torch.isnan(out).any()
         for got, ref, name in zip((q2, k2, vt2), want, "q k vt".split()):
             assert not torch.isnan(got.float()).any(), name
@@ -1025,6 +1025,23 @@ def test_hat_last_block_tail_with_the_ocab_qkv_stage_equals_the_separate_qkv_lau
     outs = []
     for flag in ("1", "0"):
         monkeypatch.setenv("SR_TAIL_OCA", flag)
+        with torch.no_grad():
+            outs.append(m(x).clone())
+    torch.cuda.synchronize()
+    new, old = outs
+    assert not torch.isnan(new).any()
+    assert torch.equal(new, old), float((new - old).abs().max())
+
+
+def test_hat_forward_with_32_token_tail_workgroups_equals_the_64_token_form(monkeypatch):
+    """sr_swin_tail with 32 tokens per workgroup (SrSwinTail.wg_tokens; what small batches run) against 64: the same rows through the same arithmetic (gated second
+    residual, LayerNorm side output, fused next-block and OCAB QKV included) -> the same bits."""
+    torch.manual_seed(8)
+    m = _randomised(S.HAT(scale=2, depths=[3], num_heads=[6]), seed=13).to(DEV).eval().set_precision("bf16")
+    x = torch.rand(2, 3, 48, 32, device=DEV)
+    outs = []
+    for upto in ("1000000", "0"):
+        monkeypatch.setenv("SR_TAIL_WG32_UPTO", upto)
         with torch.no_grad():
             outs.append(m(x).clone())
     torch.cuda.synchronize()
