@@ -6,11 +6,14 @@
 
 namespace {
 
-// The squeeze half (pool partials -> mean -> 2-layer MLP -> sigmoid) for image b; leaves y_scale * gate in sm + C_p + Cr (C_p floats).
+// The squeeze half (pool partials -> mean -> 2-layer MLP -> sigmoid) for image b; returns y_scale * gate (C_p floats in the scratch).
 // Recomputed by every workgroup that needs it, so it must be short: every step spreads its (independent) loads over all 256 threads
 // instead of walking n_tiles / C / Cr dependent loads in a few of them.  Three pieces, so that a caller can request the MLP operands early and
 // hand the partial sums over from LDS (sr_swin_tail.hip); ca_squeeze() below is their plain composition.
 constexpr int CA_SLICES = 8;
+// scratch layout: mean [C_p] | hid [Cr rounded up to 4] | gate [C_p] | part [CA_SLICES][C_p]  (16-byte aligned pieces when C_p is a multiple of 4)
+SR_DEV constexpr int ca_hid_pad(int Cr) { return (Cr + 3) & ~3; }
+SR_DEV float* ca_part(float* sm, int C_p, int Cr) { return sm + C_p + ca_hid_pad(Cr) + C_p; }
 SR_DEV bool ca_small(const SrChannelAttn& a) { return a.Cr <= 8 && a.C <= 256 && a.C_p <= 256; }  // every model here
 
 struct CaOps {  // the MLP operands of one thread (ca_small geometries)
@@ -18,45 +21,53 @@ struct CaOps {  // the MLP operands of one thread (ca_small geometries)
 };
 // The MLP operands do not depend on the pool sums: they are requested together with the partials instead of one exposed L2 round trip per
 // phase (this prologue is the whole of sr_channel_gate: 14 -> 8 us).
+// Template arguments CP / CC / CR (here and below): the padded and true channel counts and the squeeze width as compile-time constants (0 = read them from `a`).
+// Callers that run the squeeze in every workgroup at one wave per SIMD (sr_swin_tail.hip) instantiate their geometry: the generic form is ~1,000 instructions of
+// guards and address arithmetic, and at one wave per SIMD every instruction is ~5 cycles of the chain.  Same arithmetic in the same order either way.
+template <int CC = 0, int CR = 0>
 SR_DEV void ca_load_ops(const SrChannelAttn& a, CaOps& o) {
+    const int C = CC ? CC : a.C, Cr = CR ? CR : a.Cr;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     o.b2v = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int j = wave + 4 * u;
-        o.b1v[u] = j < a.Cr ? a.b1[j] : 0.f;
+        o.b1v[u] = j < Cr ? a.b1[j] : 0.f;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int c = lane + 64 * v;
-            o.w1v[u][v] = (j < a.Cr && c < a.C) ? a.w1[j * a.C + c] : 0.f;
+            o.w1v[u][v] = (j < Cr && c < C) ? a.w1[j * C + c] : 0.f;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.w2v[j] = (tid < a.C && j < a.Cr) ? a.w2[tid * a.Cr + j] : 0.f;
-    if (tid < a.C) o.b2v = a.b2[tid];
+    for (int j = 0; j < 8; ++j) o.w2v[j] = (tid < C && j < Cr) ? a.w2[tid * Cr + j] : 0.f;
+    if (tid < C) o.b2v = a.b2[tid];
 }
 
 // slice sums of one image's partials pool_img[n_tiles][C_p] (global memory, or an LDS copy of the same floats) -> part[CA_SLICES][C_p]: work item =
 // (slice, channel quad); 16-byte loads, 8 partials in flight per item (unconditional loads from clamped addresses, added in slot order: the
 // same sums as one scalar load at a time, which made this prologue 12 us per 32 slots)
-template <typename P>
+template <int CP = 0, int CC = 0, typename P>
 SR_DEV void ca_slice_sums(const SrChannelAttn& a, P pool_img, float* part) {
+    const int C_p = CP ? CP : a.C_p, C = CC ? CC : a.C;
     const int tid = threadIdx.x;
-    const int quads = a.C_p >> 2;
+    const int quads = C_p >> 2;
     for (int idx = tid; idx < CA_SLICES * quads; idx += 256) {
         const int sl = idx / quads, q = idx - sl * quads;
         f32x4 s = (f32x4)(0.0f);
         for (int t0 = sl; t0 < a.n_tiles; t0 += 8 * CA_SLICES) {
             f32x4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pool_img + (size_t)min(t0 + k * CA_SLICES, a.n_tiles - 1) * a.C_p + 4 * q);
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(pool_img + min(t0 + k * CA_SLICES, a.n_tiles - 1) * C_p + 4 * q);  // (one image: < 2^31 floats)
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (t0 + k * CA_SLICES < a.n_tiles) s += v[k];
         }
+        f32x4 o4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[sl * a.C_p + 4 * q + r] = (4 * q + r < a.C) ? s[r] : 0.f;
+        for (int r = 0; r < 4; ++r) o4[r] = (4 * q + r < C) ? s[r] : 0.f;
+        *reinterpret_cast<f32x4*>(part + sl * C_p + 4 * q) = o4;
     }
 }
 
@@ -77,15 +88,21 @@ SR_DEV float ca_wave_sum(float v) {
 
 // part -> mean -> hidden -> gate; `o` is read when ca_small(a).  Starts with the barrier behind the slice sums.  Leaves mean [C_p] | hid [Cr] | gate [C_p]
 // in sm (sr_tr_ca_bwd reads all three).  Called with 256 threads, all lanes active.
-SR_DEV float* ca_finish(const SrChannelAttn& a, const CaOps& o, float* sm) {
+template <int CP = 0, int CC = 0, int CR = 0>
+SR_DEV float* ca_finish(const SrChannelAttn& a_, const CaOps& o, float* sm) {
+    struct {  // the geometry as constants where given
+        int C_p, C, Cr, H, W;
+        const float *w1, *b1, *w2, *b2;
+        float y_scale;
+    } a = {CP ? CP : a_.C_p, CC ? CC : a_.C, CR ? CR : a_.Cr, a_.H, a_.W, a_.w1, a_.b1, a_.w2, a_.b2, a_.y_scale};
     float* mean = sm;                 // [C_p]
     float* hid = sm + a.C_p;          // [Cr]
-    float* gate = hid + a.Cr;         // [C_p]
+    float* gate = hid + ca_hid_pad(a.Cr);  // [C_p]
     float* part = gate + a.C_p;       // [CA_SLICES][C_p] partial channel sums
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / (float)(a.H * a.W);
-    const bool small = ca_small(a);
+    const bool small = (CP && CC && CR) ? true : ca_small(a_);
     __syncthreads();
     if (small) {
         // Three barriers instead of five and no ds_bpermute chains (this runs in the prologue of every sr_swin_tail workgroup): every wave forms the
@@ -152,12 +169,12 @@ SR_DEV float* ca_finish(const SrChannelAttn& a, const CaOps& o, float* sm) {
     __syncthreads();
     return gate;
 }
-constexpr int ca_scratch_floats(int C_p, int Cr) { return C_p + Cr + C_p + CA_SLICES * C_p; }
+constexpr int ca_scratch_floats(int C_p, int Cr) { return C_p + ((Cr + 3) & ~3) + C_p + CA_SLICES * C_p; }
 
 SR_DEV float* ca_squeeze(const SrChannelAttn& a, int b, float* sm) {
     CaOps o = {};
     if (ca_small(a)) ca_load_ops(a, o);
-    ca_slice_sums(a, a.pool_partial + (size_t)b * a.n_tiles * a.C_p, sm + a.C_p + a.Cr + a.C_p);
+    ca_slice_sums(a, a.pool_partial + (size_t)b * a.n_tiles * a.C_p, ca_part(sm, a.C_p, a.Cr));
     return ca_finish(a, o, sm);
 }
 

@@ -306,7 +306,7 @@ extern "C" int sr_channel_gate(const SrChannelAttn* p, float* gate, void* stream
     SR_REQUIRE(p && gate && p->pool_partial && p->w1 && p->b1 && p->w2 && p->b2, "sr_channel_gate: null pointer");
     const SrChannelAttn& a = *p;
     SR_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= a.C_p && a.C_p % 4 == 0 && a.Cr > 0 && a.n_tiles > 0, "sr_channel_gate: bad geometry");
-    const int lds = (2 * a.C_p + a.Cr + 8 * a.C_p) * (int)sizeof(float);
+    const int lds = ca_scratch_floats(a.C_p, a.Cr) * (int)sizeof(float);
     hipLaunchKernelGGL(sr_channel_gate_kernel, dim3(a.B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a, gate);
     SR_CHECK_LAUNCH("sr_channel_gate");
     return SR_OK;
@@ -316,7 +316,7 @@ extern "C" int sr_channel_attention(const SrChannelAttn* p, void* stream) {
     SR_REQUIRE(p && p->y && p->pool_partial && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "sr_channel_attention: null pointer");
     const SrChannelAttn& a = *p;
     SR_REQUIRE(a.B > 0 && a.C > 0 && a.C <= a.C_p && a.C_p % 4 == 0 && a.Cr > 0 && a.n_tiles > 0, "sr_channel_attention: bad geometry");
-    const int lds = (2 * a.C_p + a.Cr + 8 * a.C_p) * (int)sizeof(float);
+    const int lds = ca_scratch_floats(a.C_p, a.Cr) * (int)sizeof(float);
     const long per_img = (long)a.H * a.W * (a.C_p / 4);
     int gx = (int)((per_img + 256 * 8 - 1) / (256 * 8));  // >= 8 vector groups per thread: the squeeze prologue is paid per workgroup
     if (gx > 512) gx = 512;

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
         ca.pool_partial = a.pool_partial; ca.w1 = a.ca_w1; ca.b1 = a.ca_b1; ca.w2 = a.ca_w2; ca.b2 = a.ca_b2;
         ca.B = a.B; ca.H = a.H; ca.W = a.W; ca.C = a.C; ca.C_p = a.Cp; ca.Cr = a.ca_Cr; ca.n_tiles = a.ca_n_tiles; ca.y_scale = a.y_scale;
         if (squeeze_lds) {
-            ca_load_ops(ca, cops);  // its MLP operands fly with everything else; the sums wait for the DMA below
+            if (a.ca_Cr == 6)  // its MLP operands fly with everything else; the sums wait for the DMA below
+                ca_load_ops<180, 6>(ca, cops);
+            else
+                ca_load_ops(ca, cops);
         } else {
             // partials from global memory while the loads above fly.  Scratch behind the O image, in the hidden-half region (unused until the MLP).
             const float* gate = ca_squeeze(ca, (int)bimg, reinterpret_cast<float*>(smem + (X3 ? LDS_X : NTOK * OSTRIDE)));
@@ -214,8 +217,14 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? SR_TAIL_WGS : 1) void 
     TSTAMP(2);
     if (squeeze_lds) {
         float* scratch = reinterpret_cast<float*>(smem + POOL_OFF + a.ca_n_tiles * a.Cp * 4);
-        ca_slice_sums(ca, reinterpret_cast<const float*>(smem + POOL_OFF), scratch + a.Cp + a.ca_Cr + a.Cp);
-        const float* gate = ca_finish(ca, cops, scratch);
+        const float* gate;
+        if (a.ca_Cr == 6) {  // HAT's geometry (180 channels in 192, squeeze_factor 30) as compile-time constants: a third of the instructions
+            ca_slice_sums<192, 180>(ca, reinterpret_cast<const float*>(smem + POOL_OFF), ca_part(scratch, 192, 6));
+            gate = ca_finish<192, 180, 6>(ca, cops, scratch);
+        } else {
+            ca_slice_sums(ca, reinterpret_cast<const float*>(smem + POOL_OFF), ca_part(scratch, a.Cp, a.ca_Cr));
+            gate = ca_finish(ca, cops, scratch);
+        }
 #pragma unroll
         for (int n = 0; n < 3; ++n) gt[n] = *reinterpret_cast<const f32x4*>(gate + ch0 + n * 16);
         TSTAMP(28);
@@ -553,7 +562,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     SR_REQUIRE(!a.y || (a.ldy >= a.Cp && a.ldy % 4 == 0), "sr_swin_tail: gated second residual needs ldy");
     SR_REQUIRE(!a.y || a.pool_partial || (a.gate && a.ld_gate >= a.Cp && a.ld_gate % 4 == 0), "sr_swin_tail: gated second residual needs gate / ld_gate or the pool partials");
     SR_REQUIRE(!a.y || !a.pool_partial || (a.ca_w1 && a.ca_b1 && a.ca_w2 && a.ca_b2 && a.ca_Cr > 0 && a.ca_n_tiles > 0 &&
-                                           (2 * a.Cp + a.ca_Cr + 8 * a.Cp) * 4 <= 22 * 1024),
+                                           ca_scratch_floats(a.Cp, a.ca_Cr) * 4 <= 22 * 1024),
                "sr_swin_tail: in-kernel gate needs the squeeze weights (scratch: 22 KiB)");
     SR_REQUIRE(!a.n1 || (a.n1_gamma && a.n1_beta && a.ldn >= a.Cp && a.ldn % 4 == 0), "sr_swin_tail: the LayerNorm side output needs n1_gamma, n1_beta, ldn");
     SR_REQUIRE(!a.q2 || (a.k2 && a.vt2 && a.shift2 >= 0 && a.shift2 < a.ws && a.shift2 % 4 == 0 && a.shift % 4 == 0 && a.y_mode == SR_Y_ROLL),
