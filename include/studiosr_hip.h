@@ -529,6 +529,9 @@ int sr_pack_bias_fragments(const float* table, const long long* rpi, float* out,
 int sr_tr_gather(const float* P, const int* idx, const int* idx2, const float* scl, const unsigned char* mode, void* out, int out_dtype, long long n, void* stream);
 /* The adjoint: grad[i] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]]  (src[i] == -1: grad[i] = 0; src[i] == -2: grad[i] untouched); sums in slice order. */
 int sr_tr_finalize(const float* arena, const long long* src, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream);
+/* (ABI v9) the same sums with the items in arena order: grad[dst[i]] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]] (the host sorts the items by src: coalesced
+ * partial reads whatever the parameter order is; ns[i] = 0 writes a zero) */
+int sr_tr_finalize_to(const float* arena, const long long* src, const int* dst, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream);
 
 typedef struct SrTrWgradJob {
     /* dW[slice][tap][n][k] = sum over the slice's tokens t of A[t][n] * B[t'][k]: the weight gradient of nn.Linear (taps 1, t' = t;

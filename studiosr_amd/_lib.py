@@ -297,6 +297,7 @@ SYMBOLS = {
     # fast training path (ABI v7)
     "sr_tr_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "sr_tr_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "sr_tr_finalize_to": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sr_tr_wgrad": (_i, [C.POINTER(SrTrWgradJob), _i, _vp]),
     "sr_tr_wgrad_out_floats": (_ll, [C.POINTER(SrTrWgradJob)]),
     "sr_tr_attn_bwd": (_i, [C.POINTER(SrTrAttnBwd), _vp]),

@@ -61,6 +61,30 @@ __global__ __launch_bounds__(256) void sr_tr_finalize_kernel(const float* __rest
     grad[i] = acc * scale[i];
 }
 
+// The same sums with the work items in ARENA order: item i reads arena[src[i] + s * stride[i]] and writes grad[dst[i]].  The host sorts the items by src, so
+// adjacent lanes read adjacent partials also where the parameter order is not the packed order (3x3 conv weights: the nine taps of a (co, ci) pair are adjacent
+// parameters but 144 KB apart in the packed gradient -- in parameter order every lane of such a load sat on its own cache line, 16 slices deep); the one
+// scattered access per item is the 4-byte result store.  ns[i] = 0 writes a zero.
+__global__ __launch_bounds__(256) void sr_tr_finalize_to_kernel(const float* __restrict__ arena, const long long* __restrict__ src, const int* __restrict__ dst,
+                                                               const int* __restrict__ stride, const int* __restrict__ ns, const float* __restrict__ scale,
+                                                               float* __restrict__ grad, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int st = stride[i], cnt = ns[i];
+    const float* p = arena + src[i];
+    float acc = 0.0f;
+    int s = 0;
+    for (; s + 4 <= cnt; s += 4) {  // four partials in flight, added in slice order (deterministic; the same order as sr_tr_finalize)
+        const float v0 = p[(long long)s * st], v1 = p[(long long)(s + 1) * st], v2 = p[(long long)(s + 2) * st], v3 = p[(long long)(s + 3) * st];
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+    }
+    for (; s < cnt; ++s) acc += p[(long long)s * st];
+    grad[dst[i]] = acc * scale[i];
+}
+
 // ----------------------------------------------------------------------------- wgrad
 constexpr int WG_TN = 64, WG_TK = 64, WG_STEP = 32;
 constexpr int WG_LD = 160;                       // bytes per LDS tile row (64 bf16 + 32 B): see the header comment
@@ -407,6 +431,15 @@ extern "C" int sr_tr_finalize(const float* arena, const long long* src, const in
     if (n == 0) return SR_OK;
     hipLaunchKernelGGL(sr_tr_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), arena, src, stride, ns, scale, grad, n);
     SR_CHECK_LAUNCH("sr_tr_finalize");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_finalize_to(const float* arena, const long long* src, const int* dst, const int* stride, const int* ns, const float* scale, float* grad, long long n,
+                                 void* stream) {
+    SR_REQUIRE(arena && src && dst && stride && ns && scale && grad && n >= 0, "sr_tr_finalize_to: bad arguments");
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(sr_tr_finalize_to_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), arena, src, dst, stride, ns, scale, grad, n);
+    SR_CHECK_LAUNCH("sr_tr_finalize_to");
     return SR_OK;
 }
 

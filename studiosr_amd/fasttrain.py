@@ -222,16 +222,25 @@ class FinalMap:
         self.scale[i] = np.asarray(scale, dtype=np.float32).reshape(-1) if np.ndim(scale) else scale
 
     def finish(self, device) -> None:
-        self.d_src = torch.from_numpy(self.src).to(device)
-        self.d_stride = torch.from_numpy(self.stride).to(device)
-        self.d_ns = torch.from_numpy(self.ns).to(device)
-        self.d_scale = torch.from_numpy(self.scale).to(device)
+        # Work items in ARENA order (sr_tr_finalize_to, ABI v9): sorted by src, so that adjacent lanes read adjacent partials also for 3x3 conv weights (their nine
+        # taps are adjacent parameters but a whole [Np][Kp] plane apart in the packed gradient).  src -1 (no source: the gradient is zero) becomes an item
+        # with no slices; src -2 (the element belongs to another map) is no item at all.
+        idx = np.nonzero(self.src != -2)[0]
+        idx = idx[np.argsort(self.src[idx], kind="stable")]
+        src, ns = self.src[idx].copy(), self.ns[idx].copy()
+        ns[src < 0] = 0
+        src[src < 0] = 0
+        self.n_items = int(idx.size)
+        self.d_src = torch.from_numpy(src).to(device)
+        self.d_dst = torch.from_numpy(idx.astype(np.int32)).to(device)
+        self.d_stride = torch.from_numpy(self.stride[idx].copy()).to(device)
+        self.d_ns = torch.from_numpy(ns).to(device)
+        self.d_scale = torch.from_numpy(self.scale[idx].copy()).to(device)
         self.part = torch.zeros(max(self.size, 64), dtype=torch.float32, device=device)
 
     def run(self, G: Tensor) -> None:
-        n = self.p1 - self.p0
-        L.check(L.lib().sr_tr_finalize(self.part.data_ptr(), self.d_src.data_ptr(), self.d_stride.data_ptr(), self.d_ns.data_ptr(), self.d_scale.data_ptr(),
-                                       G.data_ptr() + 4 * self.p0, n, _st()), "sr_tr_finalize")
+        L.check(L.lib().sr_tr_finalize_to(self.part.data_ptr(), self.d_src.data_ptr(), self.d_dst.data_ptr(), self.d_stride.data_ptr(), self.d_ns.data_ptr(),
+                                          self.d_scale.data_ptr(), G.data_ptr() + 4 * self.p0, self.n_items, _st()), "sr_tr_finalize_to")
 
 
 # --------------------------------------------------------------------------- index-form packers (cf. studiosr_amd/packing.py)
