@@ -11,6 +11,7 @@
 #include "sr_common.h"
 #include "sr_host.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -95,7 +96,9 @@ struct WgradJobs {
     SrTrWgradJob j[WG_MAXJOBS];
     int wg0[WG_MAXJOBS + 1];  // first workgroup of each job
     int tiles_n[WG_MAXJOBS], tiles_k[WG_MAXJOBS];
+    int nwg[WG_MAXJOBS];      // workgroups of each job (its range of block ids is padded to a multiple of 8 when xcd is set)
     int n;
+    int xcd;                  // XCD-aware order of a job's workgroups (see the kernel)
 };
 
 // 8 bytes of a transposed fragment: for 16-lane group g, block rows r0 .. r0+3, columns c0 .. c0+15 of a row-major bf16 tile -> lane i gets column c0 + i
@@ -237,6 +240,14 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
         if (i < J.n && (int)blockIdx.x >= J.wg0[i]) jb = i;
     const SrTrWgradJob& j = J.j[jb];
     int rem = blockIdx.x - J.wg0[jb];
+    if (J.xcd) {
+        // Blocks whose ids agree mod 8 share an XCD (= an L2).  A job's work items are ordered tile-fastest, token slice slowest, and all tiles of a slice read
+        // the same operand rows: give each of the eight residue classes a CONTIGUOUS eighth of the items (= its own slices), so that a slice's rows enter one L2
+        // instead of all eight.  The job's id range is a multiple of 8 long (launcher); ids beyond its items do nothing.
+        const int per = (J.wg0[jb + 1] - J.wg0[jb]) >> 3;
+        rem = (rem & 7) * per + (rem >> 3);
+        if (rem >= J.nwg[jb]) return;
+    }
     if (j.halo) {  // (job-uniform branch)
         wgrad_conv_halo(j, rem, J.tiles_n[jb], J.tiles_k[jb], smem);
         return;
@@ -449,6 +460,8 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
     SR_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAXJOBS, "sr_tr_wgrad: 1..%d jobs per launch", WG_MAXJOBS);
     WgradJobs J;
     J.n = njobs;
+    static const int xcd = getenv("SR_WG_XCD") ? atoi(getenv("SR_WG_XCD")) : 1;  // A/B knob: 0 = block ids in item order
+    J.xcd = xcd;
     int wg = 0;
     for (int i = 0; i < njobs; ++i) {
         const SrTrWgradJob& j = jobs[i];
@@ -464,17 +477,19 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
         if (j.halo) {
             J.tiles_n[i] = (j.Np + 31) / 32;
             J.tiles_k[i] = (j.Kp + 63) / 64;
-            wg += J.tiles_n[i] * J.tiles_k[i] * j.ks;
+            J.nwg[i] = J.tiles_n[i] * J.tiles_k[i] * j.ks;
         } else {
             J.tiles_n[i] = (j.Np + WG_TN - 1) / WG_TN;
             J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
-            wg += J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
+            J.nwg[i] = J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
         }
+        wg += J.xcd ? (J.nwg[i] + 7) & ~7 : J.nwg[i];
     }
     J.wg0[njobs] = wg;
     for (int i = njobs; i < WG_MAXJOBS; ++i) {
         J.j[i] = J.j[0];
         J.tiles_n[i] = J.tiles_k[i] = 1;
+        J.nwg[i] = 0;
         J.wg0[i + 1 <= WG_MAXJOBS ? i + 1 : i] = wg;
     }
     hipLaunchKernelGGL(sr_tr_wgrad_kernel, dim3(wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), J);
