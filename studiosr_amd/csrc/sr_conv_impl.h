@@ -56,7 +56,7 @@ struct EpiGeo {
 };
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
-__global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
+__global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c, int xcd_order) {
     static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
     constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
     // row stride of the K-group-major image in cells: ROWS + 1, so that the staging writes of ONE pixel's 8 K-groups (8 adjacent lanes,
@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c) {
     const int tiles_x = (c.W + 15) >> 4;
     const int tiles_y = (c.H + TH - 1) / TH;
     int t = blockIdx.x;
+    if (xcd_order) {  // neighbouring tiles (shared halo rows) on one XCD: each residue class mod 8 of the block ids takes a contiguous range of tiles (see sr_conv_big.hip)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = t & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    }
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -427,7 +431,9 @@ int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
     }
     const int tiles = ((c.W + 15) / 16) * ((c.H + TH - 1) / TH) * c.B;
     dim3 grid(tiles, c.Cout_p / (WN * NW * 16));
-    hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>), grid, dim3(256), lds, st, c);
+    static const int xcd_env = getenv("SR_CONV_XCD") ? atoi(getenv("SR_CONV_XCD")) : 1;  // A/B knob: 0 = tiles in block-id order
+    const int xcd_order = (xcd_env && tiles >= 64 && (grid.y == 1 || (tiles & 7) == 0)) ? 1 : 0;  // (the residue class of a block id is that of blockIdx.x)
+    hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>), grid, dim3(256), lds, st, c, xcd_order);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
 }
