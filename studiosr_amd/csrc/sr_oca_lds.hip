@@ -14,6 +14,9 @@
 #include "sr_host.h"
 #include <cstdlib>
 
+#ifndef SR_OCA_XCD
+#define SR_OCA_XCD 1  // HAT x4 b4 2.41 -> 2.36 ms (0: (window, head) items in block-id order)
+#endif
 namespace {
 
 constexpr int OL_NK = 576, OL_KT = 36, OL_KB = 9, OL_REL = 1521;
@@ -81,7 +84,13 @@ __global__ __launch_bounds__(256, 2) void sr_oca_lds_kernel(OcaLdsArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
+#if SR_OCA_XCD
+    {   // neighbouring windows of one head (their 24 x 24-key neighbourhoods overlap 2.25 x) on one XCD
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = block & 7;
+        block = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (block >> 3);
+    }
+#endif
     const int bwin = block % a.n_bwin, head = block / a.n_bwin;
     const Src src(a, bwin, head);
     const Frag<bf16>* Kl = reinterpret_cast<const Frag<bf16>*>(smem + OL_OFF_K);
