@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void sr_tr_finalize_to_kernel(const float* __r
 // ----------------------------------------------------------------------------- wgrad
 constexpr int WG_TN = 64, WG_TK = 64, WG_STEP = 32;
 constexpr int WG_LD = 160;                       // bytes per LDS tile row (64 bf16 + 32 B): see the header comment
-constexpr int WG_TILE = WG_STEP * WG_LD;         // one operand tile
+constexpr int WG_SUB = 2;                        // 32-token sub-steps per barrier interval (generic path): the stash -> barrier -> transposed reads -> MFMA chain of a step
+                                                 // was ~650 cycles for 4 MFMAs per wave; two sub-steps share one barrier
+constexpr int WG_TILE = WG_SUB * WG_STEP * WG_LD;  // one operand tile (all sub-steps)
 constexpr int WG_MAXJOBS = 8;
 
 struct WgradJobs {
@@ -305,10 +307,6 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
             }
         }
     };
-    auto stash = [&](int buf, const bf16x8& ra, const bf16x8& rb) {
-        *reinterpret_cast<bf16x8*>(smem + (2 * buf) * WG_TILE + srow * WG_LD + spc * 16) = ra;
-        *reinterpret_cast<bf16x8*>(smem + (2 * buf + 1) * WG_TILE + srow * WG_LD + spc * 16) = rb;
-    };
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -316,33 +314,52 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4)(0.0f);
 
-    // the launch is a chain of dependent steps per workgroup (global -> registers -> LDS -> MFMA): operands travel TWO steps ahead in registers
-    bf16x8 ra1, rb1, ra2, rb2;
-    fetch(t_beg, ra1, rb1);
-    stash(0, ra1, rb1);
-    fetch(t_beg + WG_STEP, ra1, rb1);
+    // the launch is a chain of dependent steps per workgroup (global -> registers -> LDS -> MFMA): operands travel TWO steps ahead in registers; a step is
+    // WG_SUB sub-steps of 32 tokens (the accumulation order over the tokens is unchanged)
+    constexpr int STEP = WG_SUB * WG_STEP;
+    bf16x8 ra1[WG_SUB], rb1[WG_SUB], ra2[WG_SUB], rb2[WG_SUB];
+    auto fetch_all = [&](int t0, bf16x8 (&ra)[WG_SUB], bf16x8 (&rb)[WG_SUB]) {
+#pragma unroll
+        for (int u = 0; u < WG_SUB; ++u) fetch(t0 + u * WG_STEP, ra[u], rb[u]);
+    };
+    auto stash_all = [&](int buf, const bf16x8 (&ra)[WG_SUB], const bf16x8 (&rb)[WG_SUB]) {
+#pragma unroll
+        for (int u = 0; u < WG_SUB; ++u) {
+            *reinterpret_cast<bf16x8*>(smem + (2 * buf) * WG_TILE + (u * WG_STEP + srow) * WG_LD + spc * 16) = ra[u];
+            *reinterpret_cast<bf16x8*>(smem + (2 * buf + 1) * WG_TILE + (u * WG_STEP + srow) * WG_LD + spc * 16) = rb[u];
+        }
+    };
+    fetch_all(t_beg, ra1, rb1);
+    stash_all(0, ra1, rb1);
+    fetch_all(t_beg + STEP, ra1, rb1);
     __syncthreads();
     int buf = 0;
-    for (int t0 = t_beg; t0 < t_end; t0 += WG_STEP) {
-        const bool more = t0 + WG_STEP < t_end;
-        if (t0 + 2 * WG_STEP < t_end) fetch(t0 + 2 * WG_STEP, ra2, rb2);
-        const char* ta = smem + (2 * buf) * WG_TILE;
-        const char* tb = ta + WG_TILE;
-        Frag<bf16> xa[2], yb[2];
+    for (int t0 = t_beg; t0 < t_end; t0 += STEP) {
+        const bool more = t0 + STEP < t_end;
+        if (t0 + 2 * STEP < t_end) fetch_all(t0 + 2 * STEP, ra2, rb2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const s16x4 a0 = tr_read(ta, 4 * lg, wn * 32 + 16 * i, lane), a1 = tr_read(ta, 16 + 4 * lg, wn * 32 + 16 * i, lane);
-            const s16x4 b0 = tr_read(tb, 4 * lg, wk * 32 + 16 * i, lane), b1 = tr_read(tb, 16 + 4 * lg, wk * 32 + 16 * i, lane);
-            xa[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-            yb[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int u = 0; u < WG_SUB; ++u) {
+            const char* ta = smem + (2 * buf) * WG_TILE + u * WG_STEP * WG_LD;
+            const char* tb = ta + WG_TILE;
+            Frag<bf16> xa[2], yb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 a0 = tr_read(ta, 4 * lg, wn * 32 + 16 * i, lane), a1 = tr_read(ta, 16 + 4 * lg, wn * 32 + 16 * i, lane);
+                const s16x4 b0 = tr_read(tb, 4 * lg, wk * 32 + 16 * i, lane), b1 = tr_read(tb, 16 + 4 * lg, wk * 32 + 16 * i, lane);
+                xa[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                yb[i].v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) mma(xa[a], yb[b], acc[a][b]);
         }
+        if (more) stash_all(buf ^ 1, ra1, rb1);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) mma(xa[a], yb[b], acc[a][b]);
-        if (more) stash(buf ^ 1, ra1, rb1);
-        ra1 = ra2;
-        rb1 = rb2;
+        for (int u = 0; u < WG_SUB; ++u) {
+            ra1[u] = ra2[u];
+            rb1[u] = rb2[u];
+        }
         __syncthreads();
         buf ^= 1;
     }
