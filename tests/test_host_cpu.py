@@ -358,3 +358,62 @@ def test_export_routes_to_a_reference_loadable_checkpoint(tmp_path):
     m2 = S.EDSR(**{k: v for k, v in blob["config"].items() if k in ("scale", "n_feats", "n_resblocks", "n_colors", "res_scale", "img_range")})
     m2.load_state_dict(blob["state_dict"])
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_finalize_items_in_arena_order_are_the_same_sums():
+    """fasttrain.FinalMap.finish() turns the per-parameter maps (grad[p] = scale[p] * sum_s part[src[p] + s * stride[p]]) into work items sorted by src with a
+    destination index (sr_tr_finalize_to, ABI v9): emulate both forms on random partials -- every parameter is written once, with the same sum in the same order;
+    parameters without a source get a zero, parameters of another map are not touched."""
+    from studiosr_amd import fasttrain as FT
+
+    rng = np.random.default_rng(0)
+    fm = FT.FinalMap.__new__(FT.FinalMap)
+    n = 500
+    fm.p0, fm.p1 = 40, 40 + n
+    fm.src = np.full(n, -1, dtype=np.int64)
+    fm.stride = np.zeros(n, dtype=np.int32)
+    fm.ns = np.ones(n, dtype=np.int32)
+    fm.scale = np.ones(n, dtype=np.float32)
+    fm.size = 0
+    a = fm.alloc(9 * 20 * 3)  # a "conv" job: 3 slices of [9 taps][20]; parameters (c, tap) -> tap-major packed order
+    pidx = 40 + np.arange(180)
+    fm.put(pidx, a + (np.arange(180) % 9) * 20 + np.arange(180) // 9, 180, 3, scale=0.5)
+    b = fm.alloc(100 * 4)     # a "linear" job: 4 slices of 100
+    fm.put(40 + 200 + np.arange(100), b + np.arange(100), 100, 4)
+    fm.src[350:360] = -2      # another map's elements
+    fm.finish("cpu")
+    part = rng.standard_normal(fm.size).astype(np.float32)
+    want = np.full(n, np.nan, dtype=np.float32)
+    for p in range(n):
+        if fm.src[p] == -2:
+            continue
+        acc = np.float32(0)
+        if fm.src[p] >= 0:
+            for s in range(fm.ns[p]):
+                acc = np.float32(acc + part[fm.src[p] + s * fm.stride[p]])
+        want[p] = acc * fm.scale[p]
+    got = np.full(n, np.nan, dtype=np.float32)
+    src, dst, st, ns, sc = (t.numpy() for t in (fm.d_src, fm.d_dst, fm.d_stride, fm.d_ns, fm.d_scale))
+    assert fm.n_items == n - 10 and np.all(np.diff(src) >= 0) and len(set(dst.tolist())) == fm.n_items
+    for i in range(fm.n_items):
+        acc = np.float32(0)
+        for s in range(ns[i]):
+            acc = np.float32(acc + part[src[i] + s * st[i]])
+        got[dst[i]] = acc * sc[i]
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    assert np.all(got[180:200] == 0) and np.isnan(got[350:360]).all()
+
+
+def test_xcd_remap_is_a_bijection_with_contiguous_classes():
+    """The block-id remap of the XCD-aware kernels (sr_conv3x3, sr_conv_big, sr_rcab, sr_oca_lds, the CAB tiles of sr_hab_mid; cdna guide T1, bijective form): every
+    work item exactly once, and the block ids of one residue class mod 8 (= the blocks that share an XCD) take a contiguous range of items."""
+    def remap(t, nwg):
+        q, r, xcd = nwg >> 3, nwg & 7, t & 7
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (t >> 3)
+
+    for nwg in (1, 7, 8, 9, 55, 220, 240, 648, 1000, 1296):
+        items = [remap(t, nwg) for t in range(nwg)]
+        assert sorted(items) == list(range(nwg))
+        for c in range(min(8, nwg)):
+            mine = [items[t] for t in range(c, nwg, 8)]
+            assert mine == list(range(mine[0], mine[0] + len(mine)))
