@@ -320,9 +320,12 @@ typedef struct SrCab {
     int dtype;            /* SR_BF16 */
     void* mid_pre;        /* optional side output (ABI v8; training): conv1(x) + b1 BEFORE the GELU, NHWC [B,H,W,Cmid_p] bf16 -- what the backward needs for GELU' and for conv2's
                            * weight gradient, so that it does not run conv1 again (trainer.py:104 loss.backward() through hat.py:41-49) */
+    int tile_rows;        /* (ABI v9) output rows per workgroup tile (14 columns): 0 or 6, or 8 in sr_hab_mid (large launches: fewer workgroups, less halo recomputation);
+                           * pool_partial then has sr_cab_pool_tiles_rows(H, W, tile_rows) slots per image */
 } SrCab;
 int sr_cab_supported(int Cin_p, int Cmid_p, int Cout_p, int dtype);
 int sr_cab_pool_tiles(int H, int W);
+int sr_cab_pool_tiles_rows(int H, int W, int tile_rows);
 int sr_cab_fused(const SrCab* a, void* stream);
 
 typedef struct SrWindowAttn {

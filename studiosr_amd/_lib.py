@@ -71,7 +71,7 @@ class SrCab(C.Structure):  # (mid_pre: ABI v8)
     _fields_ = [
         ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cmid_p", _i), ("Cout_p", _i), ("dtype", _i),
-        ("mid_pre", _vp),
+        ("mid_pre", _vp), ("tile_rows", _i),
     ]
 
 
@@ -249,6 +249,7 @@ SYMBOLS = {
     "sr_swin_light": (_i, [C.POINTER(SrSwinLight), _vp]),
     "sr_cab_supported": (_i, [_i, _i, _i, _i]),
     "sr_cab_pool_tiles": (_i, [_i, _i]),
+    "sr_cab_pool_tiles_rows": (_i, [_i, _i, _i]),
     "sr_cab_fused": (_i, [C.POINTER(SrCab), _vp]),
     "sr_swin_qkv_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sr_swin_qkv": (_i, [C.POINTER(SrSwinQkv), _vp]),

@@ -28,6 +28,7 @@ extern "C" int sr_cab_supported(int Cin_p, int Cmid_p, int Cout_p, int dtype) { 
 extern "C" int sr_cab_fused(const SrCab* p, void* stream) {
     if (const int rc = cab_check(p, "sr_cab_fused")) return rc;
     const SrCab& c = *p;
+    SR_REQUIRE(c.tile_rows == 0 || c.tile_rows == TOH, "sr_cab_fused: %d-row tiles only (SrCab.tile_rows = 8 exists in sr_hab_mid)", TOH);
     static SrDeviceOnce attr_once;
     {
         const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_cab_kernel, LDS_BYTES); });

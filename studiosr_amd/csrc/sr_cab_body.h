@@ -1,10 +1,15 @@
 // Body of sr_cab_kernel (sr_cab.hip: HAT's CAB convs in one launch) as a device function, shared with sr_hab_mid.hip (the CAB and the window attention of
 // a HAB as ONE launch).  SR_CAB_PH (K phases of conv1: 1 = 88 KiB of LDS, 2 = 52 KiB) is fixed per translation unit before this header is included.
-#pragma once
+// The header can be included MORE THAN ONCE per translation unit with different SR_CAB_TOH (tile heights) inside different namespaces: the includer defines
+// SR_CAB_NS_BEGIN / SR_CAB_NS_END (default: the anonymous namespace) and SR_CAB_TOH before each inclusion (sr_hab_mid.hip: 6 rows for small launches, 8 for large).
 #include "sr_common.h"
 #include "sr_host.h"
 
-namespace {
+#ifndef SR_CAB_NS_BEGIN
+#define SR_CAB_NS_BEGIN namespace {
+#define SR_CAB_NS_END }
+#endif
+SR_CAB_NS_BEGIN
 
 constexpr int CI = 192, CM = 64, CO = 192;
 constexpr int KG_IN = CI / 8, KC_IN = CI / 32, KCT1 = 9 * KC_IN;   // 24 K-groups, 6 chunks per tap, 54 steps
@@ -264,4 +269,4 @@ static inline int cab_check(const SrCab* p, const char* who) {
     return SR_OK;
 }
 
-}  // namespace
+SR_CAB_NS_END

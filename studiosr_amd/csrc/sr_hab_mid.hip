@@ -10,7 +10,17 @@
 // workgroups per CU -- the attention role's 221 VGPRs -- must fit); its conv1 therefore sums K phase-major (same products, another fp32 order).
 // With SrWindowAttn.bias_tiles the attention role is the LDS form (sr_wattn_lds_body.h: one (window, head) per workgroup, K / V^T / the 31 distinct bias
 // tiles staged once; 63 KiB of LDS).
+// Two tile heights of the CAB role (SrCab.tile_rows): 14 x 6 outputs per workgroup (small launches: more, shorter latency chains) and 14 x 8 (from 4 x 64 x 64 pixels
+// on: a quarter fewer workgroups, 18 % less halo recomputation -- HAT x4 b16 6.52 -> 6.28 ms, 64 tiles 27.7 -> 26.7; a single tile 1.64 -> 1.74 the other way)
 #define SR_CAB_PH 2
+#define SR_CAB_NS_BEGIN namespace { namespace cab6 {
+#define SR_CAB_NS_END } }
+#define SR_CAB_TOH 6
+#include "sr_cab_body.h"
+#undef SR_CAB_NS_BEGIN
+#undef SR_CAB_TOH
+#define SR_CAB_NS_BEGIN namespace { namespace cab8 {
+#define SR_CAB_TOH 8
 #include "sr_cab_body.h"
 #include "sr_wattn_lds_body.h"
 #include "sr_wattn_qkv_body.h"
@@ -20,6 +30,7 @@
 #endif
 namespace {
 
+// MODE bit 4: the CAB role's tiles are 8 rows high (cab8) instead of 6
 // MODE bit 0: q / k / v^T in fragment order (SrWindowAttn.qkv_frag); bit 1: the LDS form of the attention (SrWindowAttn.bias_tiles: one (window, head) per
 // workgroup, sr_wattn_lds_body.h) instead of the register-only flash form (four (window, head, 32 queries) items per workgroup)
 template <int MODE>
@@ -27,12 +38,15 @@ __global__ __launch_bounds__(256, 2) void sr_hab_mid_kernel(SrWindowAttn a, SrCa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int block = __builtin_amdgcn_readfirstlane(blockIdx.x);
     if (block < n_cab) {
+        int tile = block;
 #if SR_MID_XCD
         const int q = n_cab >> 3, r = n_cab & 7, xcd = block & 7;  // neighbouring CAB tiles (18 x 10-pixel halos of 14 x 6 tiles) on one XCD
-        cab_block(c, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (block >> 3), smem);
-#else
-        cab_block(c, block, smem);
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (block >> 3);
 #endif
+        if constexpr ((MODE & 16) != 0)
+            cab8::cab_block(c, tile, smem);
+        else
+            cab6::cab_block(c, tile, smem);
     }
     else if constexpr ((MODE & 4) != 0)
         wattn_qkv_block(a, block - n_cab, smem);  // LayerNorm1 + the head's QKV projection + attention (SrWindowAttn.x)
@@ -45,7 +59,12 @@ __global__ __launch_bounds__(256, 2) void sr_hab_mid_kernel(SrWindowAttn a, SrCa
 }  // namespace
 
 extern "C" int sr_hab_mid_supported(int ntok, int hd_p, int ws, int attn_dtype, int Cin_p, int Cmid_p, int Cout_p, int cab_dtype) {
-    return (ntok == 256 && hd_p == 32 && ws == 16 && attn_dtype == SR_BF16 && Cin_p == CI && Cmid_p == CM && Cout_p == CO && cab_dtype == SR_BF16) ? 1 : 0;
+    return (ntok == 256 && hd_p == 32 && ws == 16 && attn_dtype == SR_BF16 && Cin_p == cab6::CI && Cmid_p == cab6::CM && Cout_p == cab6::CO && cab_dtype == SR_BF16) ? 1 : 0;
+}
+
+extern "C" int sr_cab_pool_tiles_rows(int H, int W, int tile_rows) {  // pool slots per image of the CAB role for SrCab.tile_rows (0 / 6 / 8)
+    const int th = tile_rows == 8 ? cab8::TOH : cab6::TOH;
+    return ((W + cab6::TOW - 1) / cab6::TOW) * ((H + th - 1) / th);
 }
 
 extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream) {
@@ -53,7 +72,9 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
     SR_REQUIRE(!pa->x || (pa->wqkv && pa->bias && pa->bias_tiles && pa->heads == 6 && pa->C == 180 && pa->ldx >= 192 && pa->ldx % 4 == 0 &&
                           ((reinterpret_cast<uintptr_t>(pa->x) | reinterpret_cast<uintptr_t>(pa->wqkv)) & 15) == 0),
                "sr_hab_mid: the fused QKV form needs x, wqkv, bias, bias_tiles, 6 heads, C = 180 in >= 192 padded channels, 16-byte aligned rows");
-    if (const int rc = cab_check(pc, "sr_hab_mid")) return rc;
+    SR_REQUIRE(pc && (pc->tile_rows == 0 || pc->tile_rows == 6 || pc->tile_rows == 8), "sr_hab_mid: SrCab.tile_rows is 0 (= 6), 6 or 8");
+    const bool t8 = pc->tile_rows == 8;
+    if (const int rc = t8 ? cab8::cab_check(pc, "sr_hab_mid") : cab6::cab_check(pc, "sr_hab_mid")) return rc;
     const SrWindowAttn& a = *pa;
     const SrCab& c = *pc;
     SR_REQUIRE(sr_hab_mid_supported(a.ntok, a.hd_p, a.ws, a.dtype, c.Cin_p, c.Cmid_p, c.Cout_p, c.dtype), "sr_hab_mid: unsupported geometry (16 x 16 windows, head_dim <= 32, bf16)");
@@ -61,13 +82,14 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
     SR_REQUIRE(a.n_bwin > 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0, "sr_hab_mid: n_bwin");
     SR_REQUIRE(!a.bias_tiles || a.x || ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.bias_tiles)) & 15) == 0,
                "sr_hab_mid: the LDS form of the attention stages 16-byte pieces (q, k, vt, bias_tiles must be 16-byte aligned)");
-    const long n_cab = (long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B;
+    const long n_cab = (long)(((c.W + cab6::TOW - 1) / cab6::TOW) * ((c.H + (t8 ? cab8::TOH : cab6::TOH) - 1) / (t8 ? cab8::TOH : cab6::TOH))) * c.B;
     const bool lds_form = a.bias_tiles != nullptr;
+    SR_REQUIRE(!t8 || (lds_form && !a.x), "sr_hab_mid: 8-row CAB tiles exist beside the LDS form of the attention only (bias_tiles set, no x)");
     const long items = (long)a.n_bwin * a.heads * 8;  // flash form: (window, head, block of 32 queries), four per workgroup
     const long blocks = n_cab + (lds_form ? (long)a.n_bwin * a.heads : (items + 3) / 4);
     SR_REQUIRE(blocks < (1l << 31), "sr_hab_mid: too many workgroups");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static SrDeviceOnce once[5];
+    static SrDeviceOnce once[7];
     auto launch = [&](auto kernel, SrDeviceOnce& o, int lds) -> int {
         const hipError_t e = sr_once_per_device(o, [&] { return sr_allow_lds(kernel, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_hab_mid: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -75,10 +97,13 @@ extern "C" int sr_hab_mid(const SrWindowAttn* pa, const SrCab* pc, void* stream)
         SR_CHECK_LAUNCH("sr_hab_mid");
         return SR_OK;
     };
-    constexpr int LDS_BOTH = LDS_BYTES > WL_LDS ? LDS_BYTES : WL_LDS;
-    constexpr int LDS_QKV = LDS_BYTES > WQ_LDS ? LDS_BYTES : WQ_LDS;
-    static_assert(2 * LDS_BOTH <= 160 * 1024 && 2 * LDS_QKV <= 160 * 1024, "two workgroups per CU");
+    constexpr int LDS6 = cab6::LDS_BYTES, LDS8 = cab8::LDS_BYTES;
+    constexpr int LDS_BOTH = LDS6 > WL_LDS ? LDS6 : WL_LDS;
+    constexpr int LDS_BOTH8 = LDS8 > WL_LDS ? LDS8 : WL_LDS;
+    constexpr int LDS_QKV = LDS6 > WQ_LDS ? LDS6 : WQ_LDS;
+    static_assert(2 * LDS_BOTH <= 160 * 1024 && 2 * LDS_BOTH8 <= 160 * 1024 && 2 * LDS_QKV <= 160 * 1024, "two workgroups per CU");
     if (a.x) return launch(sr_hab_mid_kernel<4>, once[4], LDS_QKV);
+    if (t8) return a.qkv_frag ? launch(sr_hab_mid_kernel<19>, once[6], LDS_BOTH8) : launch(sr_hab_mid_kernel<18>, once[5], LDS_BOTH8);
     if (lds_form) return a.qkv_frag ? launch(sr_hab_mid_kernel<3>, once[3], LDS_BOTH) : launch(sr_hab_mid_kernel<2>, once[2], LDS_BOTH);
-    return a.qkv_frag ? launch(sr_hab_mid_kernel<1>, once[1], LDS_BYTES) : launch(sr_hab_mid_kernel<0>, once[0], LDS_BYTES);
+    return a.qkv_frag ? launch(sr_hab_mid_kernel<1>, once[1], LDS6) : launch(sr_hab_mid_kernel<0>, once[0], LDS6);
 }

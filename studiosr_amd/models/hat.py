@@ -300,8 +300,6 @@ class HAT(Model):
         th = 4 if (cdt == torch.bfloat16 and ((W + 15) // 16) * ((H + 7) // 8) * B < 256) else 0
         # conv -> GELU -> conv as ONE launch (sr_cab_fused; SR_CAB_FUSED=0: two sr_conv3x3 launches)
         cab_fused = cdt == torch.bfloat16 and knob("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, L.SR_BF16)
-        n_tiles = ops.cab_pool_tiles(H, W) if cab_fused else ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th)
-        pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
         # tile sizes of this model every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention
         # branch and joins before the projection GEMM -- the first writer of t (which may be t_in) and the consumer of the conv branch.
@@ -330,6 +328,12 @@ class HAT(Model):
                        and (knob("SR_ATTN_QKV", "auto") == "1" or (knob("SR_ATTN_QKV", "auto") == "auto" and (getattr(self, "_total_B", B) * H * W // geo.ntok) * geo.heads <= 128)))
         if qkv_in_attn:
             fuse_next_qkv = False
+        # CAB tiles of 14 x 8 outputs instead of 14 x 6 in sr_hab_mid from 4 x 64 x 64 pixels on (SrCab.tile_rows, ABI v9; SR_CAB_ROWS8_FROM pixels): b16 6.52 -> 6.28 ms,
+        # 64 tiles 27.7 -> 26.7, b4 2.44 -> 2.41; a single tile 1.64 -> 1.74 the other way (there the launch is one short chain per CU)
+        cab_rows = 8 if (mid_fused and not qkv_in_attn and "bias_tiles" in bp and knob("SR_ATTN_LDS", "1") != "0"
+                         and getattr(self, "_total_B", B) * H * W >= int(knob("SR_CAB_ROWS8_FROM", "16384"))) else 0
+        n_tiles = (ops.cab_pool_tiles_rows(H, W, cab_rows) if cab_fused else ops.conv_pool_tiles(H, W, Cp, sr_dtype(cdt), th))
+        pool = ws_.get("hab.pool", (B, n_tiles, Cp), f32)
         qkv_n1 = None
         if mid_fused:
             side = main
@@ -339,7 +343,7 @@ class HAT(Model):
                 else:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         cab_kw = dict(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(), b2=bp["cab2"][1].data_ptr(),
-                      y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=L.SR_BF16)
+                      y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=L.SR_BF16, tile_rows=cab_rows)
 
         def conv_branch():
             if mid_fused:

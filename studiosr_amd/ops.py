@@ -105,6 +105,11 @@ def cab_pool_tiles(H: int, W: int) -> int:
     return int(L.lib().sr_cab_pool_tiles(H, W))
 
 
+def cab_pool_tiles_rows(H: int, W: int, tile_rows: int) -> int:
+    """Pool slots per image of sr_hab_mid's CAB role for SrCab.tile_rows (0 / 6 / 8; ABI v9)."""
+    return int(L.lib().sr_cab_pool_tiles_rows(H, W, tile_rows))
+
+
 def cab_fused(**kw) -> None:
     """conv -> GELU -> conv of HAT's CAB in one launch, with the pool partials of the channel-attention squeeze (ABI v6; hat.py:41-49)."""
     a = L.SrCab()

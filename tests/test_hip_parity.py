@@ -1050,6 +1050,25 @@ def test_hat_forward_with_32_token_tail_workgroups_equals_the_64_token_form(monk
     assert torch.equal(new, old), float((new - old).abs().max())
 
 
+def test_hat_forward_with_8_row_cab_tiles_matches_the_6_row_form(monkeypatch):
+    """sr_hab_mid's CAB role with 14 x 8-output tiles (SrCab.tile_rows = 8: what launches from 4 x 64 x 64 pixels on take) against 14 x 6: the same convolutions per
+    pixel; the pool partials are sums over another tile partition, so the gate (and with it the output) agrees to fp32 rounding of a 180-term mean, not bit for bit.
+    Image heights that are and are not multiples of either tile height."""
+    torch.manual_seed(9)
+    m = _randomised(S.HAT(scale=2, depths=[2, 2], num_heads=[6, 6]), seed=17).to(DEV).eval().set_precision("bf16")
+    for shape in ((2, 3, 48, 32), (1, 3, 64, 64)):
+        x = torch.rand(*shape, device=DEV)
+        outs = []
+        for frm in ("0", "1000000000"):
+            monkeypatch.setenv("SR_CAB_ROWS8_FROM", frm)
+            with torch.no_grad():
+                outs.append(m(x).clone())
+        torch.cuda.synchronize()
+        new, old = outs
+        assert not torch.isnan(new).any()
+        assert float((new - old).abs().max()) <= 2e-3 * max(1.0, float(old.abs().max())), float((new - old).abs().max())
+
+
 def test_gated_second_residual_of_the_projection_gemm_equals_channel_attention():
     """HAT's combine x = shortcut + attn + conv_scale * CA(cab) (hat.py:192): sr_channel_gate + sr_gemm's gated second residual against the
     two-pass form (projection GEMM with the shortcut, then sr_channel_attention over the stream)."""
