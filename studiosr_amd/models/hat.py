@@ -476,8 +476,9 @@ class HAT(Model):
         # Inside a HIP-graph capture a large batch runs as two half batches on two streams (as SwinIR's SR_SWIN_PARTS / RCAN's quarter batches): every launch
         # of this model is one or two residency rounds of latency-chain workgroups, and two out-of-phase chains fill each other's rounds (HAT x4 b16 7.61 ->
         # 7.19 ms as two batches of 8 in flight; no gain at b4: 2.62 vs 2.56).  bf16 path only (one queue per half: the other precisions fork a side stream per block).
-        # (four quarter batches from 16 images on: b16 6.80 -> 6.64 ms, 64 tiles 27.9 -> 27.6; eight: no further gain)
-        parts = int(knob("SR_HAT_PARTS", "0")) or (4 if (B >= 16 and B % 4 == 0) else 2)
+        # Part batches of FOUR images (each part's launches are then the b4 sizes: 256 tail / 544 mid workgroups, out of phase on up to 16 streams): b16 in 4 parts 6.80 ->
+        # 6.64 ms; b32 in 4 / 8 / 16 parts 13.7 / 12.7 / 14.1 ms; 64 tiles in 4 / 8 / 16 parts 27.2 / 26.8 / 24.9 ms
+        parts = int(knob("SR_HAT_PARTS", "0")) or (min(16, B // 4) if (B >= 16 and B % 4 == 0 and B % min(16, B // 4) == 0) else 2)
         if parts > 1 and cdt == torch.bfloat16 and B >= 8 * parts // 2 and B % parts == 0 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
