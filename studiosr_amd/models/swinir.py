@@ -414,6 +414,8 @@ def direct_cps_p(c_ps: int, r: int) -> int:
 
 # --------------------------------------------------------------------------- the model
 class SwinIR(Model):
+    part_batches = 1  # inside a HIP-graph capture, run a batch as this many part batches on the model's own streams (latency of a lone batch; see forward)
+
     def __init__(
         self,
         scale: int = 4,
@@ -526,8 +528,9 @@ class SwinIR(Model):
         out = torch.empty(B, self.n_colors, H * s, W * s, dtype=torch.float32, device=x.device)
         # Inside a HIP-graph capture a batch can run as part batches on several streams: the parts' launches are out of phase, so one part's
         # x-fetch / store / convolution phases run under the other's MFMAs (what bench.py's two batches in flight do across steps).  Eager
-        # forwards stay one launch sequence (they are launch-bound).  SR_SWIN_PARTS: 1 = off (default), 2 = two half batches.
-        parts = int(os.environ.get("SR_SWIN_PARTS", "1"))
+        # forwards stay one launch sequence (they are launch-bound).  `part_batches` (attribute; SR_SWIN_PARTS overrides): 1 = off (default).  It is a LATENCY knob:
+        # one batch of 8 alone on the GPU 1.77 -> 1.70 (2 parts) / 1.65 ms (4); with a second batch in flight (bench.py's throughput leg) 1.44 -> 1.67 / 1.60 ms.
+        parts = int(os.environ.get("SR_SWIN_PARTS", "0")) or int(getattr(self, "part_batches", 1) or 1)
         if parts > 1 and B % parts == 0 and B // parts >= 2 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
