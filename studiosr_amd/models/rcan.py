@@ -174,7 +174,7 @@ class RCAN(Model):
             main = torch.cuda.current_stream(x.device)
             # parts (SR_RCAN_PARTS): b16 5.89 (2) / 5.70 (4) / 9.63 ms (8: the captured graph's cross-queue signalling takes over); b32 8.50 / 8.26 / 11.86
             # with the XCD-aware tile order of sr_rcab (round 4): parts of EIGHT images -- b16 4.86 (4 parts) -> 4.73 ms (2), b32 7.37 (2) / 7.26 (4)
-            parts = int(os.environ.get("SR_RCAN_PARTS", "0")) or max(2, B // 8)
+            parts = int(os.environ.get("SR_RCAN_PARTS", "0")) or min(4, max(2, B // 8))  # (b64: 4 parts 14.0 ms, 8 parts 14.4; b32: 4 parts 7.27, 8 parts 9.5)
             if parts < 2 or B % parts:
                 parts = 2
             h = B // parts
