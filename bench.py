@@ -545,6 +545,9 @@ def main() -> None:
     barrier()
     elapsed1 = time.perf_counter() - t0
     pipes[:] = pipes_all
+    if not args.no_graph:
+        model._ws = pipes_all[-1][2]  # time_dominant_kernel() below launches the block kernel on the stream tensors of a throughput pipeline's last forward (real
+        # activations -- a fresh, zero-filled workspace would be timed at another power level)
     if world > 1:
         t = torch.tensor([elapsed1], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
