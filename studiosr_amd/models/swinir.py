@@ -414,7 +414,7 @@ def direct_cps_p(c_ps: int, r: int) -> int:
 
 # --------------------------------------------------------------------------- the model
 class SwinIR(Model):
-    part_batches = 1  # inside a HIP-graph capture, run a batch as this many part batches on the model's own streams (latency of a lone batch; see forward)
+    part_batches = 0  # inside a HIP-graph capture, run a batch as this many part batches on the model's own streams (0: two from 16 tiles on; see forward)
 
     def __init__(
         self,
@@ -530,7 +530,8 @@ class SwinIR(Model):
         # x-fetch / store / convolution phases run under the other's MFMAs (what bench.py's two batches in flight do across steps).  Eager
         # forwards stay one launch sequence (they are launch-bound).  `part_batches` (attribute; SR_SWIN_PARTS overrides): 1 = off (default).  It is a LATENCY knob:
         # one batch of 8 alone on the GPU 1.77 -> 1.70 (2 parts) / 1.65 ms (4); with a second batch in flight (bench.py's throughput leg) 1.44 -> 1.67 / 1.60 ms.
-        parts = int(os.environ.get("SR_SWIN_PARTS", "0")) or int(getattr(self, "part_batches", 1) or 1)
+        # part_batches = 0 (default): two half batches from 16 tiles on (a lone batch: b16 3.30 -> 2.90 ms, b32 6.10 -> 5.66; lightweight geometry b32 1.85 -> 1.65)
+        parts = int(os.environ.get("SR_SWIN_PARTS", "0")) or int(getattr(self, "part_batches", 0) or 0) or (2 if B >= 16 else 1)
         if parts > 1 and B % parts == 0 and B // parts >= 2 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
