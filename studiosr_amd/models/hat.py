@@ -479,7 +479,7 @@ class HAT(Model):
         # Part batches of FOUR images (each part's launches are then the b4 sizes: 256 tail / 544 mid workgroups, out of phase on up to 16 streams): b16 in 4 parts 6.80 ->
         # 6.64 ms; b32 in 4 / 8 / 16 parts 13.7 / 12.7 / 14.1 ms; 64 tiles in 4 / 8 / 16 parts 27.2 / 26.8 / 24.9 ms
         parts = int(knob("SR_HAT_PARTS", "0")) or (min(16, B // 4) if (B >= 16 and B % 4 == 0 and B % min(16, B // 4) == 0) else 2)
-        if parts > 1 and cdt == torch.bfloat16 and B >= 8 * parts // 2 and B % parts == 0 and x.is_cuda and capturing_or_warming_up():
+        if parts > 1 and cdt == torch.bfloat16 and B >= int(knob("SR_HAT_PART_MIN", "4")) * parts and B % parts == 0 and x.is_cuda and capturing_or_warming_up():
             from ..runtime import WorkspaceView
 
             main = torch.cuda.current_stream(x.device)
