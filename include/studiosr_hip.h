@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 9
+#define SR_ABI_VERSION 10
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -93,34 +93,6 @@ typedef struct SrGemm {
     int skip2_dtype, ldskip2, gate_rows, ld_gate;
 } SrGemm;
 int sr_gemm(const SrGemm* a, void* stream);
-
-typedef struct SrSwinAttn {
-    /* out = x + proj(window_attention(qkv(LayerNorm1(x)))) in ONE kernel: swinir.py:146-171 (norm1, roll,
-     * window_partition, WindowAttention :78-105 incl. bias table + calculate_mask, window_reverse, roll back,
-     * shortcut add); hat.py:164-192 (attention branch).  One workgroup per window, one wave per head; q/k/v, the
-     * logits and the attention output stay in registers / LDS.  bf16 operands, fp32 stream; out may alias x. */
-    const float* x;       /* [B,H,W,ldx] fp32 stream */
-    float* out;
-    const void* wqkv;     /* packed [3*heads*hd_p x Cp] bf16: LayerNorm affine folded in, q rows pre-scaled */
-    const float* bqkv;    /* [3*heads*hd_p]; only the q third is read: the k bias cancels in the softmax and the v bias
-                           * must be folded into bproj (bproj' = bproj + Wproj b_v), see models/swinir.py pack_attention */
-    const void* wproj;    /* packed [Cp x heads*hd_p] bf16 */
-    const float* bproj;   /* [Cp] (with W_proj b_v folded in) */
-    const float* bias;    /* relative-position bias in fragment order [heads][qt][kt][lane][4] (packing.bias_fragments) */
-    int B, H, W, C, Cp, ldx, heads, hd_p, ws, shift;
-    float eps;
-    /* optional MLP tail: when w1p != NULL the kernel continues with out += fc2(GELU(fc1(LayerNorm2(out)))) on the same
-     * tokens (the WHOLE SwinTransformerBlock, swinir.py:146-174, in one launch; x1 never leaves the CU).  LayerNorm2's
-     * affine must be folded into w1p / b1. */
-    const void* w1p;      /* packed fc1 [Hp x Cp] bf16 or NULL */
-    const float* b1;      /* [Hp] */
-    const void* w2p;      /* packed fc2 [Cp x Hp] bf16 */
-    const float* b2;      /* [Cp] */
-    int Hp;               /* 384 */
-    int y_mode;           /* SR_Y_* */
-} SrSwinAttn;
-int sr_swin_attn_supported(int Cp, int heads, int hd_p, int ws, int compute_dtype);
-int sr_swin_attn_fused(const SrSwinAttn* a, void* stream);
 
 typedef struct SrSwinBlock {
     /* The WHOLE SwinTransformerBlock (swinir.py:146-174: norm1, roll, window_partition, WindowAttention :78-105 with bias table and

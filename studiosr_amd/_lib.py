@@ -24,7 +24,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -41,14 +41,6 @@ class SrGemm(C.Structure):
         ("epi", _i), ("heads", _i), ("hd_p", _i), ("ntok", _i),
         ("ln_eps", _f), ("ln_norm_only", _i), ("oca_pad", _i), ("y_mode", _i),
         ("skip2", _vp), ("skip2_gate", _vp), ("skip2_dtype", _i), ("ldskip2", _i), ("gate_rows", _i), ("ld_gate", _i),
-    ]
-
-
-class SrSwinAttn(C.Structure):
-    _fields_ = [
-        ("x", _vp), ("out", _vp), ("wqkv", _vp), ("bqkv", _vp), ("wproj", _vp), ("bproj", _vp), ("bias", _vp),
-        ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i),
-        ("eps", _f), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("Hp", _i), ("y_mode", _i),
     ]
 
 
@@ -241,8 +233,6 @@ SYMBOLS = {
     "sr_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sr_layernorm_to": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sr_gemm": (_i, [C.POINTER(SrGemm), _vp]),
-    "sr_swin_attn_supported": (_i, [_i, _i, _i, _i, _i]),
-    "sr_swin_attn_fused": (_i, [C.POINTER(SrSwinAttn), _vp]),
     "sr_swin_block_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_swin_block": (_i, [C.POINTER(SrSwinBlock), _vp]),
     "sr_swin_light_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),

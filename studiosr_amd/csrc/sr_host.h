@@ -63,11 +63,6 @@ bool sr_oca_attention_flash_supported(const SrOcaAttn& o);
 int sr_oca_attention_flash(const SrOcaAttn& o, hipStream_t st);
 
 
-// one-window-per-workgroup Swin block kernel (sr_swin_block.hip); SR_SWIN_BLOCK=v1 selects the round-1 kernel instead
-struct SrSwinAttn;
-bool sr_swin_block_v2_enabled();
-int sr_swin_block_v2(const SrSwinAttn& a, hipStream_t st);
-
 // LDS form of the overlapping cross attention (sr_oca_lds.hip): inference (zero-bordered k / v^T) and the training forward (unfolded k / v^T)
 struct SrTrAttnFwd;
 bool sr_oca_attention_lds_supported(const SrOcaAttn& o);

@@ -101,12 +101,19 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
         int x = wx * WS + (t & 7) + a.shift;
         if (y >= a.H) y -= a.H;
         if (x >= a.W) x -= a.W;
+#ifdef SR_EXP_XSMALL
+        return (((int)bimg * a.H + y) * a.W + x) & 4095;  // experiment: all I/O inside 3 MB (L2-resident): the I/O instructions without the HBM traffic
+#endif
         return ((int)bimg * a.H + y) * a.W + x;
     };
     const int hh = w >> 1, half = w & 1;  // GEMM role: d-half `half` of head 2p + hh; attention atom: queries [32 half, +32) of that head
 
     STAMP(0);
     WGTRACE(0);
+#ifdef SR_EXP_DEPHASE
+    // experiment: the second / third workgroup of a CU (dispatch order: blocks b, b + 256, b + 512 share a CU) starts its x fetch late
+    for (int i = 0, k = (blockIdx.x >> 8) % 3; i < k; ++i) __builtin_amdgcn_s_sleep(SR_EXP_DEPHASE);
+#endif
     // ---- x: 16 full token rows per wave by LDS-DMA (window gather = one scalar row address per piece), then the first weight slots
     {
         const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -126,7 +133,9 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
     for (int s0 = 0; s0 < WStream<T>::DIST; ++s0) ws.load(s0, lane);
     const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, 6 * 16 * 64 * 16, 0x00020000);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef SR_EXP_XNOWAIT
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WStream<T>::LOADS_PER_SLOT * WStream<T>::DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
+#endif
     BLOCK_SYNC();
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
 #pragma unroll

@@ -82,7 +82,7 @@ class FlatParams:
 
     def intact(self) -> bool:
         base = self.P.data_ptr()
-        return all(p.data_ptr() == base + 4 * self._off[id(p)] and p.device == self.P.device for p in self.params)
+        return all(id(p) in self._off and p.data_ptr() == base + 4 * self._off[id(p)] and p.device == self.P.device for p in self.params)
 
     def grad_view(self, p: Tensor, G: Optional[Tensor] = None) -> Tensor:
         o = self._off[id(p)]
@@ -913,7 +913,7 @@ class HatPlan:
     @staticmethod
     def supported(model) -> bool:
         try:
-            return (type(model).__name__ == "HAT" and model.embed_dim == C_REAL and model.window_size == 16 and all(h == HEADS for h in model.num_heads) and
+            return (type(model).__name__ == "HAT" and len(set(model.depths)) == 1 and model.embed_dim == C_REAL and model.window_size == 16 and all(h == HEADS for h in model.num_heads) and
                     int(model.embed_dim * model.mlp_ratio) == HID and int(model.window_size * model.overlap_ratio) == 8 and model.embed_dim // model.compress_ratio == 60 and model.embed_dim // model.squeeze_factor == CR and
                     next(model.parameters()).is_cuda)
         except Exception:
@@ -1068,12 +1068,12 @@ class HatPlan:
         self.fm.run(G)
 
     def pack(self) -> None:
-        """Packed operands <- current parameters (once per optimizer step: the parameter versions decide)."""
-        ver = tuple(p._version for p in self.fp.params)
-        if self.packed_version is None or ver != self.packed_version:
-            self.wa.gather(self.fp.P)
-            self.fa.gather(self.fp.P)
-            self.packed_version = ver
+        """Packed operands <- current parameters: two sr_tr_gather launches (~130 MB of traffic) on EVERY recorded forward.  (Until round 5 the
+        parameters' version counters decided; torch.optim.Adam(fused=True) updates parameters without bumping them, so the second step of such a run
+        trained on the first step's weights.  The launches cost less than reading 860 version counters on the host.)"""
+        self.wa.gather(self.fp.P)
+        self.fa.gather(self.fp.P)
+        self.packed_version = True
 
 
 def get_plan(model) -> Optional[HatPlan]:

@@ -69,11 +69,26 @@ class Model(nn.Module):
         self._ws = None
         return super()._apply(fn, *args, **kwargs)
 
+    def invalidate_packed(self) -> None:
+        """Drop every cache derived from the parameters (fragment-ordered weights of the inference path, the fused training plan's packed operands).
+        `_get_packed` notices ordinary in-place updates through the parameters' version counters; an update that does not bump them
+        (torch.optim.Adam(fused=True): torch._fused_adam_; raw kernels writing p.data) needs this call -- studiosr_amd.optim.Adam and train() / eval() make it."""
+        self._packed = {}
+        plan = self.__dict__.get("_fast_plan")
+        if plan is not None:
+            plan.packed_version = None
+
+    def train(self, mode: bool = True):
+        if mode != self.training:  # the Trainer's train -> evaluate -> train pattern (trainer.py:125-131): never evaluate on weights packed before the last steps
+            self.invalidate_packed()
+        return super().train(mode)
+
     def __getstate__(self):  # deepcopy / pickle: derived device state (workspace, packed weights) is rebuilt on demand
         state = dict(self.__dict__)
         state["_packed"], state["_ws"] = {}, None
         state.pop("_side", None)  # HIP stream(s) of the two-branch blocks / part batches: per process, re-created on demand
         state.pop("_part_streams", None)
+        state.pop("_fast_plan", None)  # the fused training plan (static device buffers, events, offsets keyed by parameter identity): rebuilt by the copy's first step
         return state
 
     def __call__(self, *args, **kwargs):

@@ -291,9 +291,7 @@ class HAT(Model):
         f32 = torch.float32
         # conv branch on LayerNorm1(x)  (hat.py:165-170)
         n1 = ws_.get("hab.n1", (B, H, W, Cp), cdt)  # consumed only by the conv, which rounds to the compute dtype anyway
-        unfused = not (ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sr_dtype(cdt)))  # run_window_msa will take its GEMM path
-        if not unfused and not n1_ready:  # the one-kernel attention half writes t (= t_in when in place) before any join: LayerNorm1 must run ahead of it
-            ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
+        unfused = True  # (the attention half is always QKV -> attention -> tail launches; the round-1 one-kernel attention half left with ABI v10)
         mid = ws_.get("hab.mid", (B, H, W, P["c3p"]), cdt)
         y = ws_.get("hab.y", (B, H, W, Cp), cdt)  # enters the block scaled by conv_scale = 0.01
         # small batches: 4-row conv tiles (twice the workgroups) also for the conv with the pool side output

@@ -265,11 +265,6 @@ def run_swin_tail(p: Dict, geo: SwinGeometry, o: Tensor, skip: Tensor, t_out: Te
     )
 
 
-def swin_block_kernel_choice() -> str:
-    """SR_SWIN_BLOCK = v3 (default: sr_swin_block, one weight stream) | v2 (round-2 one-window kernel) | v1 (round-1 kernel); read per call."""
-    return os.environ.get("SR_SWIN_BLOCK", "v3")
-
-
 def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_, cdt: torch.dtype, shift: int, y_mode: int = L.Y_ROLL) -> None:
     """t_out = SwinTransformerBlock(t_in) (swinir.py:146-174): ONE launch when a fused kernel covers the geometry
     (attention half + MLP half on the same window), otherwise attention and MLP as separate launches."""
@@ -279,7 +274,7 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
 
     # the stream was packed for bf16 (cdt bf16) or for split operands (cdt fp32 inside a precision="fp32x3" forward)
     want = L.SR_BF16 if cdt == torch.bfloat16 else (L.SR_BF16X3 if x3_active() else -1)
-    if p.get("stream_dtype", -2) == want and swin_block_kernel_choice() == "v3" and ops.swin_block_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, want):
+    if p.get("stream_dtype", -2) == want and ops.swin_block_supported(geo.C, Cp, geo.heads, geo.hd_p, geo.ws, geo.hid_p, want):
         ops.swin_block(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wstream=p["stream"].data_ptr(), bias=p["bias_frag_l2"].data_ptr(), B=B, H=H, W=W, C=geo.C,
             Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode, compute_dtype=want,
@@ -289,14 +284,6 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
         wqkv, bqkv, wproj, bproj, fc1, fb1, fc2, fb2 = p["light"]
         ops.swin_light(x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=wqkv.data_ptr(), bqkv=bqkv.data_ptr(), wproj=wproj.data_ptr(), bproj=bproj.data_ptr(), w1=fc1.data_ptr(),
                        b1=fb1.data_ptr(), w2=fc2.data_ptr(), b2=fb2.data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, ldx=Cp, shift=shift, eps=1e-5, y_mode=y_mode, compute_dtype=want)
-        return
-    if ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt) and geo.hid_p == 384 and fold_ln(cdt):
-        ops.swin_attn_fused(
-            x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
-            bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
-            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, w1p=p["fc1_w"].data_ptr(), b1=p["fc1_b"].data_ptr(), w2p=p["fc2_w"].data_ptr(),
-            b2=p["fc2_b"].data_ptr(), Hp=geo.hid_p, y_mode=y_mode,
-        )
         return
     run_window_msa(p, p["ln1"], geo, t_in, t_out, t_in, ws_, cdt, shift, y_mode=y_mode)
     run_mlp(p, p["ln2"], geo, t_out, ws_, cdt)
@@ -318,13 +305,6 @@ def run_window_msa(p: Dict, ln, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, 
     M = B * H * W
     nb = M // geo.ntok
     sdt = sr_dtype(cdt)
-    if skip is t_in and ops.swin_attn_supported(Cp, geo.heads, geo.hd_p, geo.ws, sdt):  # one kernel per attention half
-        ops.swin_attn_fused(
-            x=t_in.data_ptr(), out=t_out.data_ptr(), wqkv=p["qkv_w"].data_ptr(), bqkv=p["qkv_b"].data_ptr(), wproj=p["proj_w"].data_ptr(),
-            bproj=p["proj_b_fused"].data_ptr(), bias=p["bias_frag"].data_ptr(), B=B, H=H, W=W, C=geo.C, Cp=Cp, ldx=Cp, heads=geo.heads,
-            hd_p=geo.hd_p, ws=geo.ws, shift=shift, eps=1e-5, y_mode=y_mode,
-        )
-        return False
     q = ws_.get(name + ".q", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     k = ws_.get(name + ".k", (nb, geo.heads, geo.ntok, geo.hd_p), cdt)
     vt = ws_.get(name + ".vt", (nb, geo.heads, geo.hd_p, geo.ntok), cdt)

@@ -160,7 +160,13 @@ def _fast_plan(model, B: int, Hp: int, Wp: int):
     if plan is None:
         return None
     if plan.geo is not None and plan.geo != (B, Hp, Wp):
-        return None  # one geometry per plan: other sizes (evaluation inside a training run) take the generic engine
+        if not getattr(plan, "_bypass_logged", False):  # one geometry per plan: other sizes (evaluation inside a training run) take the generic engine
+            plan._bypass_logged = True
+            import warnings
+
+            warnings.warn(f"studiosr_amd: the fused training plan is prepared for batch geometry {plan.geo}; {(B, Hp, Wp)} runs on the generic engine "
+                          "(correct, about 4x slower; gradients are then not views of the flat buffer, so the optimizer takes torch's own step)")
+        return None
     plan.prepare(B, Hp, Wp)
     plan.pack()
     return plan

@@ -62,17 +62,6 @@ def gemm(**kw) -> None:
     L.check(L.lib().sr_gemm(C.byref(g), _stream()), "sr_gemm")
 
 
-def swin_attn_supported(Cp: int, heads: int, hd_p: int, ws: int, compute_dtype: int) -> bool:
-    return bool(L.lib().sr_swin_attn_supported(Cp, heads, hd_p, ws, compute_dtype))
-
-
-def swin_attn_fused(**kw) -> None:
-    a = L.SrSwinAttn()
-    for k, v in kw.items():
-        setattr(a, k, v)
-    L.check(L.lib().sr_swin_attn_fused(C.byref(a), _stream()), "sr_swin_attn_fused")
-
-
 def swin_light_supported(C_: int, Cp: int, heads: int, hd: int, ws: int, hidden: int, compute_dtype: int) -> bool:
     return bool(L.lib().sr_swin_light_supported(C_, Cp, heads, hd, ws, hidden, compute_dtype))
 

@@ -15,8 +15,9 @@ class Adam(torch.optim.Adam):
     def __init__(self, params, model=None, **kw) -> None:
         self._sr_model = model
         params = list(params)
-        if "fused" not in kw and "foreach" not in kw and params and all(isinstance(p, torch.Tensor) and p.is_cuda for p in params):
-            kw["fused"] = True  # torch's own single-kernel-per-chunk step for everything the flat path does not cover
+        # (No `fused=True` default for the steps the flat path does not cover: torch._fused_adam_ updates the parameters WITHOUT bumping their
+        # version counters (torch 2.10), which the packed-weight caches of the model key on; torch's default foreach step bumps them.  Whatever the
+        # caller chooses, step() below invalidates those caches itself.)
         super().__init__(params, **kw)
         self._flat = None  # (plan, m, v)
         self._steps = 0
@@ -62,10 +63,14 @@ class Adam(torch.optim.Adam):
         plan = self._plan()
         if plan is None:
             if self._flat is not None:  # leaving the flat path: give every parameter its own step tensor again
+                g0 = self.param_groups[0]
+                on_device = bool(g0.get("capturable") or g0.get("fused"))  # as torch's Adam._init_group: torch._fused_adam_ reads the step tensors on the device
                 for p in self._flat[0].fp.params:
-                    self.state[p]["step"] = torch.tensor(float(self._steps), dtype=torch.float32, device=p.device if self.param_groups[0].get("capturable") else "cpu")
+                    self.state[p]["step"] = torch.tensor(float(self._steps), dtype=torch.float32, device=p.device if on_device else "cpu")
                 self._flat = None
-            return super().step(closure)
+            out = super().step(closure)
+            self._invalidate_packed()
+            return out
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -78,9 +83,14 @@ class Adam(torch.optim.Adam):
         fp = plan.fp
         L.check(L.lib().sr_tr_adam(fp.P.data_ptr(), fp.G.data_ptr(), m.data_ptr(), v.data_ptr(), fp.n, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                    float(g["weight_decay"]), self._steps, torch.cuda.current_stream(fp.P.device).cuda_stream), "sr_tr_adam")
-        plan.packed_version = None      # the parameters changed behind torch's version counters
-        plan.model._packed = {}         # (the inference path's packed-weight cache keys on them too)
+        self._invalidate_packed()
         return loss
+
+    def _invalidate_packed(self) -> None:
+        """The parameters changed, possibly behind torch's version counters (sr_tr_adam, torch._fused_adam_): drop the model's packed-weight caches."""
+        m = self._sr_model
+        if m is not None and hasattr(m, "invalidate_packed"):
+            m.invalidate_packed()
 
     def load_state_dict(self, state_dict):
         self._flat = None

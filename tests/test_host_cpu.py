@@ -35,14 +35,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/studiosr_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in studiosr_amd/_lib.py"
     assert sorted(L.SYMBOLS) == names
-    assert lib.sr_abi_version() == L.ABI_VERSION == 9
+    assert lib.sr_abi_version() == L.ABI_VERSION == 10
 
 
 def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() of every argument struct."""
     import subprocess
 
-    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinAttn", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrSwinLight", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd"]
+    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrSwinLight", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd"]
     c = tmp_path / "sz.c"
     c.write_text('#include <stdio.h>\n#include "studiosr_hip.h"\nint main(){' + "".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}\n")
     exe = tmp_path / "sz"

@@ -352,9 +352,92 @@ def test_fused_training_path_matches_the_generic_engine(size):
     tot = lambda g: torch.cat([g[n].flatten() for n in sorted(g32)])  # noqa: E731
     e_gen, e_fast = _rel(tot(gac), tot(g32)), _rel(tot(gf), tot(g32))
     assert e_fast <= 1.15 * e_gen + 2e-3, (e_fast, e_gen)
-    for n in g32:  # every parameter tensor: no gradient may be missing, mis-mapped or mis-scaled
-        scale = float(g32[n].abs().max())
-        assert float((gf[n] - g32[n]).abs().max()) <= 0.08 * max(scale, 1e-9) + 3 * float((gac[n] - g32[n]).abs().max()), n
+    for n in g32:  # every parameter tensor: no gradient may be missing, mis-mapped or mis-scaled (relative L2 against the exact-fp32 step)
+        assert _rel(gf[n], g32[n]) <= max(0.15, 1.5 * _rel(gac[n], g32[n])), (n, _rel(gf[n], g32[n]), _rel(gac[n], g32[n]))
+
+
+# which fused kernel produces which parameter gradient (fasttrain.py BlockPlan.backward): the per-group bounds below localise a failure
+_FUSED_GROUPS = {
+    "sr_tr_tail_bwd + sr_tr_wgrad (proj, LayerNorm2, Mlp)": ("attn.proj.", "norm2.", "mlp.fc1.", "mlp.fc2."),
+    "sr_tr_qkv_bwd + sr_tr_wgrad (LayerNorm1, qkv)": ("norm1.", "attn.qkv.", ".qkv."),
+    "sr_tr_attn_bwd (bias tables)": ("relative_position_bias_table",),
+    "sr_tr_ca_bwd (channel-attention squeeze MLP)": (".attention.",),
+    "sr_tr_ln_bwd (PatchEmbed / final LayerNorm)": ("patch_embed.norm.", "norm."),
+    "conv dgrad + sr_tr_wgrad 9 taps (CAB convs, head / tail convs)": ("conv_block.cab.0.", "conv_block.cab.2.", "conv_first.", "conv_after_body.", "conv_before_upsample.", "upsample.", "conv_last.", ".conv."),
+}
+
+
+@pytest.mark.parametrize("size", [(32, 32), (24, 40)])
+def test_fused_training_step_against_oracle_autograd(size):
+    """BASELINE config 5's PRODUCT path pinned to the oracle directly: the fused HAT training step (fasttrain.py: ONE autograd
+    node of sr_tr_* launches, taken at the default block width under the reference Trainer's autocast, trainer.py:97-109 on hat.py:153-195,239-293)
+    against torch autograd through the fp32 CPU oracle (pinned to the reference's own gradients by the f15 fixtures): default width (embed 180,
+    6 heads, 16 x 16 windows, a shifted HAB, CAB, OCAB), batch 2, 32 x 32 and the reflect-padded 24 x 40.  Output, loss and EVERY parameter
+    gradient; yardstick of test_gradients_under_bf16_autocast (bf16 operands, fp32 accumulate: whole gradient <= 4e-2, every tensor <= 0.15
+    relative L2), and the same bounds per producing kernel."""
+    m = _default_width_hat()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(3)
+    x, y = torch.rand(2, 3, *size), torch.rand(2, 3, size[0] * 2, size[1] * 2)
+    ref_out, ref = _oracle_grads(OM.hat_forward, sd, x, y, m.get_model_config(), True)
+    ref_loss = float(F.l1_loss(ref_out, y))
+    lf, gf, of = _train_step(m, x.to(DEV), y.to(DEV), True, True)
+    assert m._fast_plan is not None and m._fast_plan.full  # the fused path really ran
+    assert abs(lf - ref_loss) <= 2e-3 * max(1.0, abs(ref_loss))
+    assert _rel(of.cpu(), ref_out) <= 1e-2
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert set(names) <= set(ref), sorted(set(names) - set(ref))[:5]
+    num = den = 0.0
+    per_group = {k: [0.0, 0.0] for k in _FUSED_GROUPS}
+    for n in names:
+        g, r = gf[n].cpu().double(), ref[n].double()
+        assert g.shape == r.shape, n
+        e2, r2 = float(((g - r) ** 2).sum()), float((r ** 2).sum())
+        assert e2 ** 0.5 <= 0.15 * max(r2 ** 0.5, 1e-12), f"{n}: relative L2 {e2 ** 0.5 / max(r2 ** 0.5, 1e-12):.3e}"
+        num, den = num + e2, den + r2
+        hit = [k for k, pats in _FUSED_GROUPS.items() if any(pt in n for pt in pats)]
+        assert len(hit) >= 1, f"no producing kernel listed for {n}"
+        per_group[hit[0]][0] += e2
+        per_group[hit[0]][1] += r2
+    assert (num / den) ** 0.5 <= 4e-2, f"whole gradient: relative L2 {(num / den) ** 0.5:.3e}"
+    for k, (e2, r2) in per_group.items():
+        assert r2 > 0, k
+        print(f"{k}: relative L2 {(e2 / r2) ** 0.5:.3e}")
+        assert (e2 / r2) ** 0.5 <= 6e-2, (k, (e2 / r2) ** 0.5)
+
+
+def test_weight_gradient_kernel_against_torch():
+    """sr_tr_wgrad alone (csrc/sr_tr_wgrad.hip; the adjoint of nn.Linear / nn.Conv2d with respect to the weight under loss.backward(), trainer.py:104):
+    a 1-tap job (dW = A^T B with the bias column wired to ones) against a torch matmul and two 9-tap jobs against torch's conv2d weight gradient, on the
+    same bf16-rounded operands; split-K partials summed on the host side of the check."""
+    from studiosr_amd import fasttrain as FT
+
+    bf = torch.bfloat16
+    torch.manual_seed(0)
+    T, Np, Kp, ks = 4096, 576, 192, 8
+    A = (torch.randn(T, Np, device=DEV) * 0.5).to(bf)
+    Bm = (torch.randn(T, Kp, device=DEV) * 0.5).to(bf)
+    out = torch.full((ks, 1, Np, Kp), float("nan"), device=DEV)
+    FT._wgrad([dict(A=A.data_ptr(), B=Bm.data_ptr(), out=out.data_ptr(), lda=Np, ldb=Kp, Np=Np, Kp=Kp, T=T, taps=1, H=1, W=1, ones_col=180, ks=ks)])
+    Bo = Bm.float().clone()
+    Bo[:, 180] = 1.0  # the bias column: dW[:, 180] = column sums of A = the bias gradient
+    assert _rel(out.sum(0)[0], A.float().t() @ Bo) <= 1e-5
+    Bn, H, W, Co, Ci = 2, 16, 32, 64, 192
+    T = Bn * H * W
+    dy = (torch.randn(Bn, H, W, Co, device=DEV) * 0.5).to(bf)
+    xx = (torch.randn(Bn, H, W, Ci, device=DEV) * 0.5).to(bf)
+    o1 = torch.full((ks, 9, Co, Ci), float("nan"), device=DEV)
+    o2 = torch.full((ks, 9, Ci, Co), float("nan"), device=DEV)
+    FT._wgrad([dict(A=dy.data_ptr(), B=xx.data_ptr(), out=o1.data_ptr(), lda=Co, ldb=Ci, Np=Co, Kp=Ci, T=T, taps=9, H=H, W=W, ones_col=-1, ks=ks),
+               dict(A=xx.data_ptr(), B=dy.data_ptr(), out=o2.data_ptr(), lda=Ci, ldb=Co, Np=Ci, Kp=Co, T=T, taps=9, H=H, W=W, ones_col=60, ks=ks)])
+    w = torch.zeros(Co, Ci, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(xx.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert _rel(o1.sum(0), w.grad.permute(2, 3, 0, 1).reshape(9, Co, Ci)) <= 1e-5
+    dyo = dy.float().clone()
+    dyo[..., 60] = 1.0  # job 2: dW2[tap][ci][co] = sum_p x[p][ci] dy[p + off(tap)][co], dy's column 60 := 1 where the source pixel exists
+    pad = F.pad(dyo, (0, 0, 1, 1, 1, 1))
+    ref2 = torch.stack([torch.einsum("bhwi,bhwo->io", xx.float(), pad[:, t // 3:t // 3 + H, t % 3:t % 3 + W, :]) for t in range(9)])
+    assert _rel(o2.sum(0), ref2) <= 1e-5
 
 
 def test_fused_training_path_drop_path_and_accumulation():
@@ -417,6 +500,19 @@ def test_fused_training_path_guards():
     m.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         assert m(x).shape == (2, 3, 64, 64)
+    # a snapshot (EMA / best-model copy) after fused steps: the plan is not copied, the copy builds its own on its first step
+    import copy
+
+    m.train()
+    m2 = copy.deepcopy(m)
+    assert getattr(m2, "_fast_plan", None) is None and m._fast_plan is not None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        F.l1_loss(m2(x).float(), y).backward()
+    assert m2._fast_plan is not None and m2._fast_plan is not m._fast_plan and all(p.grad is not None for p in m2.parameters())
+    # non-uniform depths per RHAG are not a fused geometry (the generic engine handles them)
+    from studiosr_amd import fasttrain
+
+    assert not fasttrain.HatPlan.supported(S.HAT(scale=2, depths=[2, 1], num_heads=[6, 6]).to(DEV))
 
 
 def test_flat_adam_equals_torch_adam_on_the_fused_path(tmp_path):
@@ -454,6 +550,80 @@ def test_flat_adam_equals_torch_adam_on_the_fused_path(tmp_path):
     torch.save(sd, tmp_path / "opt.pth")
     m3, o3 = run(lambda m: torch.optim.Adam(m.parameters(), **kw), n=0, state=torch.load(tmp_path / "opt.pth"))  # loads into torch's Adam
     assert float(o3.state_dict()["state"][0]["step"]) == 3.0
+
+
+def test_flat_adam_leaves_and_re_enters_the_flat_path():
+    """a step whose gradients are not views of the plan's flat buffer (here: another batch geometry, which takes the generic
+    engine) leaves the flat path and runs torch's fused Adam -- whose per-parameter step tensors must then live on the device -- and the next
+    fused-geometry step re-enters it.  Parameters after flat -> generic -> flat equal torch.optim.Adam's on the same sequence."""
+    from studiosr_amd.optim import Adam
+
+    torch.manual_seed(11)
+    xa, ya = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+    xb, yb = torch.rand(1, 3, 48, 48, device=DEV), torch.rand(1, 3, 96, 96, device=DEV)
+    kw = dict(lr=1e-3, betas=(0.9, 0.99))
+
+    def run(make_opt):
+        m = _default_width_hat()
+        opt = make_opt(m)
+        flat = []
+        for x, y in ((xa, ya), (xb, yb), (xa, ya)):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.l1_loss(m(x).float(), y)
+            loss.backward()
+            opt.step()
+            flat.append(getattr(opt, "_flat", None) is not None)
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return m, opt, flat
+
+    m0 = _default_width_hat()
+    init = [p.detach().clone() for p in m0.parameters()]
+    m_ref, _, _ = run(lambda m: torch.optim.Adam(m.parameters(), **kw))
+    for fused in (False, True):  # fused=True is the ADVICE case: torch._fused_adam_ dereferences the step tensors on the device
+        m_new, o_new, flat = run(lambda m: Adam(m.parameters(), model=m, **(dict(kw, fused=True) if fused else kw)))
+        assert flat == [True, False, True], flat
+        assert all(float(o_new.state[p]["step"]) == 3.0 for p in m_new.parameters())
+        # Adam's update lr * m / sqrt(v) is a sign function of gradients at rounding-noise level, so single entries may differ by ~lr between two correct
+        # runs: the bound is on the update as a whole and on the fraction of entries that moved differently
+        num = den = 0.0
+        far = tot = 0
+        for a, b, i0 in zip(m_ref.parameters(), m_new.parameters(), init):
+            d = (a.detach() - b.detach()).abs()
+            num, den = num + float((d ** 2).sum()), den + float(((a.detach() - i0) ** 2).sum())
+            far, tot = far + int((d > 0.5 * kw["lr"]).sum()), tot + d.numel()
+        assert (num / den) ** 0.5 <= 2e-2 and far <= 1e-3 * tot, (fused, (num / den) ** 0.5, far / tot)
+
+
+def test_fused_training_path_sees_parameter_updates_that_bump_no_version_counter():
+    """torch.optim.Adam(fused=True) (torch._fused_adam_) changes the parameters without bumping their version counters (torch 2.10): the fused training
+    plan and the inference path's packed-weight cache must still see the new values (round 4's plan keyed its repacking on the counters and trained
+    every step of such a run on the first step's weights).  The recorded forward repacks every time; eval() / train() drop the inference cache."""
+    m = _default_width_hat()
+    torch.manual_seed(2)
+    x, y = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    m.eval()
+    with torch.no_grad():
+        y0 = m(x).clone()  # fills the inference cache
+    m.train()
+    losses = []
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = F.l1_loss(m(x).float(), y)
+        loss.backward()
+        losses.append(loss.item())
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    assert m._fast_plan is not None
+    assert abs(losses[1] - losses[0]) > 1e-3 * losses[0], losses  # an Adam step of 1e-3 moves this loss by far more than rounding
+    m2 = _default_width_hat()  # a fresh model holding the trained parameters
+    m2.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    m.eval()
+    m2.eval()
+    with torch.no_grad():
+        y1, y2 = m(x), m2(x)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y0)  # inference after training runs on the trained weights
 
 
 def test_fused_training_path_under_ddp_two_ranks_gloo(tmp_path):

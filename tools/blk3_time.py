@@ -18,7 +18,7 @@ lp = m._get_packed(cdt)["layers"][0]
 geo, bp = lp["geo"], lp["blocks"][1]
 ws_ = S.runtime.Workspace(dev)
 kinds = sys.argv[1:] or ["v3"]
-for B in (1, 8, 16):
+for B in [int(b) for b in os.environ.get("SR_BS", "1,8,16").split(",")]:
     t = torch.randn(B, 72, 72, geo.Cp, device=dev)
     t[..., geo.C:] = 0
     o = torch.empty_like(t)
