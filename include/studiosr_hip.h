@@ -110,6 +110,10 @@ typedef struct SrSwinBlock {
     int y_mode;            /* SR_Y_* */
     int compute_dtype;     /* SR_BF16: bf16 operands (wstream 48 * 12 * 64 * 8 bf16); SR_BF16X3: split operands hi + lo (precision "fp32x3": fp32-class
                             * accuracy, wstream 48 * 12 * 64 * 16 bf16 = per lane 8 hi | 8 lo, erf GELU, bias pre-scaled by log2(e) as for bf16) */
+    int max_workgroups;    /* ABI v10.  0: one workgroup per window while all windows are resident at once (bf16: 3 per CU), otherwise that many persistent
+                            * workgroups, each walking windows b, b + grid, ... with the next window's rows fetched under the current result stores;
+                            * > 0: at most this many workgroups (two batches in flight: half the device each); < 0: always one workgroup per window.
+                            * Results do not depend on it (a window's arithmetic is the same whoever computes it). */
 } SrSwinBlock;
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);
@@ -645,6 +649,46 @@ int sr_tr_adam(float* p, const float* g, float* m, float* v, long long n, float 
 
 /* g = GELU(x) and / or dx = dg * GELU'(x), bf16 (the nn.GELU between the CAB's convolutions, hat.py:43); n elements, n % 8 == 0. */
 int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long long n, void* stream);
+/* ABI v10: the positional launches of a training step with their arguments in a block (int f(const Block*, void* stream)): recordable in a launch plan.
+ * Each forwards to the function of the same name without the suffix. */
+typedef struct SrTrGelu { const void* x; const void* dg; void* g; void* dx; long long n; } SrTrGelu;
+int sr_tr_gelu_args(const SrTrGelu* a, void* stream);
+typedef struct SrTrAdd { const float* a; const void* b; float* out; long long n; int b_dtype; } SrTrAdd;
+int sr_tr_add_args(const SrTrAdd* a, void* stream);
+typedef struct SrTrFinalize { const float* arena; const long long* src; const int* dst; const int* stride; const int* ns; const float* scale; float* grad; long long n; } SrTrFinalize;
+int sr_tr_finalize_to_args(const SrTrFinalize* a, void* stream);
+typedef struct SrTrUnshuffle { const void* src; void* dst; int B, H, W, cps, r; } SrTrUnshuffle;
+int sr_tr_unshuffle_args(const SrTrUnshuffle* a, void* stream);
+typedef struct SrTrLreluBwd { const void* dy; const void* y; void* dx; long long n; float slope; } SrTrLreluBwd;
+int sr_tr_lrelu_bwd_args(const SrTrLreluBwd* a, void* stream);
+typedef struct SrLayernorm { const float* x; void* y; const float* gamma; const float* beta; int y_dtype, M, C, Cp; float eps; } SrLayernorm;
+int sr_layernorm_to_args(const SrLayernorm* a, void* stream);
+
+/* Launch plans (ABI v10; csrc/sr_plan.cpp).  The reference's training loop (studiosr/engine/trainer.py:97-109) is a handful of ATen calls per layer; here a
+ * training step is ~530 C-ABI launches whose arguments are static after the first step.  A plan is that sequence recorded once: sr_plan_create copies the
+ * operations AND their argument blocks; sr_plan_run enqueues them in order, each on streams[op.stream] (slot 0 = the caller's current stream).
+ *   SR_PLAN_CALL1  fn(arg, stream)            every entry point of the form int f(const Struct*, void* stream)
+ *   SR_PLAN_CALL2  fn(arg, arg2, stream)      sr_hab_mid
+ *   SR_PLAN_CALLI  fn(arg, ival, stream)      sr_tr_wgrad (job array, count), sr_tr_oca_fold (block, direction)
+ *   SR_PLAN_EVENT_RECORD / SR_PLAN_STREAM_WAIT  hipEventRecord(event[ival], stream) / hipStreamWaitEvent(stream, event[ival]): the cross-stream edges
+ * Enqueue-only like everything else here; a plan may be run any number of times, from one thread at a time. */
+enum { SR_PLAN_CALL1 = 0, SR_PLAN_CALL2 = 1, SR_PLAN_CALLI = 2, SR_PLAN_EVENT_RECORD = 3, SR_PLAN_STREAM_WAIT = 4 };
+typedef struct SrPlanOp {
+    int kind;       /* SR_PLAN_* */
+    int stream;     /* index into the stream table of sr_plan_run */
+    int ival;       /* CALLI: the integer argument; EVENT_RECORD / STREAM_WAIT: event index in [0, n_events) */
+    int arg_bytes;  /* bytes of *arg (copied by sr_plan_create) */
+    int arg2_bytes; /* CALL2: bytes of *arg2 */
+    int reserved;
+    const void* fn;
+    const void* arg;
+    const void* arg2;
+} SrPlanOp;
+void* sr_plan_create(const SrPlanOp* ops, int n, int n_events);  /* NULL on error (sr_last_error) */
+int sr_plan_streams(const void* plan);                           /* stream slots the plan uses */
+int sr_plan_ops(const void* plan);
+int sr_plan_run(const void* plan, void* const* streams, int n_streams);
+void sr_plan_destroy(void* plan);
 
 #ifdef __cplusplus
 }

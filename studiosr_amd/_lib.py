@@ -9,6 +9,7 @@ import ctypes as C
 import os
 import subprocess
 import threading
+from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_LIB_PATH selects an experimental build (tools/variants.sh) without touching the shipped library.
@@ -48,7 +49,7 @@ class SrSwinBlock(C.Structure):
     _fields_ = [
         ("x", _vp), ("out", _vp), ("wstream", _vp), ("bias", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("Cp", _i), ("ldx", _i), ("heads", _i), ("hd_p", _i), ("ws", _i), ("shift", _i), ("Hp", _i),
-        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i),
+        ("eps", _f), ("y_mode", _i), ("compute_dtype", _i), ("max_workgroups", _i),
     ]
 
 
@@ -225,6 +226,36 @@ class SrTrCaBwd(C.Structure):
 EW_GELU_FWD, EW_GELU_BWD, EW_RELU_FWD, EW_RELU_BWD, EW_LRELU_FWD, EW_LRELU_BWD, EW_AXPBY, EW_MUL = range(8)
 EW_SIGMOID_FWD, EW_SIGMOID_BWD, EW_SCALE_SAMPLE, EW_MUL_BC, EW_BCAST_BC, EW_AFFINE_C = range(8, 14)
 
+class SrTrGelu(C.Structure):  # ABI v10
+    _fields_ = [("x", _vp), ("dg", _vp), ("g", _vp), ("dx", _vp), ("n", _ll)]
+
+
+class SrTrAdd(C.Structure):
+    _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("n", _ll), ("b_dtype", _i)]
+
+
+class SrTrFinalize(C.Structure):
+    _fields_ = [("arena", _vp), ("src", _vp), ("dst", _vp), ("stride", _vp), ("ns", _vp), ("scale", _vp), ("grad", _vp), ("n", _ll)]
+
+
+class SrTrUnshuffle(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("B", _i), ("H", _i), ("W", _i), ("cps", _i), ("r", _i)]
+
+
+class SrTrLreluBwd(C.Structure):
+    _fields_ = [("dy", _vp), ("y", _vp), ("dx", _vp), ("n", _ll), ("slope", _f)]
+
+
+class SrLayernorm(C.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("gamma", _vp), ("beta", _vp), ("y_dtype", _i), ("M", _i), ("C", _i), ("Cp", _i), ("eps", _f)]
+
+
+class SrPlanOp(C.Structure):  # ABI v10 (csrc/sr_plan.cpp)
+    _fields_ = [("kind", _i), ("stream", _i), ("ival", _i), ("arg_bytes", _i), ("arg2_bytes", _i), ("reserved", _i), ("fn", _vp), ("arg", _vp), ("arg2", _vp)]
+
+
+PLAN_CALL1, PLAN_CALL2, PLAN_CALLI, PLAN_EVENT_RECORD, PLAN_STREAM_WAIT = range(5)
+
 # every symbol include/studiosr_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sr_abi_version": (_i, []),
@@ -301,6 +332,18 @@ SYMBOLS = {
     "sr_tr_qkv_bwd": (_i, [C.POINTER(SrTrQkvBwd), _vp]),
     "sr_tr_ca_bwd": (_i, [C.POINTER(SrTrCaBwd), _vp]),
     "sr_tr_gelu": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    "sr_tr_gelu_args": (_i, [C.POINTER(SrTrGelu), _vp]),
+    "sr_tr_add_args": (_i, [C.POINTER(SrTrAdd), _vp]),
+    "sr_tr_finalize_to_args": (_i, [C.POINTER(SrTrFinalize), _vp]),
+    "sr_tr_unshuffle_args": (_i, [C.POINTER(SrTrUnshuffle), _vp]),
+    "sr_tr_lrelu_bwd_args": (_i, [C.POINTER(SrTrLreluBwd), _vp]),
+    "sr_layernorm_to_args": (_i, [C.POINTER(SrLayernorm), _vp]),
+    # launch plans (ABI v10)
+    "sr_plan_create": (_vp, [C.POINTER(SrPlanOp), _i, _i]),
+    "sr_plan_streams": (_i, [_vp]),
+    "sr_plan_ops": (_i, [_vp]),
+    "sr_plan_run": (_i, [_vp, C.POINTER(_vp), _i]),
+    "sr_plan_destroy": (None, [_vp]),
     "sr_tr_ln_bwd": (_i, [C.POINTER(SrTrLnBwd), _vp]),
     "sr_tr_unshuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sr_tr_lrelu_bwd": (_i, [_vp, _vp, _vp, _f, _ll, _vp]),
@@ -327,8 +370,15 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
-def lib() -> C.CDLL:
-    """The loaded library; raises HipLibraryError when it is absent (no CPU fallback exists)."""
+def lib():
+    """The loaded library; raises HipLibraryError when it is absent (no CPU fallback exists).  While a launch plan is being recorded (`recording()`)
+    the returned object records every launch entry point instead of calling it."""
+    if _REC is not None:
+        return _REC.proxy
+    return _handle()
+
+
+def _handle() -> C.CDLL:
     global _lib
     if _lib is None:
         with _lock:
@@ -350,4 +400,183 @@ def lib() -> C.CDLL:
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise HipLibraryError(f"{what} failed ({rc}): {lib().sr_last_error().decode()}")
+        raise HipLibraryError(f"{what} failed ({rc}): {_handle().sr_last_error().decode()}")
+
+
+# --------------------------------------------------------------------------- launch plans (ABI v10, csrc/sr_plan.cpp)
+_REC = None  # the PlanRecorder that is recording, if any (one thread drives a model: no lock)
+
+
+def _is_launch(name: str) -> bool:
+    res, args = SYMBOLS.get(name, (None, []))
+    return res is _i and len(args) >= 2 and args[-1] is _vp and not name.startswith(("sr_plan_", "sr_pack_"))
+
+
+class _RecordingLib:
+    """What `lib()` returns while a plan is recorded: launch entry points are recorded (and report success), everything else passes through."""
+
+    def __init__(self, rec: "PlanRecorder") -> None:
+        self._rec, self._h = rec, _handle()
+
+    def __getattr__(self, name: str):
+        fn = getattr(self._h, name)
+        if not _is_launch(name):
+            return fn
+        rec = self._rec
+
+        def record(*args):
+            rec.add_call(name, fn, args)
+            return 0
+
+        setattr(self, name, record)
+        return record
+
+
+class LaunchPlan:
+    """A recorded launch sequence: C segments (sr_plan_run: one call enqueues the segment) with the few launches that have no argument-block form
+    (positional scalars: sr_tr_add, sr_tr_finalize_to, ...) kept as Python closures between them."""
+
+    def __init__(self, segments, side_streams, n_launches: int) -> None:
+        self.segments, self.side_streams, self.n_launches = segments, side_streams, n_launches
+        self._tab = (_vp * (1 + len(side_streams)))()
+        for i, s in enumerate(side_streams):
+            self._tab[1 + i] = s
+
+    def run(self, stream: int) -> None:
+        h = _handle()
+        tab = self._tab
+        tab[0] = stream
+        n = len(tab)
+        for kind, seg in self.segments:
+            if kind == "c":
+                rc = h.sr_plan_run(seg, tab, n)
+                if rc != 0:
+                    check(rc, "sr_plan_run")
+            else:
+                seg(tab)
+
+    def __del__(self):
+        try:
+            h = _handle()
+            for kind, seg in self.segments:
+                if kind == "c":
+                    h.sr_plan_destroy(seg)
+        except Exception:
+            pass
+
+
+class PlanRecorder:
+    """Records the launches made through `lib()` between `with recording(rec):` ... (nothing is enqueued meanwhile).  Streams are recorded by handle:
+    the stream that is current when recording starts becomes slot 0 and is replaced by the caller's current stream at every run; other handles (the
+    side streams of two-branch blocks: persistent torch streams) are replayed as they are."""
+
+    def __init__(self, main_stream: int) -> None:
+        self.main = int(main_stream or 0)
+        self.side: list = []
+        self.items: list = []  # ("op", SrPlanOp, keep-alive) | ("py", closure)
+        self.n_events = 0
+        self.n_launches = 0
+        self.proxy = _RecordingLib(self)
+
+    def slot(self, stream) -> int:
+        s = int(stream or 0)
+        if s == self.main:
+            return 0
+        if s not in self.side:
+            self.side.append(s)
+        return 1 + self.side.index(s)
+
+    @staticmethod
+    def _block(a):
+        """(address, bytes, keep-alive) of an argument block given as byref(struct), a ctypes array or a ctypes structure; None for anything else."""
+        obj = getattr(a, "_obj", a)  # C.byref(x) keeps x in ._obj
+        if isinstance(obj, (C.Structure, C.Array)):
+            return C.addressof(obj), C.sizeof(obj), obj
+        return None
+
+    def add_call(self, name: str, fn, args) -> None:
+        *a, st = args
+        slot = self.slot(st)
+        self.n_launches += 1
+        blocks = [self._block(x) for x in a]
+        op = SrPlanOp()
+        op.stream, op.fn = slot, C.cast(fn, _vp).value
+        if len(a) == 1 and blocks[0]:
+            op.kind = PLAN_CALL1
+        elif len(a) == 2 and blocks[0] and blocks[1]:
+            op.kind = PLAN_CALL2
+            op.arg2, op.arg2_bytes = blocks[1][0], blocks[1][1]
+        elif len(a) == 2 and blocks[0] and isinstance(a[1], int):
+            op.kind, op.ival = PLAN_CALLI, a[1]
+        else:  # positional scalars / raw pointers: replayed from Python with the run's stream
+            frozen = tuple(a)
+            self.items.append(("py", lambda tab, fn=fn, frozen=frozen, slot=slot, name=name: check(fn(*frozen, tab[slot]), name)))
+            return
+        op.arg, op.arg_bytes = blocks[0][0], blocks[0][1]
+        self.items.append(("op", op, [b[2] for b in blocks if b]))
+
+    def event(self) -> int:
+        self.n_events += 1
+        return self.n_events - 1
+
+    def add_event_record(self, stream, ev: int) -> None:
+        op = SrPlanOp()
+        op.kind, op.stream, op.ival = PLAN_EVENT_RECORD, self.slot(stream), ev
+        self.items.append(("op", op, None))
+
+    def add_stream_wait(self, stream, ev: int) -> None:
+        op = SrPlanOp()
+        op.kind, op.stream, op.ival = PLAN_STREAM_WAIT, self.slot(stream), ev
+        self.items.append(("op", op, None))
+
+    def finish(self) -> LaunchPlan:
+        h = _handle()
+        segments, run = [], []
+
+        def flush():
+            if not run:
+                return
+            arr = (SrPlanOp * len(run))(*run)
+            # events are per C segment: an edge may not cross a Python-replayed launch
+            recorded = set()
+            for o in run:
+                if o.kind == PLAN_EVENT_RECORD:
+                    recorded.add(o.ival)
+                elif o.kind == PLAN_STREAM_WAIT and o.ival not in recorded:
+                    raise HipLibraryError("launch plan: a cross-stream edge spans a launch that is replayed from Python")
+            seg = h.sr_plan_create(arr, len(run), self.n_events)
+            if not seg:
+                raise HipLibraryError("sr_plan_create failed: " + h.sr_last_error().decode())
+            segments.append(("c", seg))
+            run.clear()
+
+        for it in self.items:
+            if it[0] == "op":
+                run.append(it[1])
+            else:
+                flush()
+                segments.append(("py", it[1]))
+        flush()
+        return LaunchPlan(segments, list(self.side), self.n_launches)
+
+
+class recording:
+    """with recording(rec): ...   -- launches made through lib() inside the block are recorded into rec, not enqueued."""
+
+    def __init__(self, rec: PlanRecorder) -> None:
+        self.rec = rec
+
+    def __enter__(self):
+        global _REC
+        assert _REC is None, "a launch plan is already being recorded"
+        _REC = self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        return False
+
+
+def recorder() -> Optional["PlanRecorder"]:
+    return _REC

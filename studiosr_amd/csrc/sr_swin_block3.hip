@@ -61,6 +61,8 @@ __device__ unsigned long long sr_dbg_wgtrace[4096 * 6];
 struct SwinBlock3Dev {
     SrSwinBlock a;
     FastDiv div_nw, div_nwx;  // windows per image, windows per row
+    int nwin;                 // windows of the launch (B * windows per image); the grid may be smaller (SrSwinBlock.max_workgroups): workgroup b then
+                              // takes windows b, b + gridDim.x, ... and fetches the next window's rows while its result rows leave
 };
 
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
     float* red = reinterpret_cast<float*>(smem + Lds<T>::RED_OFF);
     Frag<T>* Himg = Qimg;  // [24][64] hidden half (MLP stage: Q / K / V are dead)
 
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (re-read through an opaque asm at the top of every trip of the window loop, see there)
     const int lane0 = threadIdx.x & 63;
     int lane = lane0, ar = lane & 15, ag = lane >> 4;
     // hipcc would hoist every per-lane LDS / global offset to kernel entry and keep ~40 address registers alive (and spilled);
@@ -91,22 +93,38 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
         ag = lane >> 4;
     };
 
-    // ---- window geometry (one window per workgroup)
+    // ---- window geometry.  One window per workgroup, or (grid < nwin) a persistent workgroup walking windows blockIdx.x + k gridDim.x
     uint32_t bimg, win, wy, wx;
-    dv.div_nw.divmod((uint32_t)blockIdx.x, bimg, win);
-    dv.div_nwx.divmod(win, wy, wx);
     const int shift_y = a.y_mode == SR_Y_ROLL ? a.shift : 0;  // strips arrive already rolled in y (halo exchange)
-    auto pixel_row = [&](int t) {  // image-order row of window token t (roll + partition as one gather)
-        int y = wy * WS + (t >> 3) + shift_y;
-        int x = wx * WS + (t & 7) + a.shift;
-        if (y >= a.H) y -= a.H;
-        if (x >= a.W) x -= a.W;
-#ifdef SR_EXP_XSMALL
-        return (((int)bimg * a.H + y) * a.W + x) & 4095;  // experiment: all I/O inside 3 MB (L2-resident): the I/O instructions without the HBM traffic
-#endif
-        return ((int)bimg * a.H + y) * a.W + x;
+    // Token rows of a window as [row base pointer (one per window row: a wave's 16 tokens are window rows 2 w, 2 w + 1)] + [byte offset of the column,
+    // the same eight values for every window row, for x and for out]: roll + partition as one gather with 2 scalar pointers + 8 scalar offsets live
+    // instead of 16 pointers (a persistent workgroup addresses two windows at the end of a trip: the next one's rows and its own result rows).
+    struct WinRows {
+        size_t rbase[2];  // element offset of pixel (y, 0) for the wave's two window rows
+        int coff[8];      // byte offset of the window's eight columns inside an image row
     };
-    const int hh = w >> 1, half = w & 1;  // GEMM role: d-half `half` of head 2p + hh; attention atom: queries [32 half, +32) of that head
+    auto rows_of = [&](uint32_t bi, uint32_t gy, uint32_t gx) {
+        WinRows r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int y = gy * WS + 2 * w + j + shift_y;
+            if (y >= a.H) y -= a.H;
+            r.rbase[j] = (size_t)(((int)bi * a.H + y) * a.W) * a.ldx;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int x = gx * WS + c + a.shift;
+            if (x >= a.W) x -= a.W;
+            r.coff[c] = x * a.ldx * 4;
+        }
+        return r;
+    };
+    int item = blockIdx.x;
+    dv.div_nw.divmod((uint32_t)item, bimg, win);
+    dv.div_nwx.divmod(win, wy, wx);
+    bimg = __builtin_amdgcn_readfirstlane(bimg);
+    wy = __builtin_amdgcn_readfirstlane(wy);
+    wx = __builtin_amdgcn_readfirstlane(wx);
 
     STAMP(0);
     WGTRACE(0);
@@ -115,16 +133,17 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
     for (int i = 0, k = (blockIdx.x >> 8) % 3; i < k; ++i) __builtin_amdgcn_s_sleep(SR_EXP_DEPHASE);
 #endif
     // ---- x: 16 full token rows per wave by LDS-DMA (window gather = one scalar row address per piece), then the first weight slots
-    {
-        const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto fetch_rows = [&](uint32_t bi, uint32_t gy, uint32_t gx) {
+        const WinRows r = rows_of(bi, gy, gx);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int t = 16 * w + i;
 #if !defined(SR_EXP_NOXIO) && !defined(SR_EXP_NOXLOAD)
-            dma_row48(a.x + (size_t)pixel_row(t) * a.ldx, __builtin_amdgcn_readfirstlane(tile_lds + t * XS), lane);
+            dma_row48(a.x + r.rbase[i >> 3], r.coff[i & 7], __builtin_amdgcn_readfirstlane(tile_lds + (16 * w + i) * XS), lane);
 #endif
         }
-    }
+    };
+    fetch_rows(bimg, wy, wx);
     __builtin_amdgcn_sched_barrier(0);
     WStream<T> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wstream), 0, NSLOT * 12 * 64 * (int)sizeof(Frag<T>), 0x00020000);
@@ -133,10 +152,22 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
     for (int s0 = 0; s0 < WStream<T>::DIST; ++s0) ws.load(s0, lane);
     const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, 6 * 16 * 64 * 16, 0x00020000);
     __builtin_amdgcn_sched_barrier(0);
+    bool first = true;
+    for (;;) {  // one window per trip
+    // The window's 16 rows per wave have landed; younger operations may still fly: the first weight slots, and behind a previous trip also its 16 row stores
+    // (vector-memory operations complete in issue order: rows -> [row stores] -> weight slots).
 #ifndef SR_EXP_XNOWAIT
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WStream<T>::LOADS_PER_SLOT * WStream<T>::DIST) : "memory");  // the 16 rows have landed; the weight slots issued after them may still fly
+    if (first)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WStream<T>::LOADS_PER_SLOT * WStream<T>::DIST) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WStream<T>::LOADS_PER_SLOT * WStream<T>::DIST + 16) : "memory");
 #endif
     BLOCK_SYNC();
+    // The wave index is made opaque once per trip: everything derived from it (144 weight-slot offsets, bias-tile offsets, image cells) would otherwise be
+    // loop-invariant, get hoisted out of the window loop and spill ~160 SGPRs; this way a trip compiles like the one-window kernel did.
+    asm volatile("" : "+s"(w));
+    ws.wave_frag = w * 3;
+    const int hh = w >> 1, half = w & 1;  // GEMM role: d-half `half` of head 2p + hh; attention atom: queries [32 half, +32) of that head
     f32x4 x1[4][3];  // [m][n]: token 16 m + ar, channels 48 w + 16 n + 4 ag .. +3   (the residual, then x1, then the output)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -426,15 +457,43 @@ __global__ __launch_bounds__(256, sizeof(Frag<T>) == 16 ? 3 : 1) void sr_swin_bl
         const int l48 = lane < 48 ? lane : 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) rowv[i] = *reinterpret_cast<const f32x4*>(smem + (16 * w + i) * XS + l48 * 16);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#if !defined(SR_EXP_NOXIO) && !defined(SR_EXP_NOXSTORE)
-            store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);
-#else
-            if (rowv[i][0] == 1.2345e-30f) store_row48(a.out + (size_t)pixel_row(16 * w + i) * a.ldx, rowv[i], lane);  // keeps the value live
-#endif
+        // Persistent form: this workgroup's next window.  Its 16 rows per wave are fetched into the tile rows this wave has just read (each wave reads and
+        // refills only its own 16 rows: no barrier), BEFORE the result rows are issued, so that the fetch flies under the stores and the first weight slots.
+        const int next = __builtin_amdgcn_readfirstlane(item + (int)gridDim.x);
+        const bool more = next < dv.nwin;
+        uint32_t nb = 0, nwin_ = 0, ny = 0, nx = 0;
+        if (more) {
+            dv.div_nw.divmod((uint32_t)next, nb, nwin_);
+            dv.div_nwx.divmod(nwin_, ny, nx);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            ny = __builtin_amdgcn_readfirstlane(ny);
+            nx = __builtin_amdgcn_readfirstlane(nx);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // rowv is in registers: the rows may be overwritten
+            fetch_rows(nb, ny, nx);
         }
+        {
+            const WinRows r = rows_of(bimg, wy, wx);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#if !defined(SR_EXP_NOXIO) && !defined(SR_EXP_NOXSTORE)
+                store_row48(a.out + r.rbase[i >> 3], r.coff[i & 7], rowv[i], lane);
+#else
+                if (rowv[i][0] == 1.2345e-30f) store_row48(a.out + r.rbase[i >> 3], r.coff[i & 7], rowv[i], lane);  // keeps the value live
+#endif
+            }
+        }
+        if (!more) break;
+        item = next;  // (readfirstlane: the row addresses are scalar operands; the loop-carried values are uniform, which the compiler does not prove)
+        bimg = __builtin_amdgcn_readfirstlane(nb);
+        wy = __builtin_amdgcn_readfirstlane(ny);
+        wx = __builtin_amdgcn_readfirstlane(nx);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s0 = 0; s0 < WStream<T>::DIST; ++s0) ws.load(s0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        first = false;
     }
+    }  // for (;;)
     STAMP(41);
     WGTRACE(1);
 }
@@ -455,6 +514,19 @@ extern "C" int sr_debug_sw3_wgtrace(unsigned long long* host, int n) {
 
 extern "C" int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype) {
     return ((compute_dtype == SR_BF16 || compute_dtype == SR_BF16X3) && C == 180 && Cp == 192 && heads == 6 && hd_p == 32 && ws == 8 && Hp == 384) ? 1 : 0;
+}
+
+// Workgroups the device holds at once (bf16: three per CU; bf16x3: one): the default grid of a launch with more windows than that
+static int resident_workgroups(int per_cu) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256 * per_cu;
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    return n * per_cu;
 }
 
 template <typename T>
@@ -484,6 +556,16 @@ extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
     const int nwx = a.W / a.ws, nwy = a.H / a.ws;
     dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
-    if (cdt == SR_BF16X3) return launch_swin_block3<bf3>(dv, a.B * nwx * nwy, reinterpret_cast<hipStream_t>(stream));
-    return launch_swin_block3<bf16>(dv, a.B * nwx * nwy, reinterpret_cast<hipStream_t>(stream));
+    dv.nwin = a.B * nwx * nwy;
+    // grid: one workgroup per window while they are all resident at once; beyond that (or when the caller asks: two batches in flight share the
+    // CUs as two grids of half the device each) persistent workgroups that walk windows b, b + grid, ... and prefetch the next window's rows
+    int grid = dv.nwin;
+    if (a.max_workgroups > 0)
+        grid = a.max_workgroups < grid ? a.max_workgroups : grid;
+    else if (a.max_workgroups == 0) {
+        const int slots = resident_workgroups(cdt == SR_BF16X3 ? 1 : 3);
+        grid = slots < grid ? slots : grid;
+    }
+    if (cdt == SR_BF16X3) return launch_swin_block3<bf3>(dv, grid, reinterpret_cast<hipStream_t>(stream));
+    return launch_swin_block3<bf16>(dv, grid, reinterpret_cast<hipStream_t>(stream));
 }

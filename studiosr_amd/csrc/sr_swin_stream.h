@@ -174,6 +174,24 @@ SR_DEV void dma_row48(const float* row, unsigned lds_dst, int lane) {
                      : "memory");
     }
 }
+// the same with the row given as [scalar base pointer of the image row] + [scalar byte offset of the pixel]: the offset joins the lane part in a VGPR
+// inside the asm block (one v_add per row), so that a window's 16 rows per wave need 2 pointers + 8 offsets in SGPRs instead of 16 pointers
+SR_DEV void store_row48(float* base, int byte_off, const f32x4& v, int lane) {
+    if (lane < 48) {
+        int voff;
+        asm volatile("v_add_u32 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %4" SR_X_STORE_POLICY "\n\ts_nop 1" : "=&v"(voff) : "s"(byte_off), "v"(lane * 16), "v"(v), "s"(base) : "memory");
+    }
+}
+SR_DEV void dma_row48(const float* base, int byte_off, unsigned lds_dst, int lane) {
+    if (lane < 48) {
+        unsigned keep;
+        int voff;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\tv_add_u32 %1, %3, %2\n\tglobal_load_lds_dwordx4 %1, %4" SR_X_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(voff)
+                     : "v"(lane * 16), "s"(byte_off), "s"(base), "s"(lds_dst)
+                     : "memory");
+    }
+}
 
 // The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of RING slots in registers.
 // Buffer loads: the fragment's byte offset is a scalar (soffset), the lane part one shared VGPR -- no per-load 64-bit address arithmetic.

@@ -1112,6 +1112,11 @@ extern "C" int sr_tr_gelu(const void* x, const void* dg, void* g, void* dx, long
     return SR_OK;
 }
 
+extern "C" int sr_tr_gelu_args(const SrTrGelu* a, void* stream) {
+    SR_REQUIRE(a, "sr_tr_gelu_args: null pointer");
+    return sr_tr_gelu(a->x, a->dg, a->g, a->dx, a->n, stream);
+}
+
 extern "C" int sr_tr_ln_bwd(const SrTrLnBwd* p, void* stream) {
     SR_REQUIRE(p && p->x && p->dy && p->gamma && p->dx && p->ln_part, "sr_tr_ln_bwd: null pointer");
     const SrTrLnBwd& a = *p;

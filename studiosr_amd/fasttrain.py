@@ -53,6 +53,52 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+PLAN = os.environ.get("SR_TR_PLAN", "1") != "0"  # A/B knob: the step's launch sequences recorded once and replayed from C (sr_plan_run); 0 = enqueue from Python every step
+
+
+WG_SIDE = os.environ.get("SR_TR_WG_SIDE", "0") != "0"  # A/B knob: the blocks' weight-gradient launches (and each stage's sr_tr_finalize_to) on a stream of their own
+_WG = {}
+
+
+def _wg_stream(device) -> "torch.cuda.Stream":
+    st = _WG.get(device)
+    if st is None:
+        st = _WG[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _ev_record(stream: "torch.cuda.Stream"):
+    """A point on `stream` that another stream can wait for later (_ev_wait): a plan-owned event inside a recording, a torch event otherwise."""
+    rec = L.recorder()
+    if rec is not None:
+        e = rec.event()
+        rec.add_event_record(stream.cuda_stream, e)
+        return e
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+def _ev_wait(stream: "torch.cuda.Stream", tok) -> None:
+    rec = L.recorder()
+    if rec is not None:
+        rec.add_stream_wait(stream.cuda_stream, tok)
+    else:
+        stream.wait_event(tok)
+
+
+def _edge(src: "torch.cuda.Stream", dst: "torch.cuda.Stream", ev: "torch.cuda.Event") -> None:
+    """dst waits for everything enqueued on src so far.  Inside a launch-plan recording the edge is recorded (events owned by the plan); otherwise a torch event."""
+    rec = L.recorder()
+    if rec is not None:
+        e = rec.event()
+        rec.add_event_record(src.cuda_stream, e)
+        rec.add_stream_wait(dst.cuda_stream, e)
+    else:
+        ev.record(src)
+        dst.wait_event(ev)
+
+
 # --------------------------------------------------------------------------- flat parameters
 class FlatParams:
     """All parameters of a model as views of one fp32 buffer (P) and their gradients as views of another (G)."""
@@ -239,8 +285,8 @@ class FinalMap:
         self.part = torch.zeros(max(self.size, 64), dtype=torch.float32, device=device)
 
     def run(self, G: Tensor) -> None:
-        L.check(L.lib().sr_tr_finalize_to(self.part.data_ptr(), self.d_src.data_ptr(), self.d_dst.data_ptr(), self.d_stride.data_ptr(), self.d_ns.data_ptr(),
-                                          self.d_scale.data_ptr(), G.data_ptr() + 4 * self.p0, self.n_items, _st()), "sr_tr_finalize_to")
+        _call(L.lib().sr_tr_finalize_to_args, L.SrTrFinalize, "sr_tr_finalize_to", arena=self.part.data_ptr(), src=self.d_src.data_ptr(), dst=self.d_dst.data_ptr(),
+              stride=self.d_stride.data_ptr(), ns=self.d_ns.data_ptr(), scale=self.d_scale.data_ptr(), grad=G.data_ptr() + 4 * self.p0, n=self.n_items)
 
 
 # --------------------------------------------------------------------------- index-form packers (cf. studiosr_amd/packing.py)
@@ -582,25 +628,30 @@ class BlockPlan:
         pp = lambda off: fm.part.data_ptr() + 4 * off  # noqa: E731
         s_a = None if sc_i is None else sc_i[0].data_ptr()
         s_m = None if sc_i is None else sc_i[1].data_ptr()
+        # operand set of this block's weight-gradient launch (see Scratch): wait until the launch that read it two blocks ago is through
+        main = torch.cuda.current_stream()
+        k = sc.turn & 1
+        sc.turn += 1
+        op = sc.ops[k]
+        if WG_SIDE and sc.wg_busy[k] is not None:
+            _ev_wait(main, sc.wg_busy[k])
+            sc.wg_busy[k] = None
         kw = {}
         if self.cab is not None:
-            kw = dict(y=self.y.data_ptr(), gate=self.gate.data_ptr(), dyc=sc.dyc.data_ptr(), dgate_part=sc.dgate_part.data_ptr())
+            kw = dict(y=self.y.data_ptr(), gate=self.gate.data_ptr(), dyc=op.dyc.data_ptr(), dgate_part=sc.dgate_part.data_ptr())
         _call(lib.sr_tr_tail_bwd, L.SrTrTailBwd, "sr_tr_tail_bwd", dout=d.data_ptr(), x1=self.x1.data_ptr(), gamma=fa[self.o_g2:].data_ptr(), beta=fa[self.o_b2:].data_ptr(),
-              wstream=wa[self.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(), n2w=sc.n2w.data_ptr(), doutw=sc.doutw.data_ptr(), gw=sc.gw.data_ptr(),
-              dhw=sc.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=sc.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
+              wstream=wa[self.o_tailb:].data_ptr(), s_a=s_a, s_m=s_m, dx1=sc.dx1.data_ptr(), n2w=op.n2w.data_ptr(), doutw=op.doutw.data_ptr(), gw=op.gw.data_ptr(),
+              dhw=op.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=op.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
         # HAB: the CAB branch of the backward (channel attention, the two data-gradient convs, GELU') only shares sr_tr_tail_bwd's outputs with the attention
         # backward and joins it in sr_tr_qkv_bwd: it runs on a side stream beside sr_tr_attn_bwd (two event edges per block; SR_TR_BWD_DUAL=0: one stream)
         dual = BWD_DUAL and not self.oca
         if dual:
-            main = torch.cuda.current_stream()
             side = _side_stream(main.device)
             if self._ev is None:
                 self._ev = (torch.cuda.Event(), torch.cuda.Event())
-            self._ev[0].record(main)
-            side.wait_event(self._ev[0])
+            _edge(main, side, self._ev[0])
             with torch.cuda.stream(side):
-                jobs_cab = self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp)
-                self._ev[1].record(side)
+                jobs_cab = self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
         dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
@@ -615,22 +666,29 @@ class BlockPlan:
             a.B, a.nwy, a.nwx, a.heads, a.wse, a.pad = B, H // 16, W // 16, HEADS, 24, 4
             L.check(lib.sr_tr_oca_fold(C.byref(a), 0, _st()), "sr_tr_oca_fold")
         elif dual:
-            main.wait_event(self._ev[1])
+            _edge(side, main, self._ev[1])
             jobs += jobs_cab
         else:
-            jobs += self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp)
+            jobs += self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
         _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
               dn1c=None if self.oca else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
-              n1w=sc.n1w.data_ptr(), dqkvw=sc.dqkvw.data_ptr(), ln_part=pp(self.f_ln1), ldn=CP, shift=self.shift, **g)
+              n1w=op.n1w.data_ptr(), dqkvw=op.dqkvw.data_ptr(), ln_part=pp(self.f_ln1), ldn=CP, shift=self.shift, **g)
+        wg = _wg_stream(main.device) if WG_SIDE else None
+        if wg is not None:  # the weight gradients only feed the stage's sr_tr_finalize_to: they leave the critical path of the backward pass
+            _ev_wait(wg, _ev_record(main))
+            torch.cuda.set_stream(wg)
         _wgrad([
-            dict(A=sc.dqkvw.data_ptr(), B=sc.n1w.data_ptr(), out=pp(self.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-            dict(A=sc.dx1sw.data_ptr(), B=self.o.data_ptr(), out=pp(self.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
-            dict(A=sc.dhw.data_ptr(), B=sc.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-            dict(A=sc.doutw.data_ptr(), B=sc.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            dict(A=op.dqkvw.data_ptr(), B=op.n1w.data_ptr(), out=pp(self.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            dict(A=op.dx1sw.data_ptr(), B=self.o.data_ptr(), out=pp(self.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
+            dict(A=op.dhw.data_ptr(), B=op.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            dict(A=op.doutw.data_ptr(), B=op.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
         ] + jobs)
+        if wg is not None:
+            sc.wg_busy[k] = _ev_record(wg)
+            torch.cuda.set_stream(main)
 
 
-    def _cab_backward(self, st: "Stage", B: int, H: int, W: int, T: int, lib, wa, fa, sc, pp) -> List[dict]:
+    def _cab_backward(self, st: "Stage", B: int, H: int, W: int, T: int, lib, wa, fa, sc, pp, op) -> List[dict]:
         """CAB backward (hat.py:41-52): launches on the current stream; returns its two weight-gradient jobs."""
         w1, b1, w2, b2 = self.ca
         mid_pre = self.mid_pre
@@ -638,14 +696,14 @@ class BlockPlan:
             mid_pre = sc.mid_pre
             _conv(self.n1, wa[self.o_c1:], fa[self.o_bc1:], mid_pre, B, H, W, CP, 64)
         _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
-              w2=w2.data_ptr(), b2=b2.data_ptr(), dy=sc.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
+              w2=w2.data_ptr(), b2=b2.data_ptr(), dy=op.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
               parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
-        _conv(sc.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
-        L.check(lib.sr_tr_gelu(mid_pre.data_ptr(), sc.dmid_g.data_ptr(), sc.mid_g.data_ptr(), sc.dmid.data_ptr(), T * 64, _st()), "sr_tr_gelu")
-        _conv(sc.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
+        _conv(op.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
+        _call(lib.sr_tr_gelu_args, L.SrTrGelu, "sr_tr_gelu", x=mid_pre.data_ptr(), dg=sc.dmid_g.data_ptr(), g=op.mid_g.data_ptr(), dx=op.dmid.data_ptr(), n=T * 64)
+        _conv(op.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
         return [
-            dict(A=sc.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
-            dict(A=sc.dyc.data_ptr(), B=sc.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
+            dict(A=op.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
+            dict(A=op.dyc.data_ptr(), B=op.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
         ]
 
 
@@ -667,6 +725,21 @@ class Scratch:
         self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))
         n = T // 256 * HEADS * 576 * 32  # OCAB: unfolded neighbourhoods
         self.vwinT, self.dkwin, self.dvwin = e(n), e(n), e(n)
+        # The operands of the weight-gradient launches exist twice: consecutive blocks of a backward pass alternate between the two sets, so that a block's
+        # sr_tr_wgrad can run on its own stream beside the NEXT block's kernels (which write the other set).  wg_busy[k]: the point on the weight-gradient
+        # stream behind the last launch that reads set k (None: free); `turn` counts the blocks of the running backward pass.
+        import types
+
+        def opset(first: bool):
+            if first:
+                return types.SimpleNamespace(n2w=self.n2w, doutw=self.doutw, dx1sw=self.dx1sw, dyc=self.dyc, n1w=self.n1w, gw=self.gw, dhw=self.dhw, dqkvw=self.dqkvw,
+                                             mid_g=self.mid_g, dmid=self.dmid)
+            return types.SimpleNamespace(n2w=e(T, CP), doutw=e(T, CP), dx1sw=e(T, CP), dyc=e(T, CP), n1w=e(T, CP), gw=e(T, HP), dhw=e(T, HP), dqkvw=e(T, 3 * CP),
+                                         mid_g=e(T, 64), dmid=e(T, 64))
+
+        self.ops = [opset(True), opset(False) if WG_SIDE else opset(True)]
+        self.wg_busy = [None, None]
+        self.turn = 0
 
 
 def _conv(x: Tensor, wp: Tensor, bias: Optional[Tensor], out: Tensor, B: int, H: int, W: int, cin_p: int, cout_p: int) -> None:
@@ -731,6 +804,7 @@ class Stage:
         self.geo = (B, H, W)
         self.sc = scratch
         self.ts = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in self.blocks]  # block outputs
+        self.dxs = [torch.empty(B, H, W, CP, dtype=torch.float32, device=dev) for _ in range(2)]  # gradient w.r.t. a block's input: two static buffers in turn
 
     def forward(self, x: Tensor, scales: Optional[Tensor]) -> Tensor:
         cur = x
@@ -739,16 +813,29 @@ class Stage:
             cur = self.ts[i]
         return cur
 
-    def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor], G: Optional[Tensor] = None) -> Tensor:
-        """dout: gradient of the stage output; returns the gradient of x (a fresh tensor); fills G for the stage's parameters."""
+    def backward(self, x: Tensor, dout: Tensor, scales: Optional[Tensor], G: Optional[Tensor] = None, join: bool = True) -> Tensor:
+        """dout: gradient of the stage output; returns the gradient of x (one of the stage's two static buffers); fills G for the stage's parameters.
+        join = False: the caller waits for the weight-gradient stream itself (backward_model: once, behind the last stage)."""
         B, H, W = self.geo
+        if join:
+            self.sc.turn, self.sc.wg_busy = 0, [None, None]
         d = dout.contiguous()
         for i in range(len(self.blocks) - 1, -1, -1):
             h = self.blocks[i]
-            dx = torch.empty(B, H, W, CP, dtype=torch.float32, device=d.device)
+            dx = self.dxs[i & 1]  # static (a recorded launch plan holds the pointers); the caller consumes the result before this stage's next backward
             h.backward(self, x if i == 0 else self.ts[i - 1], d, dx, None if (scales is None or h.oca) else scales[i])
             d = dx
-        self.fm.run(self.fp.G if G is None else G)
+        if WG_SIDE:  # the stage's gradients: partial sums -> G, behind the stage's weight-gradient launches on their stream
+            main = torch.cuda.current_stream()
+            wg = _wg_stream(main.device)
+            _ev_wait(wg, _ev_record(main))  # (LayerNorm / bias-table / channel-attention partials come from the main-stream kernels)
+            torch.cuda.set_stream(wg)
+            self.fm.run(self.fp.G if G is None else G)
+            torch.cuda.set_stream(main)
+            if join:
+                _ev_wait(main, _ev_record(wg))
+        else:
+            self.fm.run(self.fp.G if G is None else G)
         return d
 
 
@@ -769,7 +856,7 @@ class _StageFn(torch.autograd.Function):
             raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
         (x,) = ctx.saved_tensors
         G = stage.fp.grad_target()
-        dx = stage.backward(x, dout, ctx.scales, G)
+        dx = stage.backward(x, dout, ctx.scales, G).clone()  # (the stage's own buffer is static: autograd gets a tensor of its own)
         grads = stage.fp.grad_views(stage.params, G)
         return (dx, None, None) + grads
 
@@ -910,6 +997,7 @@ class HatPlan:
         self.packed_version = None
         self.scales_override = None
         self.gen = 0
+        self._plans = {}  # recorded launch plans: (direction, DropPath on / off[, gradient buffer]) -> _lib.LaunchPlan
     @staticmethod
     def supported(model) -> bool:
         try:
@@ -981,21 +1069,56 @@ class HatPlan:
         s = m.scale
         fa = self.fa.buf
         ops.ingest_nchw(x, self.xin, L.PAD_REFLECT if (H != Hin or W != Win) else L.PAD_NONE, *self.ing)
-        self.c_first.fwd(self, self.xin, self.first, B, H, W)
-        ops.layernorm(self.first, self.t0, fa[self.o_pe[0]:self.o_pe[0] + CP], fa[self.o_pe[1]:self.o_pe[1] + CP], C_REAL)
-        self.scales = None
+        # DropPath (hat.py:148,192-193): per block, per branch, per image Bernoulli(keep) / keep -- drawn with torch ops into a STATIC buffer (the launches that
+        # read it are recorded once)
         dpr = _drop_rates(m)
-        if m.training and any(r > 0.0 for r in dpr):  # DropPath (hat.py:148,192-193): per block, per branch, per image Bernoulli(keep) / keep
+        nb = len(self.stages[0].blocks) - int(self.with_oca)
+        new = None
+        if m.training and any(r > 0.0 for r in dpr):
             if getattr(self, "_keep", None) is None:
-                nb = len(self.stages[0].blocks) - int(self.with_oca)
                 self._keep = (1.0 - torch.tensor(dpr, dtype=torch.float32, device=x.device)).reshape(len(self.stages), nb, 1, 1)
             mask = (torch.rand(self._keep.shape[0], self._keep.shape[1], 2, B, device=x.device) < self._keep).to(torch.float32)
-            self.scales = (mask / self._keep.clamp_min(1e-30)).contiguous()  # keep == 0: the mask is all zero and stays unscaled, as timm's DropPath
+            new = mask / self._keep.clamp_min(1e-30)  # keep == 0: the mask is all zero and stays unscaled, as timm's DropPath
         if self.scales_override is not None:  # testing hook: [stages, blocks, 2, B]
-            self.scales = self.scales_override.to(torch.float32).contiguous()
+            new = self.scales_override.to(torch.float32)
+        if new is None:
+            self.scales = None
+        else:
+            if getattr(self, "_scales_buf", None) is None:
+                self._scales_buf = torch.empty(len(self.stages), nb, 2, B, dtype=torch.float32, device=x.device)
+            self._scales_buf.copy_(new)
+            self.scales = self._scales_buf
+        for st in self.stages:
+            st.gen += 1
+        self._planned(("fwd", self.scales is None), self._forward_body)
+        t = self.ups[-1] if self.ups else self.feat
+        h, w = self.hw_out
+        out = torch.empty(B, m.n_colors, Hin * s, Win * s, dtype=torch.float32, device=x.device)
+        self.c_last.fwd(self, t, out, B, h, w, out_mode=L.OUT_FINAL_NCHW, fin=(*self.fin, m.n_colors, Hin * s, Win * s))
+        return out
+
+    def _planned(self, key, body) -> None:
+        """Run a launch sequence whose arguments are static: the first time it is recorded (studiosr_amd/_lib.py PlanRecorder -> sr_plan_create), every time
+        it is enqueued by sr_plan_run on the current stream.  SR_TR_PLAN=0: enqueue from Python as round 4 did."""
+        if not PLAN:
+            body()
+            return
+        plan = self._plans.get(key)
+        if plan is None:
+            rec = L.PlanRecorder(_st())
+            with L.recording(rec):
+                body()
+            plan = self._plans[key] = rec.finish()
+        plan.run(_st())
+
+    def _forward_body(self) -> None:
+        """conv_first ... the last upsampling conv (hat.py:519-554 between the ingest and conv_last): static arguments only."""
+        B, H, W = self.geo
+        fa = self.fa.buf
+        self.c_first.fwd(self, self.xin, self.first, B, H, W)
+        ops.layernorm(self.first, self.t0, fa[self.o_pe[0]:self.o_pe[0] + CP], fa[self.o_pe[1]:self.o_pe[1] + CP], C_REAL)
         cur = self.t0
         for li, st in enumerate(self.stages):
-            st.gen += 1
             o = st.forward(cur, None if self.scales is None else self.scales[li])
             self.c_layers[li].fwd(self, o, self.tl[li], B, H, W, skip=cur)
             cur = self.tl[li]
@@ -1006,9 +1129,6 @@ class HatPlan:
         for (cp, r, cps_p), up in zip(self.c_up, self.ups):
             cp.fwd(self, t, up, B, h, w, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=r, cps_p=cps_p)
             t, h, w = up, h * r, w * r
-        out = torch.empty(B, m.n_colors, Hin * s, Win * s, dtype=torch.float32, device=x.device)
-        self.c_last.fwd(self, t, out, B, h, w, out_mode=L.OUT_FINAL_NCHW, fin=(*self.fin, m.n_colors, Hin * s, Win * s))
-        return out
 
     def backward_model(self, dout: Tensor, G: Optional[Tensor] = None) -> None:
         G = self.fp.G if G is None else G
@@ -1023,6 +1143,16 @@ class HatPlan:
             dout = torch.nn.functional.pad(dout, (0, w - dout.shape[3], 0, h - dout.shape[2]))
         # d(conv_last output) = dout * range, NHWC, zero beyond the cropped size and in the pad channels
         ops.ingest_nchw(dout, self.dY, L.PAD_NONE, self.fin[0], self.zero3)
+        self._planned(("bwd", self.scales is None, G.data_ptr()), lambda: self._backward_body(G))
+
+    def _backward_body(self, G: Tensor) -> None:
+        """Everything of the backward pass behind the ingest of the output gradient: static arguments only (G is part of the plan's key)."""
+        B, H, W = self.geo
+        lib = L.lib()
+        fa = self.fa.buf
+        h, w = self.hw_out
+        T = B * H * W
+        self.scratch.turn, self.scratch.wg_busy = 0, [None, None]
         jobs = self.c_last.wgrad_jobs(self, self.dY, 32, self.ups[-1] if self.ups else self.feat, B, h, w)
         d_cur = self.dupA[: B * h * w * 64].view(B, h, w, 64)
         self.c_last.dgrad(self, self.dY, d_cur, B, h, w)
@@ -1032,7 +1162,7 @@ class HatPlan:
             cp, r, cps_p = self.c_up[si]
             hi, wi = h // r, w // r
             dps = self.dps[: B * hi * wi * r * r * cps_p].view(B, hi, wi, r * r * cps_p)
-            L.check(lib.sr_tr_unshuffle(d_cur.data_ptr(), dps.data_ptr(), B, hi, wi, cps_p, r, _st()), "sr_tr_unshuffle")
+            _call(lib.sr_tr_unshuffle_args, L.SrTrUnshuffle, "sr_tr_unshuffle", src=d_cur.data_ptr(), dst=dps.data_ptr(), B=B, H=hi, W=wi, cps=cps_p, r=r)
             xin = self.ups[si - 1] if si > 0 else self.feat
             jobs = cp.wgrad_jobs(self, dps, r * r * cps_p, xin, B, hi, wi)
             d_prev = other[: B * hi * wi * 64].view(B, hi, wi, 64)
@@ -1040,7 +1170,7 @@ class HatPlan:
             _wgrad(jobs)
             other = self.dupA if other is self.dupB else self.dupB
             d_cur, h, w = d_prev, hi, wi
-        L.check(lib.sr_tr_lrelu_bwd(d_cur.data_ptr(), self.feat.data_ptr(), self.dpre.data_ptr(), 0.01, T * 64, _st()), "sr_tr_lrelu_bwd")
+        _call(lib.sr_tr_lrelu_bwd_args, L.SrTrLreluBwd, "sr_tr_lrelu_bwd", dy=d_cur.data_ptr(), y=self.feat.data_ptr(), dx=self.dpre.data_ptr(), slope=0.01, n=T * 64)
         jobs = self.c_before.wgrad_jobs(self, self.dpre, 64, self.body, B, H, W)
         self.c_before.dgrad(self, self.dpre, self.dbody, B, H, W)
         jobs += self.c_after.wgrad_jobs(self, self.dbody, CP, self.tn, B, H, W)
@@ -1057,15 +1187,18 @@ class HatPlan:
             jobs = self.c_layers[li].wgrad_jobs(self, dt, CP, st.ts[-1], B, H, W)
             self.c_layers[li].dgrad(self, dt, self.dcv, B, H, W)
             _wgrad(jobs)
-            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li], G)
+            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li], G, join=False)
             nxt = self.dtB if dt is self.dtA else self.dtA
-            L.check(lib.sr_tr_add(dx.data_ptr(), dt.data_ptr(), L.SR_F32, nxt.data_ptr(), T * CP, _st()), "sr_tr_add")
+            _call(lib.sr_tr_add_args, L.SrTrAdd, "sr_tr_add", a=dx.data_ptr(), b=dt.data_ptr(), b_dtype=L.SR_F32, out=nxt.data_ptr(), n=T * CP)
             dt = nxt
         dfirst = self.dtn  # (free again)
         _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=self.first.data_ptr(), dy=dt.data_ptr(), gamma=fa[self.o_pe[0]:].data_ptr(), dskip=self.dbody.data_ptr(),
               dx=dfirst.data_ptr(), ln_part=pp(self.f_pe), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=1, eps=1e-5)
         _wgrad(self.c_first.wgrad_jobs(self, dfirst, CP, self.xin, B, H, W))
         self.fm.run(G)
+        if WG_SIDE:  # the stages' weight gradients and finalize launches are through before the gradients are handed to autograd
+            main = torch.cuda.current_stream()
+            _ev_wait(main, _ev_record(_wg_stream(main.device)))
 
     def pack(self) -> None:
         """Packed operands <- current parameters: two sr_tr_gather launches (~130 MB of traffic) on EVERY recorded forward.  (Until round 5 the

@@ -43,7 +43,9 @@ def ingest_nchw(x: Tensor, out: Tensor, pad_mode: int, scale: Tensor, bias: Tens
 def layernorm(x: Tensor, out: Tensor, gamma: Tensor, beta: Tensor, C_real: int, eps: float = 1e-5) -> Tensor:
     Cp = x.shape[-1]
     M = x.numel() // Cp
-    L.check(L.lib().sr_layernorm_to(_p(x), _p(out), _dt(out), _p(gamma), _p(beta), M, C_real, Cp, eps, _stream()), "sr_layernorm")
+    a = L.SrLayernorm()  # (the argument-block form: recordable in a launch plan)
+    a.x, a.y, a.gamma, a.beta, a.y_dtype, a.M, a.C, a.Cp, a.eps = _p(x), _p(out), _p(gamma), _p(beta), _dt(out), M, C_real, Cp, eps
+    L.check(L.lib().sr_layernorm_to_args(C.byref(a), _stream()), "sr_layernorm")
     return out
 
 

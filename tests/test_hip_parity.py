@@ -1212,6 +1212,50 @@ def test_swin_block_stream_kernel_against_the_reference_block(shift):
     assert float((outs["stream"] - outs["unfused"]).pow(2).mean().sqrt()) <= 1.5e-2 * rms
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32x3"])
+def test_swin_block_persistent_workgroups_equal_one_workgroup_per_window(prec):
+    """SrSwinBlock.max_workgroups (ABI v10): a grid smaller than the window count makes every workgroup walk windows b, b + grid, ... with the next window's
+    rows fetched under the current result stores.  A window's arithmetic does not depend on who computes it: the output must equal the one-workgroup-per-window
+    launch bit for bit, for grids that divide the window count, that do not, and for a single workgroup; shifted block (mask path), in place and out of place."""
+    import os
+
+    from studiosr_amd.models import swinir as SW
+    from studiosr_amd.runtime import x3_mode
+
+    torch.manual_seed(0)
+    m = S.SwinIR(scale=2, depths=[2], num_heads=[6]).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    m = m.to(DEV).set_precision(prec)
+    cdt = torch.bfloat16 if prec == "bf16" else torch.float32
+    with x3_mode(prec == "fp32x3"):
+        lp = m._get_packed(cdt)["layers"][0]
+        geo, ws_ = lp["geo"], S.runtime.Workspace(torch.device(DEV))
+        x = torch.randn(3, 40, 24, geo.Cp, device=DEV)  # 3 x 5 x 3 = 45 windows
+        x[..., geo.C:] = 0
+        for bp in lp["blocks"]:
+            outs = {}
+            for wgs in (-1, 45, 16, 7, 1):
+                S.runtime.reset_knobs()
+                os.environ["SR_BLOCK_WGS"] = str(wgs)
+                try:
+                    o = torch.full_like(x, float("nan"))
+                    SW.run_swin_block(bp, geo, x, o, ws_, cdt, bp["shift"])
+                    xi = x.clone()
+                    SW.run_swin_block(bp, geo, xi, xi, ws_, cdt, bp["shift"])  # in place
+                    torch.cuda.synchronize()
+                finally:
+                    os.environ.pop("SR_BLOCK_WGS", None)
+                    S.runtime.reset_knobs()
+                assert torch.equal(o, xi), (wgs, "in place")
+                outs[wgs] = o
+            assert bool(torch.isfinite(outs[-1]).all())
+            for wgs, o in outs.items():
+                assert torch.equal(o, outs[-1]), wgs
+
+
 def test_swinfir_bf16_keeps_the_fft_in_fp32_at_dft_sized_images():
     """SwinFIR precision='bf16' on an image large enough (H >= 96, W >= 190) for sr_bgemm's bf16 path: the DFT-as-GEMM rFFT / irFFT of
     the SFB blocks must stay exact fp32 (the reference never runs torch.fft under bf16 autocast); checked against the oracle."""

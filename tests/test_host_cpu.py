@@ -42,7 +42,7 @@ def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() of every argument struct."""
     import subprocess
 
-    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrSwinLight", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd"]
+    structs = ["SrGemm", "SrConv3x3", "SrWindowAttn", "SrOcaAttn", "SrChannelAttn", "SrMlp", "SrSwinBlock", "SrSwinQkv", "SrSwinTail", "SrSwinLight", "SrRcab", "SrCab", "SrBgemm", "SrTrWgradJob", "SrTrAttnBwd", "SrTrAttnFwd", "SrTrOcaFold", "SrTrQkvFwd", "SrTrTailFwd", "SrTrTailBwd", "SrTrQkvBwd", "SrTrCaBwd", "SrTrLnBwd", "SrTrGelu", "SrTrAdd", "SrTrFinalize", "SrTrUnshuffle", "SrTrLreluBwd", "SrLayernorm", "SrPlanOp"]
     c = tmp_path / "sz.c"
     c.write_text('#include <stdio.h>\n#include "studiosr_hip.h"\nint main(){' + "".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs) + "return 0;}\n")
     exe = tmp_path / "sz"
@@ -417,3 +417,46 @@ def test_xcd_remap_is_a_bijection_with_contiguous_classes():
         for c in range(min(8, nwg)):
             mine = [items[t] for t in range(c, nwg, 8)]
             assert mine == list(range(mine[0], mine[0] + len(mine)))
+
+
+def test_launch_plan_recorder_classifies_calls_and_plans_validate():
+    """Launch plans (ABI v10, csrc/sr_plan.cpp; studiosr_amd/_lib.py): the recorder turns launches made through lib() into plan operations -- argument-block
+    calls become C operations (their blocks are COPIED by sr_plan_create), positional calls stay Python closures, streams become slots -- without enqueueing
+    anything (no GPU here: nothing may be launched).  sr_plan_create validates; a plan reports its operation and stream counts."""
+    import ctypes as C
+
+    import __graft_entry__ as G
+
+    if not os.path.exists(L.LIB_PATH):
+        G.build()
+    h = L.lib()
+    rec = L.PlanRecorder(main_stream=0x1000)
+    with L.recording(rec):
+        lib = L.lib()
+        assert lib is not h and lib.sr_abi_version() == L.ABI_VERSION  # queries pass through
+        a = L.SrTrGelu()
+        a.n = 64
+        assert lib.sr_tr_gelu_args(C.byref(a), 0x1000) == 0            # CALL1 on the main stream (slot 0)
+        e = rec.event()
+        rec.add_event_record(0x1000, e)
+        rec.add_stream_wait(0x2000, e)
+        w, c = L.SrWindowAttn(), L.SrCab()
+        assert lib.sr_hab_mid(C.byref(w), C.byref(c), 0x2000) == 0     # CALL2 on a side stream (slot 1)
+        jobs = (L.SrTrWgradJob * 2)()
+        assert lib.sr_tr_wgrad(jobs, 2, 0x1000) == 0                   # CALLI
+        assert lib.sr_tr_add(1, 2, 0, 3, 64, 0x1000) == 0              # positional: a Python closure
+    assert L.lib() is h and L.recorder() is None
+    kinds = [it[1].kind if it[0] == "op" else "py" for it in rec.items]
+    assert kinds == [L.PLAN_CALL1, L.PLAN_EVENT_RECORD, L.PLAN_STREAM_WAIT, L.PLAN_CALL2, L.PLAN_CALLI, "py"]
+    assert [it[1].stream for it in rec.items if it[0] == "op"] == [0, 0, 1, 1, 0] and rec.side == [0x2000] and rec.n_launches == 4
+    a.n = 0  # the plan owns copies of its argument blocks
+    plan = rec.finish()
+    assert [k for k, _ in plan.segments] == ["c", "py"]
+    seg = plan.segments[0][1]
+    assert h.sr_plan_ops(seg) == 5 and h.sr_plan_streams(seg) == 2
+    # validation
+    bad = (L.SrPlanOp * 1)()
+    bad[0].kind = L.PLAN_STREAM_WAIT
+    bad[0].ival = 3
+    assert not h.sr_plan_create(bad, 1, 1) and b"bad operation" in h.sr_last_error()
+    assert h.sr_plan_run(seg, (C.c_void_p * 1)(), 1) != 0 and b"streams" in h.sr_last_error()  # fewer streams than the plan uses: refused before anything is enqueued

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import studiosr_amd as S
 from studiosr_amd.optim import Adam
 dev = torch.device("cuda:0")
