@@ -196,8 +196,11 @@ SR_DEV void dma_row48(const float* base, int byte_off, unsigned lds_dst, int lan
 // The weight stream of one wave: slot s = fragments [12 s + 3 w, 12 s + 3 w + 3) of the packed block, ring of RING slots in registers.
 // Buffer loads: the fragment's byte offset is a scalar (soffset), the lane part one shared VGPR -- no per-load 64-bit address arithmetic.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#ifndef SR_W_AUX
+#define SR_W_AUX 0  // cache policy bits of the weight-fragment loads (experiment knob: 1 sc0, 2 nt, 16 sc1)
+#endif
 SR_DEV void buf_load_frag(Frag<bf16>& f, __amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index) {
-    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, 0));
+    f.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, SR_W_AUX));
 }
 SR_DEV void buf_load_frag(Frag<bf3>& f, __amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index) {  // per lane 8 hi | 8 lo (32 B)
     f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, frag_index * 2048, 0));

@@ -778,9 +778,11 @@ def _call(fn, struct, what: str, **kw) -> None:
 class Stage:
     """The blocks of one RHAG (six HABs, then the OCAB) with their gradient map; forward / backward as launch sequences."""
 
-    def __init__(self, fp: FlatParams, habs, ocab, rpi_sa: Tensor, rpi_oca: Tensor, conv_scale: float, wa: Arena, fa: Arena) -> None:
+    def __init__(self, fp: FlatParams, habs, ocab, rpi_sa: Tensor, rpi_oca: Tensor, conv_scale: float, wa: Arena, fa: Arena, extra=None) -> None:
+        """extra: a module whose parameters join the stage's gradient map (the RHAG's closing conv, hat.py:356: its weight gradient is finalised with the stage's, so
+        that a stage's backward leaves ALL of its layer's gradients complete -- what DistributedDataParallel's buckets need to start reducing)."""
         self.fp, self.wa, self.fa = fp, wa, fa
-        mods = list(habs) + ([ocab] if ocab is not None else [])
+        mods = list(habs) + ([ocab] if ocab is not None else []) + ([extra] if extra is not None else [])
         params = [p for b in mods for p in b.parameters()]
         p0 = min(fp.off(p) for p in params)
         p1 = max(fp.off(p) + (p.numel() + 3) // 4 * 4 for p in params)
@@ -893,6 +895,7 @@ class ConvPlan:
     def prepare(self, fm: FinalMap, B: int, H: int, W: int) -> None:
         """Gradient map of this conv's weight-gradient job at its (own) geometry: [ks][9][cout_p][cin_p] partial sums."""
         fp, w, b, rows, cout, cin, cout_p, cin_p = self.fp, self.w, self.b, self.rows, self.cout, self.cin, self.cout_p, self.cin_p
+        self.fm = fm  # the gradient map (and partial-sum arena) this conv's weight-gradient job writes into
         ks = self.ks = conv_ks(B, H, W)
         n_of = np.zeros(cout, dtype=np.int64)
         n_of[rows[rows >= 0]] = np.nonzero(rows >= 0)[0]
@@ -922,7 +925,7 @@ class ConvPlan:
                     ps_r=0, cps_p=0, act_slope=0.0, tile_rows=0)
 
     def wgrad_jobs(self, plan, dy: Tensor, lda: int, x: Tensor, B: int, H: int, W: int) -> List[dict]:
-        pp = lambda off: plan.fm.part.data_ptr() + 4 * off  # noqa: E731
+        pp = lambda off: self.fm.part.data_ptr() + 4 * off  # noqa: E731
         T = B * H * W
         f32 = torch.float32
         jobs = [dict(A=dy.data_ptr(), B=x.data_ptr(), out=pp(self.f_w), lda=lda, ldb=self.cin_p, Np=self.cout_p, Kp=self.cin_p, T=T, taps=9, H=H, W=W, ones_col=self.ones_col,
@@ -950,8 +953,86 @@ class _ModelFn(torch.autograd.Function):
         return (None, None) + plan.fp.grad_views(plan.fp.params, G)
 
 
+# The same step as a CHAIN of autograd nodes -- head (conv_first, patch_embed.norm), one per RHAG, tail (norm ... conv_last) -- each replaying its own launch
+# plan.  What it buys is the reference's data-parallel overlap (trainer.py:89-91: DistributedDataParallel): a node's backward returns ITS parameters' gradients
+# complete (every part of the backward pass finalises its own gradient map), so DDP's bucket hooks fire part by part, last RHAG first, and the bucketed
+# all-reduce runs on DDP's stream beside the launches of the RHAGs still to come -- with ONE node all 83 MB became ready at once, behind the last launch.
+# Tensors between the nodes are fresh aliases of the plan's static buffers; autograd hands a node's returned gradient tensor to the next node unchanged
+# (every intermediate has one consumer), which is checked (and repaired by a copy) against the buffer the recorded plans read.
+NODES = os.environ.get("SR_FAST_NODES", "1") != "0"  # A/B knob: 0 = the whole step as ONE autograd node (round 4)
+
+
+def _check_gen(plan, ctx) -> None:
+    if plan.gen != ctx.gen:
+        raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
+
+
+def _into(buf: Tensor, t: Tensor) -> None:
+    if t.data_ptr() != buf.data_ptr() or t.dtype != buf.dtype:
+        buf.copy_(t.reshape(buf.shape))
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        plan.gen += 1
+        ctx.plan, ctx.gen = plan, plan.gen
+        plan.begin_forward(x)
+        plan.run_fwd_head()
+        return plan.t0.view(plan.t0.shape)
+
+    @staticmethod
+    def backward(ctx, dt0):
+        plan = ctx.plan
+        _check_gen(plan, ctx)
+        G = plan.pass_target()
+        _into(plan.dt_in(-1), dt0)
+        plan.run_bwd_head(G)
+        return (None, None) + plan.fp.grad_views(plan.head_params, G)
+
+
+class _StageNodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cur, plan, li, *params):
+        ctx.plan, ctx.gen, ctx.li = plan, plan.gen, li
+        plan.run_fwd_stage(li)
+        return plan.tl[li].view(plan.tl[li].shape)
+
+    @staticmethod
+    def backward(ctx, dt):
+        plan, li = ctx.plan, ctx.li
+        _check_gen(plan, ctx)
+        G = plan.pass_target()
+        _into(plan.dt_in(li), dt)
+        plan.run_bwd_stage(li, G, True)
+        nxt = plan.dt_in(li - 1)
+        return (nxt.view(nxt.shape), None, None) + plan.fp.grad_views(plan.stages[li].params, G)
+
+
+class _TailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cur, plan, *params):
+        ctx.plan, ctx.gen = plan, plan.gen
+        plan.run_fwd_tail()
+        return plan.finish_forward()
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        _check_gen(plan, ctx)
+        G = plan.begin_backward(dout)
+        plan.run_bwd_tail(G)
+        dt = plan.dt_in(len(plan.stages) - 1)
+        return (dt.view(dt.shape), None) + plan.fp.grad_views(plan.tail_params, G)
+
+
 def run_model(plan: "HatPlan", x: Tensor) -> Tensor:
-    return _ModelFn.apply(x, plan, *plan.fp.params)
+    if not NODES:
+        return _ModelFn.apply(x, plan, *plan.fp.params)
+    t = _HeadFn.apply(x, plan, *plan.head_params)
+    for li, st in enumerate(plan.stages):
+        t = _StageNodeFn.apply(t, plan, li, *st.params)
+    return _TailFn.apply(t, plan, *plan.tail_params)
 
 # --------------------------------------------------------------------------- whole-model plan
 class HatPlan:
@@ -964,19 +1045,26 @@ class HatPlan:
         self.wa, self.fa = Arena(torch.bfloat16), Arena(torch.float32)
         with_oca = os.environ.get("SR_FAST_OCAB", "1") != "0"
         self.with_oca = with_oca
+        self.full = with_oca and os.environ.get("SR_FAST_FULL", "1") != "0"  # the whole model on fused launches (forward_model / backward_model, or the node chain)
         self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
-                             model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa) for layer in model.layers]
-        self.full = with_oca and os.environ.get("SR_FAST_FULL", "1") != "0"  # the whole model as ONE autograd node (forward_model / backward_model)
+                             model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa, extra=layer.conv if self.full else None) for layer in model.layers]
         # ---- everything outside the blocks (hat.py:519-554): conv_first, patch_embed.norm, the RHAG convs, norm, conv_after_body, the upsampling tail
         from . import packing
         from .models.swinir import final_affine, ingest_affine
 
         m = model
-        self.fm = FinalMap(self.fp, 0, self.fp.n)
-        self.fm.src[:] = -2  # the stages' maps own the block parameters
-        fm = self.fm
-        self.c_first = ConvPlan(self.fp, m.conv_first, 32, CP, self.wa, self.fa, fm, dgrad=False)
-        self.c_layers = [ConvPlan(self.fp, layer.conv, CP, CP, self.wa, self.fa, fm) for layer in m.layers]
+        # Gradient maps outside the blocks, one per part of the backward pass that completes a set of parameters: head (conv_first, patch_embed.norm: last to run),
+        # tail (norm, conv_after_body, conv_before_upsample, upsample, conv_last: first to run); a RHAG's closing conv belongs to its stage's map.  Each map spans
+        # the whole flat buffer and leaves what it does not own untouched (src = -2).
+        def model_map():
+            f = FinalMap(self.fp, 0, self.fp.n)
+            f.src[:] = -2
+            return f
+
+        self.fm_head, self.fm_tail = model_map(), model_map()
+        fm = self.fm_tail
+        self.c_first = ConvPlan(self.fp, m.conv_first, 32, CP, self.wa, self.fa, self.fm_head, dgrad=False)
+        self.c_layers = [ConvPlan(self.fp, layer.conv, CP, CP, self.wa, self.fa, st.fm if self.full else fm) for layer, st in zip(m.layers, self.stages)]
         self.c_after = ConvPlan(self.fp, m.conv_after_body, CP, CP, self.wa, self.fa, fm)
         self.c_before = ConvPlan(self.fp, m.conv_before_upsample[0], CP, 64, self.wa, self.fa, fm)
         self.c_up = []
@@ -997,7 +1085,14 @@ class HatPlan:
         self.packed_version = None
         self.scales_override = None
         self.gen = 0
-        self._plans = {}  # recorded launch plans: (direction, DropPath on / off[, gradient buffer]) -> _lib.LaunchPlan
+        self._plans = {}  # recorded launch plans: (part, DropPath on / off[, gradient buffer]) -> _lib.LaunchPlan
+        # parameters by the part of the step that owns (and completes the gradients of) them
+        self.head_params = list(m.conv_first.parameters()) + list(m.patch_embed.parameters())
+        self.tail_params = (list(m.norm.parameters()) + list(m.conv_after_body.parameters()) + list(m.conv_before_upsample.parameters()) + list(m.upsample.parameters()) +
+                            list(m.conv_last.parameters()))
+        if self.full:
+            owned = [id(p) for p in self.head_params + self.tail_params + [p for st in self.stages for p in st.params]]
+            assert len(owned) == len(set(owned)) == len(self.fp.params) and set(owned) == {id(p) for p in self.fp.params}, "every parameter belongs to exactly one part"
     @staticmethod
     def supported(model) -> bool:
         try:
@@ -1012,7 +1107,8 @@ class HatPlan:
             return
         assert self.geo is None, "one geometry per fast-training plan"
         dev = self.fp.P.device
-        fp, fm, m = self.fp, self.fm, self.model
+        fp, m = self.fp, self.model
+        fm, fm_head = self.fm_tail, self.fm_head
         nbw = B * H * W // 256
         # window groups of the OCAB's pass Q (one 4-wave workgroup per (group, head, 64 queries), one workgroup per CU): the largest divisor of the window count
         # that keeps the launch within one residency round of the 256 CUs (HAT x4 step at groups 8 / 16 / 32 / 64: 20.07 / 20.46 / 20.61 / 21.58 ms; SR_TR_GROUPS: A/B knob)
@@ -1020,10 +1116,12 @@ class HatPlan:
         while nbw % groups:
             groups -= 1
         self.scratch = Scratch(B, H, W, dev, groups)
+        for c, st in zip(self.c_layers, self.stages):  # (before the stage finishes its map: the RHAG's closing conv is part of it)
+            c.prepare(st.fm if self.full else fm, B, H, W)
         for s in self.stages:
             s.prepare(B, H, W, dev, self.scratch)
-        self.c_first.prepare(fm, B, H, W)
-        for c in self.c_layers + [self.c_after, self.c_before]:
+        self.c_first.prepare(fm_head, B, H, W)
+        for c in [self.c_after, self.c_before]:
             c.prepare(fm, B, H, W)
         h, w = H, W
         for cp, r, _ in self.c_up:
@@ -1032,11 +1130,12 @@ class HatPlan:
         self.c_last.prepare(fm, B, h, w)
         # LayerNorm partials of patch_embed.norm / norm
         nwg = B * H * W // 64
-        self.f_pe, self.f_nm = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
-        for f, norm in ((self.f_pe, m.patch_embed.norm), (self.f_nm, m.norm)):
-            fm.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
-            fm.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
+        self.f_pe, self.f_nm = fm_head.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
+        for mp, f, norm in ((fm_head, self.f_pe, m.patch_embed.norm), (fm, self.f_nm, m.norm)):
+            mp.put(fp.pidx(norm.weight), f + np.arange(C_REAL), 2 * CP, nwg)
+            mp.put(fp.pidx(norm.bias), f + CP + np.arange(C_REAL), 2 * CP, nwg)
         fm.finish(dev)
+        fm_head.finish(dev)
         T = B * H * W
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
@@ -1059,15 +1158,14 @@ class HatPlan:
         self.dtn, self.dtA, self.dtB, self.dcv = (e(B, H, W, CP, dt=f32) for _ in range(4))
         self.geo = (B, H, W)
 
-    # ------------------------------------------------------------------ whole-model launch sequences (hat.py:519-554)
-    def forward_model(self, x: Tensor) -> Tensor:
+    # ------------------------------------------------------------------ whole-model launch sequences (hat.py:519-554), in the parts the node chain runs them in
+    def begin_forward(self, x: Tensor) -> None:
+        """Everything of a forward pass that is NOT a recorded launch: the ingest of this batch, the DropPath draw."""
         from .models.train import _drop_rates
 
         m = self.model
         B, H, W = self.geo
         Hin, Win = x.shape[2], x.shape[3]
-        s = m.scale
-        fa = self.fa.buf
         ops.ingest_nchw(x, self.xin, L.PAD_REFLECT if (H != Hin or W != Win) else L.PAD_NONE, *self.ing)
         # DropPath (hat.py:148,192-193): per block, per branch, per image Bernoulli(keep) / keep -- drawn with torch ops into a STATIC buffer (the launches that
         # read it are recorded once)
@@ -1090,12 +1188,36 @@ class HatPlan:
             self.scales = self._scales_buf
         for st in self.stages:
             st.gen += 1
-        self._planned(("fwd", self.scales is None), self._forward_body)
+        self._out_hw = (Hin, Win)
+
+    def finish_forward(self) -> Tensor:
+        """conv_last into a FRESH output tensor (the one launch of the forward whose arguments change from step to step)."""
+        m = self.model
+        B = self.geo[0]
+        Hin, Win = self._out_hw
+        s = m.scale
         t = self.ups[-1] if self.ups else self.feat
         h, w = self.hw_out
-        out = torch.empty(B, m.n_colors, Hin * s, Win * s, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, m.n_colors, Hin * s, Win * s, dtype=torch.float32, device=t.device)
         self.c_last.fwd(self, t, out, B, h, w, out_mode=L.OUT_FINAL_NCHW, fin=(*self.fin, m.n_colors, Hin * s, Win * s))
         return out
+
+    def run_fwd_head(self) -> None:
+        self._planned(("fwd_head",), self._fwd_head)
+
+    def run_fwd_stage(self, li: int) -> None:
+        self._planned(("fwd_stage", li, self.scales is None), lambda: self._fwd_stage(li))
+
+    def run_fwd_tail(self) -> None:
+        self._planned(("fwd_tail",), self._fwd_tail)
+
+    def forward_model(self, x: Tensor) -> Tensor:
+        self.begin_forward(x)
+        self.run_fwd_head()
+        for li in range(len(self.stages)):
+            self.run_fwd_stage(li)
+        self.run_fwd_tail()
+        return self.finish_forward()
 
     def _planned(self, key, body) -> None:
         """Run a launch sequence whose arguments are static: the first time it is recorded (studiosr_amd/_lib.py PlanRecorder -> sr_plan_create), every time
@@ -1111,17 +1233,26 @@ class HatPlan:
             plan = self._plans[key] = rec.finish()
         plan.run(_st())
 
-    def _forward_body(self) -> None:
-        """conv_first ... the last upsampling conv (hat.py:519-554 between the ingest and conv_last): static arguments only."""
+    def _fwd_head(self) -> None:
+        """conv_first + patch_embed.norm (hat.py:531-536): static arguments only."""
         B, H, W = self.geo
         fa = self.fa.buf
         self.c_first.fwd(self, self.xin, self.first, B, H, W)
         ops.layernorm(self.first, self.t0, fa[self.o_pe[0]:self.o_pe[0] + CP], fa[self.o_pe[1]:self.o_pe[1] + CP], C_REAL)
-        cur = self.t0
-        for li, st in enumerate(self.stages):
-            o = st.forward(cur, None if self.scales is None else self.scales[li])
-            self.c_layers[li].fwd(self, o, self.tl[li], B, H, W, skip=cur)
-            cur = self.tl[li]
+
+    def _fwd_stage(self, li: int) -> None:
+        """One RHAG (hat.py:350-357): its blocks, its closing conv, the residual."""
+        B, H, W = self.geo
+        st = self.stages[li]
+        cur = self.t0 if li == 0 else self.tl[li - 1]
+        o = st.forward(cur, None if self.scales is None else self.scales[li])
+        self.c_layers[li].fwd(self, o, self.tl[li], B, H, W, skip=cur)
+
+    def _fwd_tail(self) -> None:
+        """norm, conv_after_body (+ conv_first's output), conv_before_upsample, the upsampling convs (hat.py:537-552 up to conv_last)."""
+        B, H, W = self.geo
+        fa = self.fa.buf
+        cur = self.tl[-1] if self.tl else self.t0
         ops.layernorm(cur, self.tn, fa[self.o_nm[0]:self.o_nm[0] + CP], fa[self.o_nm[1]:self.o_nm[1] + CP], C_REAL)
         self.c_after.fwd(self, self.tn, self.body, B, H, W, skip=self.first)
         self.c_before.fwd(self, self.body, self.feat, B, H, W, act=L.ACT_LRELU)
@@ -1130,23 +1261,47 @@ class HatPlan:
             cp.fwd(self, t, up, B, h, w, out_mode=L.OUT_PIXEL_SHUFFLE, ps_r=r, cps_p=cps_p)
             t, h, w = up, h * r, w * r
 
-    def backward_model(self, dout: Tensor, G: Optional[Tensor] = None) -> None:
-        G = self.fp.G if G is None else G
-        m = self.model
+    def begin_backward(self, dout: Tensor, G: Optional[Tensor] = None) -> Tensor:
+        """Everything of a backward pass that is NOT a recorded launch: WHERE this pass writes the gradients (decided once per pass: FlatParams.grad_target looks at
+        the parameters' .grad, which the pass itself sets part by part) and the ingest of the output gradient."""
+        G = self.fp.grad_target() if G is None else G
+        self._G_pass = (self.gen, G)
         B, H, W = self.geo
-        lib = L.lib()
-        fa = self.fa.buf
         h, w = self.hw_out
-        T = B * H * W
         dout = dout.contiguous().to(torch.float32)
         if dout.shape[2] != h or dout.shape[3] != w:  # reflect-padded input (hat.py:544): the output was cropped, its gradient is zero beyond the crop
             dout = torch.nn.functional.pad(dout, (0, w - dout.shape[3], 0, h - dout.shape[2]))
         # d(conv_last output) = dout * range, NHWC, zero beyond the cropped size and in the pad channels
         ops.ingest_nchw(dout, self.dY, L.PAD_NONE, self.fin[0], self.zero3)
-        self._planned(("bwd", self.scales is None, G.data_ptr()), lambda: self._backward_body(G))
+        return G
 
-    def _backward_body(self, G: Tensor) -> None:
-        """Everything of the backward pass behind the ingest of the output gradient: static arguments only (G is part of the plan's key)."""
+    def pass_target(self) -> Tensor:
+        gen, G = getattr(self, "_G_pass", (None, None))
+        assert gen == self.gen and G is not None, "the backward pass has not begun (the tail node runs first)"
+        return G
+
+    def dt_in(self, li: int) -> Tensor:
+        """Gradient of RHAG li's OUTPUT (two static buffers in turn; li = -1: the gradient of the first RHAG's input, which the head part reads)."""
+        return (self.dtA, self.dtB)[(len(self.stages) - 1 - li) & 1]
+
+    def run_bwd_tail(self, G: Tensor) -> None:
+        self._planned(("bwd_tail", G.data_ptr()), lambda: self._bwd_tail(G))
+
+    def run_bwd_stage(self, li: int, G: Tensor, join: bool) -> None:
+        self._planned(("bwd_stage", li, self.scales is None, G.data_ptr(), join), lambda: self._bwd_stage(li, G, join))
+
+    def run_bwd_head(self, G: Tensor) -> None:
+        self._planned(("bwd_head", G.data_ptr()), lambda: self._bwd_head(G))
+
+    def backward_model(self, dout: Tensor, G: Optional[Tensor] = None) -> None:
+        G = self.begin_backward(dout, G)
+        self.run_bwd_tail(G)
+        for li in range(len(self.stages) - 1, -1, -1):
+            self.run_bwd_stage(li, G, False)
+        self.run_bwd_head(G)
+
+    def _bwd_tail(self, G: Tensor) -> None:
+        """Backward of conv_last ... norm: leaves the gradient of the last RHAG's output in dt_in(last) and the tail parameters' gradients complete in G."""
         B, H, W = self.geo
         lib = L.lib()
         fa = self.fa.buf
@@ -1176,26 +1331,37 @@ class HatPlan:
         jobs += self.c_after.wgrad_jobs(self, self.dbody, CP, self.tn, B, H, W)
         self.c_after.dgrad(self, self.dbody, self.dtn, B, H, W)
         _wgrad(jobs)
-        pp = lambda off: self.fm.part.data_ptr() + 4 * off  # noqa: E731
-        dt = self.dtA
         last = self.tl[-1] if self.tl else self.t0
-        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=last.data_ptr(), dy=self.dtn.data_ptr(), gamma=fa[self.o_nm[0]:].data_ptr(), dskip=None, dx=dt.data_ptr(),
-              ln_part=pp(self.f_nm), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=0, eps=1e-5)
-        for li in range(len(self.stages) - 1, -1, -1):
-            st = self.stages[li]
-            cur_in = self.t0 if li == 0 else self.tl[li - 1]
-            jobs = self.c_layers[li].wgrad_jobs(self, dt, CP, st.ts[-1], B, H, W)
-            self.c_layers[li].dgrad(self, dt, self.dcv, B, H, W)
-            _wgrad(jobs)
-            dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li], G, join=False)
-            nxt = self.dtB if dt is self.dtA else self.dtA
-            _call(lib.sr_tr_add_args, L.SrTrAdd, "sr_tr_add", a=dx.data_ptr(), b=dt.data_ptr(), b_dtype=L.SR_F32, out=nxt.data_ptr(), n=T * CP)
-            dt = nxt
+        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=last.data_ptr(), dy=self.dtn.data_ptr(), gamma=fa[self.o_nm[0]:].data_ptr(), dskip=None,
+              dx=self.dt_in(len(self.stages) - 1).data_ptr(), ln_part=self.fm_tail.part.data_ptr() + 4 * self.f_nm, M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=0, eps=1e-5)
+        self.fm_tail.run(G)
+
+    def _bwd_stage(self, li: int, G: Tensor, join: bool) -> None:
+        """Backward of RHAG li: dt_in(li) -> dt_in(li - 1); the RHAG's gradients (blocks AND closing conv) complete in G (join: also waited for, when the
+        weight gradients run on their own stream)."""
+        B, H, W = self.geo
+        lib = L.lib()
+        T = B * H * W
+        st = self.stages[li]
+        dt, nxt = self.dt_in(li), self.dt_in(li - 1)
+        cur_in = self.t0 if li == 0 else self.tl[li - 1]
+        jobs = self.c_layers[li].wgrad_jobs(self, dt, CP, st.ts[-1], B, H, W)
+        self.c_layers[li].dgrad(self, dt, self.dcv, B, H, W)
+        _wgrad(jobs)
+        dx = st.backward(cur_in, self.dcv, None if self.scales is None else self.scales[li], G, join=join)
+        _call(lib.sr_tr_add_args, L.SrTrAdd, "sr_tr_add", a=dx.data_ptr(), b=dt.data_ptr(), b_dtype=L.SR_F32, out=nxt.data_ptr(), n=T * CP)
+
+    def _bwd_head(self, G: Tensor) -> None:
+        """Backward of patch_embed.norm + conv_first (the gradient of conv_first's output also arrives from conv_after_body's skip: dbody)."""
+        B, H, W = self.geo
+        lib = L.lib()
+        fa = self.fa.buf
+        T = B * H * W
         dfirst = self.dtn  # (free again)
-        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=self.first.data_ptr(), dy=dt.data_ptr(), gamma=fa[self.o_pe[0]:].data_ptr(), dskip=self.dbody.data_ptr(),
-              dx=dfirst.data_ptr(), ln_part=pp(self.f_pe), M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=1, eps=1e-5)
+        _call(lib.sr_tr_ln_bwd, L.SrTrLnBwd, "sr_tr_ln_bwd", x=self.first.data_ptr(), dy=self.dt_in(-1).data_ptr(), gamma=fa[self.o_pe[0]:].data_ptr(), dskip=self.dbody.data_ptr(),
+              dx=dfirst.data_ptr(), ln_part=self.fm_head.part.data_ptr() + 4 * self.f_pe, M=T, C=C_REAL, Cp=CP, ld=CP, dy_bf16=0, dskip_bf16=1, eps=1e-5)
         _wgrad(self.c_first.wgrad_jobs(self, dfirst, CP, self.xin, B, H, W))
-        self.fm.run(G)
+        self.fm_head.run(G)
         if WG_SIDE:  # the stages' weight gradients and finalize launches are through before the gradients are handed to autograd
             main = torch.cuda.current_stream()
             _ev_wait(main, _ev_record(_wg_stream(main.device)))

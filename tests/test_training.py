@@ -672,6 +672,81 @@ dist.barrier(); dist.destroy_process_group(); print("DDP_OK", worst)
     assert p.returncode == 0 and p.stdout.count("DDP_OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_fused_training_gradient_reduction_overlaps_the_backward_pass(tmp_path):
+    """trainer.py:89-91 (DistributedDataParallel: bucketed all-reduce overlapped with backward) on the fused path: the step is a CHAIN of autograd nodes
+    (fasttrain.py: head, one per RHAG, tail), each returning its own parameters' gradients complete, so DDP's buckets fire while RHAGs are still to be
+    enqueued.  Two ranks (gloo, both on this GPU), two RHAGs, 1 MB buckets: (1) the FIRST bucket's all-reduce is launched BEFORE the launches of the first
+    RHAG's backward and of the head are enqueued (host order = enqueue order: the reduction runs beside them); (2) the averaged gradients equal the mean of
+    the two single-process fused gradients; (3) with ONE node (SR_FAST_NODES=0) every bucket fires behind the last backward launch -- the contrast."""
+    script = tmp_path / "ddp_overlap.py"
+    script.write_text(f"""
+import os, sys, torch, torch.distributed as dist, torch.nn.functional as F
+sys.path.insert(0, {ROOT!r})
+import studiosr_amd as S
+from studiosr_amd import fasttrain as FT
+from torch.nn.parallel import DistributedDataParallel as DDP
+from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+rank = int(os.environ["RANK"]); dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+torch.manual_seed(0)
+m = S.HAT(scale=2, depths=[1, 1], num_heads=[6, 6], drop_path_rate=0.0).to(dev).train()
+g = torch.Generator().manual_seed(5)
+x, t = torch.rand(4, 3, 32, 32, generator=g).to(dev), torch.rand(4, 3, 64, 64, generator=g).to(dev)
+def step(net, xs, ts):
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = F.l1_loss(net(xs).float(), ts)
+    loss.backward()
+single = []
+for r in range(2):
+    m.zero_grad(set_to_none=True)
+    step(m, x[2 * r: 2 * r + 2], t[2 * r: 2 * r + 2])
+    single.append([p.grad.clone() for p in m.parameters()])
+plan = m._fast_plan
+assert plan is not None and plan.full
+order = []
+for name in ("run_bwd_tail", "run_bwd_stage", "run_bwd_head"):
+    def wrap(f, name=name):
+        def g_(*a, **k):
+            order.append((name,) + tuple(a[:1] if name == "run_bwd_stage" else ()))
+            return f(*a, **k)
+        return g_
+    setattr(plan, name, wrap(getattr(plan, name)))
+m.zero_grad(set_to_none=True)
+ddp = DDP(m, device_ids=[0], bucket_cap_mb=1)
+def hook(state, bucket):
+    order.append(("bucket", bucket.index()))
+    return default_hooks.allreduce_hook(state, bucket)
+ddp.register_comm_hook(None, hook)
+for it in range(2):  # (DDP rebuilds its buckets in gradient-arrival order after the first iteration)
+    order.clear()
+    m.zero_grad(set_to_none=True)
+    step(ddp, x[2 * rank: 2 * rank + 2], t[2 * rank: 2 * rank + 2])
+names = [o[0] for o in order]
+nodes = FT.NODES
+if nodes:
+    assert names.index("bucket") < names.index("run_bwd_head"), order
+    assert names.index("bucket") < order.index(("run_bwd_stage", 0)), order
+else:
+    assert names.index("bucket") > names.index("run_bwd_head"), order
+worst = 0.0
+for (n, p), a, b in zip(m.named_parameters(), *single):
+    ref = (a + b) / 2
+    tol = 5e-2 if n.endswith("relative_position_bias_table") else 1e-4
+    e = float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-9)
+    assert e < tol, (n, e)
+    worst = max(worst, e)
+dist.barrier(); dist.destroy_process_group()
+os.write(1, f"\\nOVERLAP_OK_{{int(nodes)}}_R{{rank}} worst {{worst:.2e}} buckets {{sum(n == 'bucket' for n in names)}}\\n".encode())  # one write per rank: the ranks share the pipe
+""")
+    for nodes, port in (("1", "29631"), ("0", "29633")):
+        env = dict(os.environ, SR_FAST_NODES=nodes)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0 and all(f"OVERLAP_OK_{nodes}_R{r}" in p.stdout for r in (0, 1)), p.stdout[-2000:] + p.stderr[-4000:]
+
+
 @pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass")])
 def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
     """sr_tr_attn_bwd (swinir.py:83-102 / hat.py:90-107 under loss.backward()) on 16 x 16 windows against torch autograd of softmax(q k^T + table[rpi] + mask) v on
