@@ -95,16 +95,20 @@ EXECUTED_FLOP_PER_WINDOW = 2496 * 16384.0
 
 def profiled_clock_ghz():
     """Shader clock the chip holds under the dominant kernel, from the committed diagnostic run (profiles/*_block_kernel_clock.txt,
-    tools/wgtrace_blk3.py on a -DSR_WGTRACE build: s_memtime cycles / s_memrealtime time of every workgroup, median).  None if absent."""
+    tools/wgtrace_blk3.py on a -DSR_WGTRACE build: s_memtime cycles / s_memrealtime time of every workgroup, median).  The profile carries the hash of
+    the kernel sources it was taken on (`# kernel_src_sha16 = ...`); a profile of other sources (or without the line) is stale and not quoted: None."""
     import glob
     import re
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_block_kernel_clock.txt")))
-    for line in (open(files[-1]) if files else []):
-        m = re.search(r"clock_ghz_median\s*=\s*([0-9.]+)", line)
-        if m:
-            return float(m.group(1))
-    return None
+    if not files:
+        return None
+    text = open(files[-1]).read()
+    m0 = re.search(r"#\s*kernel_src_sha16\s*=\s*([0-9a-f]+)", text)
+    if not m0 or m0.group(1) != dominant_kernel_src_sha16():
+        return None
+    m = re.search(r"clock_ghz_median\s*=\s*([0-9.]+)", text)
+    return float(m.group(1)) if m else None
 
 
 DOMINANT_KERNEL_SOURCES = ("studiosr_amd/csrc/sr_swin_block3.hip", "studiosr_amd/csrc/sr_swin_stream.h", "studiosr_amd/csrc/sr_common.h")
@@ -326,7 +330,8 @@ def run_train(args, device, rank, world) -> None:
     import studiosr_amd as S
 
     torch.manual_seed(0)
-    model = S.HAT(scale=4).to(device).train()
+    kind = {"hat": "HAT", "swinir": "SwinIR"}[args.model]
+    model = getattr(S, kind)(scale=4).to(device).train()  # reference defaults (hat.py:389-406 / swinir.py:259-274)
     cfg = model.get_training_config()
     from studiosr_amd.optim import Adam  # torch.optim.Adam (what studiosr_amd.Trainer builds): one flat launch on the fused path
 
@@ -367,13 +372,17 @@ def run_train(args, device, rank, world) -> None:
         elapsed = float(t.item())
     if rank == 0:
         dt = elapsed / steps
-        tflops = 3 * 207.76e9 * per_rank * world / dt / 1e12
+        gf_fwd = {"hat": 207.76e9, "swinir": 107.11e9}[args.model]  # forward GFLOP per 64 x 64 training patch (SwinIR: train mode does not pad 64 -> 72)
+        tflops = 3 * gf_fwd * per_rank * world / dt / 1e12
+        fused = getattr(model, "_fast_plan", None) is not None
         print(json.dumps({
-            "metric": "training samples/sec at HAT x4, 64x64 LR patches, L1 + Adam step", "value": round(per_rank * world / dt, 3), "unit": "samples/s", "n_gpus": world,
+            "metric": f"training samples/sec at {kind} x4, 64x64 LR patches, L1 + Adam step", "value": round(per_rank * world / dt, 3), "unit": "samples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic", "config": {"workload": "HAT x4 (embed 180, 6x(6 HAB + OCAB), ws 16) training step: forward + backward + Adam, per-rank batch 4, 64x64 LR / 256x256 HR",
+            "data": "synthetic", "config": {"workload": ("HAT x4 (embed 180, 6x(6 HAB + OCAB), ws 16)" if args.model == "hat" else "SwinIR x4 (embed 180, 6x6 blocks, ws 8)") +
+                                                         " training step: forward + backward + Adam, per-rank batch 4, 64x64 LR / 256x256 HR",
                                              "global_batch": per_rank * world, "parallelism": f"ddp{world}" if world > 1 else "single",
-                                             "path": "fused launch sequence (studiosr_amd/fasttrain.py, C ABI v7)" if getattr(model, "_fast_plan", None) is not None else "generic engine"},
+                                             "path": ("fused launch sequences replayed from C launch plans, one autograd node per RHAG (studiosr_amd/fasttrain.py, C ABI v10 sr_plan_run)" if fused else
+                                                      "generic engine (one strided batched GEMM / row kernel per op, studiosr_amd/autograd.py)")},
             "final_loss": loss.item(),
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": round(tflops / (2500.0 * world), 4), "traffic": None,
                          "note": "bf16 operands / fp32 accumulate for the contractions (autocast), fp32 everywhere else; against the fp32 MFMA peak (157.3 TFLOP/s) the same step is "
@@ -394,6 +403,7 @@ def main() -> None:
                     help="tiles: the headline metric (independent 64x64 tiles); strips: BASELINE config 4, ONE large LR image cut into one row strip per GPU with per-layer halo exchange; "
                          "train: BASELINE config 5, HAT x4 training step, per-rank batch 4, DistributedDataParallel over RCCL")
     ap.add_argument("--size", type=int, default=2048, help="--mode strips: LR image side")
+    ap.add_argument("--model", choices=["hat", "swinir"], default="hat", help="--mode train: HAT x4 (BASELINE config 5) or SwinIR x4 (swinir.py:391-402; generic engine)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -528,7 +538,7 @@ def main() -> None:
             return fwd(inp)
 
         st1 = torch.cuda.Stream()
-        model.part_batches = one_parts = 4
+        model.part_batches = one_parts = int(os.environ.get("SR_BENCH_ONE_PARTS", "4"))  # (the override is for experiments only)
         try:
             with torch.cuda.stream(st1):
                 gf1 = GraphedForward(fwd_1, x)

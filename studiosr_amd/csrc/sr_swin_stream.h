@@ -249,6 +249,28 @@ struct WStream {
             compute(c, 0, r[s % RING], a0);
             if (c + 1 < NST) loada(c + 1, 0, a0);
             compute(c, 1, r[s % RING], a1);
+#ifdef SR_EXP_SGB
+            // the step as written: [weight slot loads][a1 reads][MFMAs of half 0][next a0 reads][MFMAs of half 1] -- the machine scheduler otherwise sinks the
+            // fragment reads to just before their first use (profiles/r05_block_kernel_ablation.txt)
+            {
+                constexpr int FR = (int)sizeof(Frag<T>) / 16;  // ds_read_b128 per fragment, MFMAs per product
+                constexpr int MM = FR == 1 ? 6 : 18;
+                if (s + DIST < NS) __builtin_amdgcn_sched_group_barrier(0x020, LOADS_PER_SLOT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * FR, 0);
+#if SR_EXP_SGB == 2
+                for (int q = 0; q < 2; ++q) {  // the next fragments' reads after the first third of a half's MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, MM / 3, 0);
+                    if (q == 1 && c + 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2 * FR, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MM - MM / 3, 0);
+                    if (q == 0 && c + 1 < NST) { }
+                }
+#else
+                __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+                if (c + 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2 * FR, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+#endif
+            }
+#endif
 #ifndef SR_EXP_NOSB
             __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -12,6 +12,10 @@ import studiosr_amd as S
 import studiosr_amd._lib as L
 from studiosr_amd.models import swinir as SW
 
+os.environ.setdefault("SR_BLOCK_WGS", "-1")  # one workgroup per window also at B = 16 (the lifetimes below are per window)
+import bench  # noqa: E402  (the hash bench.py checks the profile against)
+
+print(f"# kernel_src_sha16 = {bench.dominant_kernel_src_sha16()}")
 dev = torch.device("cuda")
 cdt = torch.bfloat16
 m = S.SwinIR(scale=4, depths=[2], num_heads=[6]).eval().to(dev).set_precision("bf16")
