@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256 * NTEAM, NTEAM == 1 ? 3 : 3) void k_team(const 
 
 // ------------------------------------------------------------------------------------------------ G
 // 4 waves, two windows: per step and wave 8 m-tiles x 3 n-tiles = 24 MFMAs per 3 weight fragments.
-template <int DIST>
-__global__ __launch_bounds__(256, 1) void k_g(const Frag* W, const Frag* Ain, float* out, int nslot) {
+template <int DIST, int WGS = 1>  // WGS = 2 (round 5): the same tile at TWO workgroups per CU (48 KiB of LDS each): four windows resident per CU, weights fetched once per two
+__global__ __launch_bounds__(256, WGS) void k_g(const Frag* W, const Frag* Ain, float* out, int nslot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag* Aimg = reinterpret_cast<Frag*>(smem);  // [24][128]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -499,6 +499,15 @@ int main(int argc, char** argv) {
     row("cur d3", [&](int nw) { hipLaunchKernelGGL(k_cur<3>, dim3(nw), dim3(256), lds_cur, 0, W, A, out, NSLOT); });
     row("G d3", [&](int nw) { hipLaunchKernelGGL(k_g<3>, dim3(nw / 2), dim3(256), lds_g, 0, W, A, out, NSLOT); });
     row("A m0", [&](int nw) { hipLaunchKernelGGL(k_a<0>, dim3(nw / 2), dim3(512), lds_a, 0, W, A, out, NSLOT); });
+    {
+        auto kg2 = k_g<3, 2>;
+        const int lds_g2 = 24 * 128 * 16 + 1024;
+        CK(hipFuncSetAttribute((const void*)kg2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g2));
+        row("G2 d3", [&](int nw) { hipLaunchKernelGGL(kg2, dim3(nw / 2), dim3(256), lds_g2, 0, W, A, out, NSLOT); });
+        auto kg22 = k_g<2, 2>;
+        CK(hipFuncSetAttribute((const void*)kg22, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g2));
+        row("G2 d2", [&](int nw) { hipLaunchKernelGGL(kg22, dim3(nw / 2), dim3(256), lds_g2, 0, W, A, out, NSLOT); });
+    }
 #define TEAM(W0, NT, SY) do { auto kf = k_team<W0, NT, SY>; const int lds = NT * 50 * 1024; CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         char nm[64]; snprintf(nm, 64, "t%d %s s%d", NT, W0 ? "w0" : "ws", SY); \
         rows.push_back({nm, [=](int nw) { hipLaunchKernelGGL(kf, dim3(nw / NT), dim3(256 * NT), lds, 0, W, A, out, NSLOT); }}); } while (0)
