@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256 * NTEAM, NTEAM == 1 ? 3 : 3) void k_team(const 
 
 // ------------------------------------------------------------------------------------------------ G
 // 4 waves, two windows: per step and wave 8 m-tiles x 3 n-tiles = 24 MFMAs per 3 weight fragments.
-template <int DIST, int WGS = 1>  // WGS = 2 (round 5): the same tile at TWO workgroups per CU (48 KiB of LDS each): four windows resident per CU, weights fetched once per two
+template <int DIST, int WGS = 1, int V = 0, int BURST = 1, bool BAR = false>  // V / BURST / BAR: synthetic non-GEMM work as k_curv (V v_fma per step per WINDOW).  WGS = 2 (round 5): the same tile at TWO workgroups per CU (48 KiB of LDS each): four windows resident per CU, weights fetched once per two
 __global__ __launch_bounds__(256, WGS) void k_g(const Frag* W, const Frag* Ain, float* out, int nslot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Frag* Aimg = reinterpret_cast<Frag*>(smem);  // [24][128]
@@ -321,10 +321,19 @@ __global__ __launch_bounds__(256, WGS) void k_g(const Frag* W, const Frag* Ain, 
     for (int s = 0; s < DIST; ++s) loadb(s, ring[s]);
     Frag aq[2][2];
     loada(0, 0, aq[0]);
+    float vx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vx[i] = (float)(lane + i);
     for (int s0 = 0; s0 < nslot; s0 += (DIST + 1)) {
 #pragma unroll
         for (int u = 0; u < DIST + 1; ++u) {
             const int s = s0 + u;
+            if (V > 0 && s % BURST == 0 && s > 0) {  // a stage epilogue of both windows
+#pragma unroll
+                for (int i = 0; i < 2 * V * BURST; ++i) vx[i & 7] = __builtin_fmaf(vx[i & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+                if (BAR) __syncthreads();
+            }
             if (s + DIST < nslot) loadb(s + DIST, ring[(u + DIST) % (DIST + 1)]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -345,7 +354,10 @@ __global__ __launch_bounds__(256, WGS) void k_g(const Frag* W, const Frag* Ain, 
     for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) t += acc[m][n];
-    out[(size_t)blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vs += vx[i];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = t[0] + t[1] + t[2] + t[3] + (V > 0 ? vs : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------ A
@@ -507,6 +519,12 @@ int main(int argc, char** argv) {
         auto kg22 = k_g<2, 2>;
         CK(hipFuncSetAttribute((const void*)kg22, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g2));
         row("G2 d2", [&](int nw) { hipLaunchKernelGGL(kg22, dim3(nw / 2), dim3(256), lds_g2, 0, W, A, out, NSLOT); });
+        auto kg2v = k_g<3, 2, 40, 6, true>;  // + the synthetic VALU / barrier load of 'v40 b6 bar' (per window)
+        CK(hipFuncSetAttribute((const void*)kg2v, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g2));
+        row("G2 v40b6", [&](int nw) { hipLaunchKernelGGL(kg2v, dim3(nw / 2), dim3(256), lds_g2, 0, W, A, out, NSLOT); });
+        auto kg2w = k_g<2, 2, 40, 6, true>;
+        CK(hipFuncSetAttribute((const void*)kg2w, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g2));
+        row("G2d2 v40b6", [&](int nw) { hipLaunchKernelGGL(kg2w, dim3(nw / 2), dim3(256), lds_g2, 0, W, A, out, NSLOT); });
     }
 #define TEAM(W0, NT, SY) do { auto kf = k_team<W0, NT, SY>; const int lds = NT * 50 * 1024; CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         char nm[64]; snprintf(nm, 64, "t%d %s s%d", NT, W0 ? "w0" : "ws", SY); \
