@@ -155,6 +155,35 @@ def profiled_hbm_traffic():
                 fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"], profile_kernel_src_sha16=prof_sha, kernel_src_sha16=cur, stale=stale)
 
 
+TRAIN_KERNEL_SOURCES = ("studiosr_amd/csrc/sr_tr_block.hip", "studiosr_amd/csrc/sr_tr_wgrad.hip", "studiosr_amd/csrc/sr_tr_attn.hip", "studiosr_amd/csrc/sr_tr_attn_lds.hip")
+
+
+def profiled_train_traffic():
+    """HBM bytes per launch of the training step's largest kernel -- sr_tr_wgrad_kernel, the launch that holds a HAB's six weight-gradient jobs (grid 1536) -- from
+    the committed PMC passes (profiles/*_train_hbm_counters_HAT.txt, tools/pmc_train.sh; FETCH_SIZE doubled per the gfx950 rule).  None when absent or taken on
+    other kernel sources (the profile's first line carries their hash)."""
+    import glob
+    import hashlib
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_hbm_counters_HAT.txt")))
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in TRAIN_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    text = open(files[-1]).read()
+    m0 = re.search(r"#\s*kernel_src_sha16\s*=\s*([0-9a-f]+)", text)
+    stale = not m0 or m0.group(1) != h.hexdigest()[:16]
+    vals = {}
+    for m in re.finditer(r"\('tr_wgrad_kernel[^\n]*, 1536\)\n\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", text):
+        vals[m.group(1)] = float(m.group(2))
+    if len(vals) != 2:
+        return None
+    return dict(kernel="sr_tr_wgrad_kernel (one HAB's weight-gradient jobs, 36 launches per step)", bytes=None if stale else int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
+                fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"], source=os.path.relpath(files[-1], ROOT), stale=stale)
+
+
 def cpu_model_string() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -384,7 +413,8 @@ def run_train(args, device, rank, world) -> None:
                                              "path": ("fused launch sequences replayed from C launch plans, one autograd node per RHAG (studiosr_amd/fasttrain.py, C ABI v10 sr_plan_run)" if fused else
                                                       "generic engine (one strided batched GEMM / row kernel per op, studiosr_amd/autograd.py)")},
             "final_loss": loss.item(),
-            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": round(tflops / (2500.0 * world), 4), "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": round(tflops / (2500.0 * world), 4),
+                         "traffic": ((profiled_train_traffic() or {}).get("bytes") if args.model == "hat" else None), "traffic_detail": profiled_train_traffic() if args.model == "hat" else None,
                          "note": "bf16 operands / fp32 accumulate for the contractions (autocast), fp32 everywhere else; against the fp32 MFMA peak (157.3 TFLOP/s) the same step is "
                                  + str(round(tflops / (157.3 * world), 3))},
             "cpu_baseline": None,

@@ -203,7 +203,7 @@ def _zeros_like(t: Tensor) -> Tensor:
 # --------------------------------------------------------------------------- nn.Linear / conv
 # --------------------------------------------------------------------------- independent backward work on a side stream
 _SIDE_STREAMS = {}
-_OVERLAP = os.environ.get("SR_WGRAD_STREAM", "0") == "1"  # off: measured 73.4 -> 81-84 ms per HAT step (two cross-stream event waits per layer cost more than the overlap buys)
+_OVERLAP = False  # (the SR_WGRAD_STREAM switch left in round 5) off: measured 73.4 -> 81-84 ms per HAT step (two cross-stream event waits per layer cost more than the overlap buys)
 
 
 class _Side:

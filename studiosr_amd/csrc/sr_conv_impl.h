@@ -431,7 +431,7 @@ int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
     }
     const int tiles = ((c.W + 15) / 16) * ((c.H + TH - 1) / TH) * c.B;
     dim3 grid(tiles, c.Cout_p / (WN * NW * 16));
-    static const int xcd_env = getenv("SR_CONV_XCD") ? atoi(getenv("SR_CONV_XCD")) : 1;  // A/B knob: 0 = tiles in block-id order
+    const int xcd_env = 1;  // XCD-aware tile order (0 = tiles in block-id order; the A/B switch left in round 5)
     const int xcd_order = (xcd_env && tiles >= 64 && (grid.y == 1 || (tiles & 7) == 0)) ? 1 : 0;  // (the residue class of a block id is that of blockIdx.x)
     hipLaunchKernelGGL((sr_conv3x3_kernel<TC, TIn, TH, WM, WN, NW, KCS>), grid, dim3(256), lds, st, c, xcd_order);
     SR_CHECK_LAUNCH("sr_conv3x3");

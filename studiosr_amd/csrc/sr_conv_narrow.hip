@@ -207,7 +207,7 @@ int launch_narrow(const SrConv3x3& c, hipStream_t st, int wgs_per_cu) {
 
 // true if sr_conv3x3_narrow covers this conv: bf16 NHWC input of 64 or 256 channels, <= 4 real output channels, plain final NCHW store
 bool sr_conv3x3_narrow_supported(const SrConv3x3& c) {
-    static const bool off = getenv("SR_CONV_NARROW") && getenv("SR_CONV_NARROW")[0] == '0';  // A/B knob: SR_CONV_NARROW=0 -> general kernel
+    const bool off = false;  // (true: the general kernel; the A/B switch left in round 5)
     if (off) return false;
     return c.compute_dtype == SR_BF16 && c.x_dtype == SR_BF16 && c.Cout_p == 16 && (c.Cin_p == 64 || c.Cin_p == 256) && c.out_mode == SR_OUT_FINAL_NCHW &&
            c.ps_r <= 1 && c.fin_c <= 4 && c.act == SR_ACT_NONE && c.out_scale == 1.0f && !c.skip && !c.pool_partial;

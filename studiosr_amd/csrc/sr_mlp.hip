@@ -235,7 +235,7 @@ extern "C" int sr_mlp_fused(const SrMlp* p, void* stream) {
     const SrMlp& a = *p;
     SR_REQUIRE(a.M > 0 && a.C > 0 && a.C <= a.Cp && a.ldx >= a.Cp, "sr_mlp_fused: bad geometry");
     SR_REQUIRE(sr_mlp_fused_supported(a.Cp, a.Hp, SR_BF16), "sr_mlp_fused: unsupported Cp=%d Hp=%d (use two sr_gemm calls)", a.Cp, a.Hp);
-    static const int rows = getenv("SR_MLP_ROWS") ? atoi(getenv("SR_MLP_ROWS")) : 64;  // experiments: 128 rows per workgroup (8 MFMAs per weight fragment), 32 rows (2)
+    const int rows = 64;  // experiments: 128 rows per workgroup (8 MFMAs per weight fragment), 32 rows (2)
     if (rows == 32) {
         constexpr int lds = (6 + 12) * 4 * 32 * 16;  // 36 KiB
         static SrDeviceOnce attr_once32;

@@ -588,7 +588,7 @@ extern "C" int sr_swin_tail(const SrSwinTail* p, void* stream) {
     // pool partials by DMA into LDS (POOL_OFF): bf16 instantiations, squeeze geometries with register-resident MLP operands, partials + scratch within 80 KiB
     int lds16 = Lds<bf16>::TOTAL;
     dv.pool_lds = 0;
-    static const bool pool_global = getenv("SR_TAIL_POOL_LDS") && getenv("SR_TAIL_POOL_LDS")[0] == '0';  // A/B knob: SR_TAIL_POOL_LDS=0 keeps the loads
+    const bool pool_global = false;  // (true keeps the loads
     if (a.compute_dtype == SR_BF16 && a.y && a.pool_partial && a.ca_Cr <= 8 && a.C <= 256 && a.Cp <= 256 && !pool_global) {
         const int need = POOL_OFF + a.ca_n_tiles * a.Cp * 4 + ca_scratch_floats(a.Cp, a.ca_Cr) * 4;
         if (need <= TAIL_LDS_MAX && (reinterpret_cast<uintptr_t>(a.pool_partial) & 15) == 0) {

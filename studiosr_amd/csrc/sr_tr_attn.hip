@@ -566,7 +566,7 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
     SR_REQUIRE(a.T > 0 && a.T <= 1536 && a.Tpad >= a.T, "sr_tr_attn_bwd: the bias table has at most 1536 rows");
     if (sr_tr_attn_bwd_lds_usable(b)) return sr_tr_attn_bwd_lds(b, st);  // 16 x 16 windows, one table partial per (head, window): everything in LDS, one launch
     const int items_q = a.groups * a.heads * (a.Nq / 16);
-    static const int var = getenv("SR_TR_QVAR") ? atoi(getenv("SR_TR_QVAR")) : 1;  // 0: the generic index-map fold (A/B knob)
+    const int var = 1;  // (0: the generic index-map fold)
     if (a.Nk == 256) {
         if (var == 1 && a.toeplitz16)
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 1>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);

@@ -477,7 +477,7 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
     SR_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAXJOBS, "sr_tr_wgrad: 1..%d jobs per launch", WG_MAXJOBS);
     WgradJobs J;
     J.n = njobs;
-    static const int xcd = getenv("SR_WG_XCD") ? atoi(getenv("SR_WG_XCD")) : 1;  // A/B knob: 0 = block ids in item order
+    const int xcd = 1;  // XCD-aware work order (0 = block ids in item order: 65.2 -> 73.1 us per HAB launch, round 4)
     J.xcd = xcd;
     int wg = 0;
     for (int i = 0; i < njobs; ++i) {

@@ -523,13 +523,13 @@ bool bgemm_row_major_out(const SrBgemm& g) {
 template <int MA, int MB>
 void launch_bf16(const SrBgemm& g, long long nz, hipStream_t st) {
     // BN = 64 where it pads N less or where 128-wide tiles leave the chip under-filled
-    static const int force = getenv("SR_BGEMM_BN") ? atoi(getenv("SR_BGEMM_BN")) : 0;
+    const int force = 0;  // (experiments forced the column tile here)
     const long long t128 = (long long)((g.N + 127) / 128) * ((g.M + BT - 1) / BT) * nz;
     const bool pad64 = ((g.N + 63) / 64) * 64 < ((g.N + 127) / 128) * 128;
     const bool bn64 = force ? force == 64 : (pad64 || t128 < 1024);
     // measured in the HAT / SwinIR training steps: the remap pays for plain GEMMs (one A panel per m-tile: -20..25 % per launch), not for
     // batched / split-K launches, which keep the x-fastest order.  SR_BGEMM_NATURAL=1 switches it off everywhere (A/B knob).
-    static const int natural = getenv("SR_BGEMM_NATURAL") ? atoi(getenv("SR_BGEMM_NATURAL")) : 2;
+    const int natural = 2;
     const int nat = natural == 1 || (natural == 2 && nz > 1);
     const BgemmGrid g64{(g.N + 63) / 64, (g.M + BT - 1) / BT, (int)nz, nat}, g128{(g.N + 127) / 128, (g.M + BT - 1) / BT, (int)nz, nat};
     if (bgemm_row_major_out(g)) {
@@ -1100,7 +1100,7 @@ extern "C" int sr_bgemm(const SrBgemm* p, void* stream) {
     SR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nb1 > 0 && g.nb2 > 0 && g.ksplit > 0, "sr_bgemm: bad sizes M=%d N=%d K=%d nb=%dx%d ksplit=%d", g.M, g.N, g.K, g.nb1, g.nb2, g.ksplit);
     const long long nz = (long long)g.nb1 * g.nb2 * g.ksplit;
     SR_REQUIRE(nz < (1ll << 31), "sr_bgemm: too many batches x ksplit (%lld)", nz);
-    static const bool no_tiled = getenv("SR_BGEMM_DIRECT") != nullptr;  // A/B switch for tools/
+    const bool no_tiled = false;  // (true: the direct-from-global form everywhere)
     if (g.M < 96 && g.N >= 96 && !g.bias) {
         // short-and-wide (weight gradients of convs with few output channels: M = 3 or 60, N = 9 Cin): run the transposed problem
         // C^T = B^T A^T so that the long axis is the 128-row tile axis -- same products, same k order
@@ -1216,7 +1216,7 @@ extern "C" int sr_colsum(const float* x, float* out, int nb, long long P, int C,
     SR_REQUIRE(x && out && nb > 0 && nb <= 65535 && P > 0 && C > 0, "sr_colsum: bad arguments");
     if ((C & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && P >= 64) {
         const int q = C / 4, ny = (q + 63) / 64, QB = (q + ny - 1) / ny, R = 256 / QB;
-        static const int env_blocks = getenv("SR_COLSUM_BLOCKS") ? atoi(getenv("SR_COLSUM_BLOCKS")) : 0;  // tools/colsum_bench.py sweep
+        const int env_blocks = 0;  // (> 0 forced the block count in a sweep)
         // row blocks per column block: enough workgroups to stream (a workgroup moves ~30-60 GB/s), few enough that the same-address
         // atomics at the end do not dominate (tools/colsum_bench.py: 16,384 rows 64 blocks, 262,144 rows 128; 256 blocks lose 2x)
         const long long target = env_blocks > 0 ? env_blocks : std::min<long long>(128, std::max<long long>(32, P / 256));

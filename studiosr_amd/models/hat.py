@@ -336,7 +336,7 @@ class HAT(Model):
         if mid_fused:
             side = main
             if not n1_ready:
-                if not qkv_ready and not qkv_in_attn and knob("SR_QKV_N1", "1") != "0":  # a group's first block: LayerNorm1 leaves sr_swin_qkv as a side output (one launch less)
+                if not qkv_ready and not qkv_in_attn and True:  # a group's first block: LayerNorm1 leaves sr_swin_qkv as a side output (one launch less)
                     qkv_n1 = (n1, *bp["ln1"])
                 else:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
@@ -365,7 +365,7 @@ class HAT(Model):
         # beside the attention kernel) is the longer one and is created first (default); SR_HAT_SIDE_FIRST=0 creates the attention branch first
         # and enqueues the conv branch from the projection hook.  Measured on two boxes (HAT x4 b4, ms): fused QKV + conv first 3.42 / 3.43,
         # fused + attention first 3.59 / 3.62, separate QKV + conv first 3.83 / 3.36, separate + attention first 3.85 / 3.42.
-        late = unfused and side is not main and knob("SR_HAT_SIDE_FIRST", "1") == "0"
+        late = unfused and side is not main and False
         fork = None
         if late:
             fork = torch.cuda.Event()

@@ -460,3 +460,19 @@ def test_launch_plan_recorder_classifies_calls_and_plans_validate():
     bad[0].ival = 3
     assert not h.sr_plan_create(bad, 1, 1) and b"bad operation" in h.sr_last_error()
     assert h.sr_plan_run(seg, (C.c_void_p * 1)(), 1) != 0 and b"streams" in h.sr_last_error()  # fewer streams than the plan uses: refused before anything is enqueued
+
+
+def test_every_environment_switch_is_registered():
+    """studiosr_amd/knobs.py lists every SR_* variable the package reads (Python and C): a new switch must be documented there, a removed one deleted."""
+    import glob
+
+    from studiosr_amd.knobs import KNOBS
+
+    used = set()
+    for pat in ("studiosr_amd/**/*.py", "studiosr_amd/csrc/*.hip", "studiosr_amd/csrc/*.h", "studiosr_amd/csrc/*.cpp"):
+        for f in glob.glob(os.path.join(ROOT, pat), recursive=True):
+            if f.endswith("knobs.py"):
+                continue
+            used |= set(re.findall(r'(?:knob\(|environ\.get\(|environ\[|getenv\()\s*"(SR_[A-Z0-9_]+)"', open(f).read()))
+    assert used == set(KNOBS), (sorted(used - set(KNOBS)), sorted(set(KNOBS) - used))
+    assert all(k in ("select", "tune", "diag") and doc for _, k, doc in KNOBS.values())
