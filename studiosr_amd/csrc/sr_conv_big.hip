@@ -40,8 +40,11 @@ constexpr int BH = BT + 2;              // halo width
 // PIPE: the LDS image holds ALL input channels and is staged in PH channel phases that are software-pipelined with the MFMAs: the global
 // loads of phase p + 1 are in flight (in registers) while phase p's nine taps run, and are converted / written to LDS afterwards -- the
 // one-workgroup-per-CU kernel no longer fetches its whole halo before the first MFMA.
-template <typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
+// TC = bf16, or bf3 (round 5; compute type SR_BF16X3, precision "fp32x3": every operand a hi + lo bf16 pair, three MFMAs per product, fp32 input only): 32-byte image
+// cells, so K is walked in twice as many phases (192 channels: 2 x 96, 256: 4 x 64) and the tile stays within the same LDS footprint.
+template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
 __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
+    static_assert(!PIPE || sizeof(Frag<TC>) == 16, "the pipelined staging exists for bf16 operands only");
     constexpr int HH = TH + 2;                       // halo height
     constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
     constexpr int BRS = BROWS | 1;                   // row stride of the image in cells (odd: the staging writes of one pixel's 8 K-groups hit 8 bank groups)
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     static_assert(KC % PH == 0 && (PIPE ? (9 * KCP) % RING == 0 : KCP % RING == 0), "phase / ring geometry");
     constexpr int KGP = KCP * 4;                   // 8-channel groups per phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<bf16>* As = reinterpret_cast<Frag<bf16>*>(smem);  // [KGP][BROWS]
+    Frag<TC>* As = reinterpret_cast<Frag<TC>*>(smem);  // [KGP][BROWS]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     const int ar = lane & 15, ag = lane >> 4;
     const int ntile0 = blockIdx.y * (4 * NW) + wave * NW;  // blockIdx.y: slices of 64 * NW output channels (PixelShuffle convs: Cout = r*r*C)
     constexpr int KCT = 9 * KC;
-    const Frag<bf16>* Bp = reinterpret_cast<const Frag<bf16>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
+    const Frag<TC>* Bp = reinterpret_cast<const Frag<TC>*>(c.Wp) + (size_t)ntile0 * KCT * 64 + lane;
     const TIn* xin = reinterpret_cast<const TIn*>(c.x);
     BSTAMP(0);
 
@@ -132,14 +135,16 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             const int p = wave * 8 + j * 32 + r8;
             bool valid;
             (void)halo_pixel(p, valid);
-            Frag<bf16> f;
+            Frag<bf16> f;  // (PIPE: bf16 operands only)
             if constexpr (sizeof(TIn) == 4) {
                 f.v[0] = (bf16)raw[j].lo[0]; f.v[1] = (bf16)raw[j].lo[1]; f.v[2] = (bf16)raw[j].lo[2]; f.v[3] = (bf16)raw[j].lo[3];
                 f.v[4] = (bf16)raw[j].hi[0]; f.v[5] = (bf16)raw[j].hi[1]; f.v[6] = (bf16)raw[j].hi[2]; f.v[7] = (bf16)raw[j].hi[3];
             } else {
                 f.v = __builtin_bit_cast(bf16x8, raw[j].lo);
             }
-            if (p < BROWS) As[(ph * KGP + kq) * BRS + p] = frag_keep_if(valid, f);
+            if constexpr (sizeof(Frag<TC>) == 16) {
+                if (p < BROWS) As[(ph * KGP + kq) * BRS + p] = frag_keep_if(valid, f);
+            }
         }
     };
     if constexpr (PIPE) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
             constexpr int KI = KGP / 8;
             constexpr int NPASS = 4;  // row passes whose loads are all in flight before the first LDS write
             for (int pb = wave * 8; pb < BROWS; pb += 32 * NPASS) {
-                Frag<bf16> f[NPASS][KI];
+                Frag<TC> f[NPASS][KI];
                 bool valid[NPASS];
 #pragma unroll
                 for (int u = 0; u < NPASS; ++u) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                     valid[u] = p < HH * BH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
                     const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * c.Cin_p + ph * KGP * 8;
 #pragma unroll
-                    for (int i = 0; i < KI; ++i) f[u][i] = load_group<bf16, TIn>(src + (kq + 8 * i) * 8);
+                    for (int i = 0; i < KI; ++i) f[u][i] = load_group<TC, TIn>(src + (kq + 8 * i) * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < NPASS; ++u) {
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         }
 
         // ---- 9 taps x KCP chunks of this phase; weight chunk index in the packed order = tap * KC + ph * KCP + kc
-        const Frag<bf16>* abase0 = As + ar + (ag + (PIPE ? ph * KGP : 0)) * BRS;
-        Frag<bf16> br[RING][NW];
+        const Frag<TC>* abase0 = As + ar + (ag + (PIPE ? ph * KGP : 0)) * BRS;
+        Frag<TC> br[RING][NW];
         auto wload = [&](int slot, int tap, int kc) {  // slot is compile-time at every call site
             int chunk = tap * KC + ph * KCP + kc;
             if (kc >= KCP) chunk += KC - KCP;  // look-ahead ran into the next tap
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
 #pragma unroll
             for (int s = 0; s < RING - 1; ++s) wload(s, 0, s);
         }
-        Frag<bf16> af[2][HALF];
+        Frag<TC> af[2][HALF];
 #pragma unroll
         for (int m = 0; m < HALF; ++m) af[0][m] = abase0[m * BH];
         if constexpr (PIPE) {
@@ -219,9 +224,9 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int tap = t / KCP, kc = t % KCP;
-                const Frag<bf16>* abase = abase0 + (tap / 3) * BH + (tap % 3);
+                const Frag<TC>* abase = abase0 + (tap / 3) * BH + (tap % 3);
                 const int tn = t + 1 < 9 * KCP ? t + 1 : t;
-                const Frag<bf16>* nb = abase0 + ((tn / KCP) / 3) * BH + ((tn / KCP) % 3) + (tn % KCP) * 4 * BRS;
+                const Frag<TC>* nb = abase0 + ((tn / KCP) / 3) * BH + ((tn / KCP) % 3) + (tn % KCP) * 4 * BRS;
                 wload_lin((t + RING - 1) % RING, t + RING - 1);
 #pragma unroll
                 for (int m = 0; m < HALF; ++m) af[1][m] = abase[(HALF + m) * BH + kc * 4 * BRS];
@@ -241,10 +246,10 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
         } else
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const Frag<bf16>* abase = abase0 + ky * BH + kx;
+            const Frag<TC>* abase = abase0 + ky * BH + kx;
             // first fragment address of the NEXT tap (for the look-ahead at the end of this one)
             const int tn = tap + 1 < 9 ? tap + 1 : tap;
-            const Frag<bf16>* abase_next = abase0 + (tn / 3) * BH + (tn % 3);
+            const Frag<TC>* abase_next = abase0 + (tn / 3) * BH + (tn % 3);
 #pragma unroll
             for (int kc = 0; kc < KCP; ++kc) {
                 wload((kc + RING - 1) % RING, tap, kc + RING - 1);
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
                 __builtin_amdgcn_sched_barrier(0);
                 // half chunk 1: fetch the upper rows of the next chunk (next tap's first chunk after the last one)
                 {
-                    const Frag<bf16>* nb = (kc + 1 < KCP) ? abase + (kc + 1) * 4 * BRS : abase_next;
+                    const Frag<TC>* nb = (kc + 1 < KCP) ? abase + (kc + 1) * 4 * BRS : abase_next;
 #pragma unroll
                     for (int m = 0; m < HALF; ++m) af[0][m] = nb[m * BH];
                 }
@@ -354,18 +359,19 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     BSTAMP(4);
 }
 
-template <typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
+template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
 int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
-    constexpr int lds = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<bf16>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
-    static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
+    constexpr int lds = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<TC>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
+    static_assert(lds <= 160 * 1024 && lds >= 4 * 2 * 16 * (NW * 64 + 16), "halo tile must fit LDS and hold the epilogue's private tiles");
+    static_assert(((KC / PH) * 4) % 8 == 0, "the staging moves 8 K-groups per wave instruction");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH, PIPE>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
-    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TIn, TH, NW, KC, PH, PIPE>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
 }
@@ -384,8 +390,16 @@ int dispatch_big(const SrConv3x3& c, hipStream_t st) {
     // 192 input channels: one phase.  (Three software-pipelined phases of 64 channels -- template parameter PIPE, K walk phase-major -- were
     // measured and lost: 36.7 -> 40.6 us on the RSTB conv even with five chunks of weight look-ahead; vector loads return in order, so the
     // next phase's halo fetch sits in front of every weight fragment issued after it, and all 240 workgroups fetch at the same time anyway.)
-    if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<TIn, TH, 3, 6, 1>(c, st);
-    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<TIn, TH, 4, 8, 2>(c, st);
+    if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf16, TIn, TH, 3, 6, 1>(c, st);
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, TH, 4, 8, 2>(c, st);
+    return SR_EUNSUPPORTED;
+}
+
+// split operands (SR_BF16X3, fp32 input): phases of 64 channels (8 K-groups of 32-byte cells: the 16-row halo tile is 84 KiB)
+template <int TH>
+int dispatch_big_x3(const SrConv3x3& c, hipStream_t st) {
+    if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf3, float, TH, 3, 6, 3>(c, st);
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf3, float, TH, 4, 8, 4>(c, st);
     return SR_EUNSUPPORTED;
 }
 
@@ -402,13 +416,15 @@ bool sr_conv3x3_big_supported(const SrConv3x3& c) {
     // Below ~224 workgroups the wide tile leaves too many CUs idle and the 8 x 16 / 4 x 16 kernel wins (192 -> 192: 4 x 64 x 64 33 vs 16.5 us,
     // 8 x 64 x 64 34.7 vs 28.8 us; 8 x 72 x 72 = 240 workgroups 36.8 vs 46.0 us: wide tile).  SR_CONV_BIG_MIN overrides (tools/kbench.py conv).
     static const int min_tiles = getenv("SR_CONV_BIG_MIN") ? atoi(getenv("SR_CONV_BIG_MIN")) : 224;
-    if (c.compute_dtype != SR_BF16 || (c.out_mode != SR_OUT_NHWC && c.out_mode != SR_OUT_PIXEL_SHUFFLE) || c.pool_partial) return false;
+    const bool x3 = c.compute_dtype == SR_BF16X3 && c.x_dtype == SR_F32;  // round 5: the split-operand instantiation (precision "fp32x3")
+    if ((c.compute_dtype != SR_BF16 && !x3) || (c.out_mode != SR_OUT_NHWC && c.out_mode != SR_OUT_PIXEL_SHUFFLE) || c.pool_partial) return false;
     if (!((c.Cin_p == 192 && c.Cout_p % 192 == 0 && c.Cout_p % 256 != 0) || (c.Cin_p == 256 && c.Cout_p % 256 == 0))) return false;
     if (c.out_mode == SR_OUT_PIXEL_SHUFFLE && c.cps_p % (big_nw(c) * 16) != 0) return false;  // the coalesced epilogue needs a wave's channels inside one sub-pixel
     return big_tiles(c, big_tile_rows(c)) >= min_tiles;  // small launches keep the 8 x 16 tiles (more workgroups)
 }
 
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st) {
+    if (c.compute_dtype == SR_BF16X3) return big_tile_rows(c) == 12 ? dispatch_big_x3<12>(c, st) : dispatch_big_x3<16>(c, st);
     if (big_tile_rows(c) == 12) return c.x_dtype == SR_F32 ? dispatch_big<float, 12>(c, st) : dispatch_big<bf16, 12>(c, st);
     return c.x_dtype == SR_F32 ? dispatch_big<float, 16>(c, st) : dispatch_big<bf16, 16>(c, st);
 }
