@@ -36,6 +36,11 @@ constexpr int HALO_W = 18;
 
 #define STAMP(i) SR_STAMP(sr_dbg_conv, i)
 
+// operand kinds that take the unrolled / coalesced forms: everything on the bf16 matrix cores (bf16, and since round 5 the split-operand bf3); the exact-fp32
+// parity path keeps the generic loop
+template <typename TC>
+constexpr bool kMatrix16 = !std::is_same<TC, float>::value;
+
 // halo rows of the LDS image: bf16 stages 64 rows per step (two passes of 32), so its images are whole steps
 template <int TH, int ESZ = 4>
 struct ConvGeo {
@@ -58,10 +63,10 @@ struct EpiGeo {
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c, int xcd_order) {
     static_assert(WM * WN == 4 && TH % WM == 0, "wave grid");
-    constexpr int ROWS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::ROWS;
+    constexpr int ROWS = ConvGeo<TH, kMatrix16<TC> ? 2 : 4>::ROWS;
     // row stride of the K-group-major image in cells: ROWS + 1, so that the staging writes of ONE pixel's 8 K-groups (8 adjacent lanes,
     // see below) fall into different banks; the fragment reads (16 consecutive rows of one K-group) do not care
-    constexpr int RS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::RS;
+    constexpr int RS = ConvGeo<TH, kMatrix16<TC> ? 2 : 4>::RS;
     constexpr int HH = ConvGeo<TH>::HH;
     constexpr int MTW = TH / WM;  // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c, int xcd_or
     // plain residual convs (no activation / scale, NHWC out): the skip tile is the initial accumulator, fetched now
     // coalesced epilogue (see EpiGeo): NHWC, or PixelShuffle when every wave's NW * 16 channels are one sub-pixel's contiguous channels
     bool coal = false;
-    if constexpr (sizeof(TC) == 2 && MTW % 2 == 0)
+    if constexpr (kMatrix16<TC> && MTW % 2 == 0)
         coal = c.out_mode == SR_OUT_NHWC || (c.out_mode == SR_OUT_PIXEL_SHUFFLE && c.cps_p % (NW * 16) == 0);
     const bool acc_from_skip = c.skip && c.act == SR_ACT_NONE && c.out_scale == 1.0f && c.out_mode == SR_OUT_NHWC && !c.pool_partial;
     f32x4 acc[MTW][NW];
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c, int xcd_or
     const bool scaled = c.out_scale != 1.0f;
     const float lrelu_slope = c.act_slope != 0.0f ? c.act_slope : 0.01f;
     if (coal) {
-        if constexpr (sizeof(TC) == 2 && MTW % 2 == 0) {
+        if constexpr (kMatrix16<TC> && MTW % 2 == 0) {
             __syncthreads();  // every wave has issued its last fragment read of the halo image: the private tiles overlay it
             char* priv = smem + wave * EpiGeo<NW>::PRIV;
             constexpr int S = EpiGeo<NW>::S;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(256) void sr_conv3x3_kernel(SrConv3x3 c, int xcd_or
 
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW, int KCS>
 int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
-    constexpr int RS = ConvGeo<TH, sizeof(TC) == 2 ? 2 : 4>::RS;
+    constexpr int RS = ConvGeo<TH, kMatrix16<TC> ? 2 : 4>::RS;
     // halo image, or the four wave-private transpose tiles of the coalesced epilogue if they need more
     const int lds_img = c.Cin_p * RS * (int)sizeof(TC);
     const int lds = lds_img > 4 * EpiGeo<NW>::PRIV ? lds_img : 4 * EpiGeo<NW>::PRIV;
@@ -442,7 +447,7 @@ int launch_conv_k(const SrConv3x3& c, hipStream_t st) {
 // bf16 only -- the exact-fp32 parity path keeps the generic loop
 template <typename TC, typename TIn, int TH, int WM, int WN, int NW>
 int launch_conv(const SrConv3x3& c, hipStream_t st) {
-    if constexpr (sizeof(TC) == 2) {
+    if constexpr (kMatrix16<TC>) {  // (round 5: the split-operand convs of RCAN / HAT / the small EDSR launches ran the generic run-time loop)
         if constexpr (NW < 4) {  // the 256-wide tile is only dispatched for Cin_p >= 128
             if (c.Cin_p == 32) return launch_conv_k<TC, TIn, TH, WM, WN, NW, 1>(c, st);
             if (c.Cin_p == 64) return launch_conv_k<TC, TIn, TH, WM, WN, NW, 2>(c, st);
