@@ -74,12 +74,15 @@ class Model(nn.Module):
         `_get_packed` notices ordinary in-place updates through the parameters' version counters; an update that does not bump them
         (torch.optim.Adam(fused=True): torch._fused_adam_; raw kernels writing p.data) needs this call -- studiosr_amd.optim.Adam and train() / eval() make it."""
         self._packed = {}
+        self.__dict__["_recorded_since_pack"] = False
         plan = self.__dict__.get("_fast_plan")
         if plan is not None:
             plan.packed_version = None
 
     def train(self, mode: bool = True):
-        if mode != self.training:  # the Trainer's train -> evaluate -> train pattern (trainer.py:125-131): never evaluate on weights packed before the last steps
+        # The Trainer's train -> evaluate -> train pattern (trainer.py:125-131): never evaluate on weights packed before the last optimizer steps.  Only when a
+        # differentiable forward ran since the cache was filled (a pure inference user toggling modes keeps its packed weights: a captured HIP graph holds pointers to them).
+        if mode != self.training and self.__dict__.get("_recorded_since_pack"):
             self.invalidate_packed()
         return super().train(mode)
 
@@ -148,6 +151,8 @@ class Model(nn.Module):
             raise NotImplementedError("the HIP training path provides parameter gradients only (the reference Trainer never differentiates w.r.t. the LR image)")
         from . import train
 
+        if recording:
+            self.__dict__["_recorded_since_pack"] = True  # (see train(): an optimizer step may follow, visibly or not)
         return train.FORWARDS[type(self).__name__](self, self._check_input(x))
 
     # ------------------------------------------------------------------ reference API

@@ -145,6 +145,9 @@ def swinir_forward(model, x: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------- HAT
+REPLAN = 3  # recorded forwards in a row at another batch geometry before the fused training plan is rebuilt for it
+
+
 def _fast_plan(model, B: int, Hp: int, Wp: int):
     """The fused training path (studiosr_amd/fasttrain.py) when it applies: bf16 autocast (the reference Trainer's context, trainer.py:80,102),
     the default block geometry, a padded size that is a multiple of the 16 x 16 windows.  SR_FAST_TRAIN=0 keeps the generic engine."""
@@ -160,13 +163,26 @@ def _fast_plan(model, B: int, Hp: int, Wp: int):
     if plan is None:
         return None
     if plan.geo is not None and plan.geo != (B, Hp, Wp):
-        if not getattr(plan, "_bypass_logged", False):  # one geometry per plan: other sizes (evaluation inside a training run) take the generic engine
-            plan._bypass_logged = True
-            import warnings
+        # One geometry per plan.  A stray other size (an evaluation inside a training run, a last partial batch) takes the generic engine; a geometry that PERSISTS
+        # (REPLAN consecutive recorded forwards: a warm-up step before the real batch size, a new patch size) gets a new plan -- the old one's static buffers are dropped.
+        other = getattr(plan, "_other_geo", None)
+        plan._other_geo = ((B, Hp, Wp), other[1] + 1) if other and other[0] == (B, Hp, Wp) else ((B, Hp, Wp), 1)
+        if plan._other_geo[1] >= REPLAN:
+            object.__delattr__(model, "_fast_plan")
+            plan = fasttrain.get_plan(model)
+            if plan is None:
+                return None
+        else:
+            if not getattr(plan, "_bypass_logged", False):
+                plan._bypass_logged = True
+                import warnings
 
-            warnings.warn(f"studiosr_amd: the fused training plan is prepared for batch geometry {plan.geo}; {(B, Hp, Wp)} runs on the generic engine "
-                          "(correct, about 4x slower; gradients are then not views of the flat buffer, so the optimizer takes torch's own step)")
-        return None
+                warnings.warn(f"studiosr_amd: the fused training plan is prepared for batch geometry {plan.geo}; {(B, Hp, Wp)} runs on the generic engine "
+                              f"(correct, about 4x slower; gradients are then not views of the flat buffer, so the optimizer takes torch's own step); the plan is rebuilt "
+                              f"for it if it persists for {REPLAN} forwards")
+            return None
+    elif plan.geo is not None:
+        plan._other_geo = None
     plan.prepare(B, Hp, Wp)
     plan.pack()
     return plan

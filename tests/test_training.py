@@ -500,6 +500,19 @@ def test_fused_training_path_guards():
     m.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         assert m(x).shape == (2, 3, 64, 64)
+    # a geometry that persists gets a plan of its own (the first geometry seen is not pinned for ever): two more steps at (1, 48, 48) ...
+    m.train()
+    x48, y48 = torch.rand(1, 3, 48, 48, device=DEV), torch.rand(1, 3, 96, 96, device=DEV)
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            F.l1_loss(m(x48).float(), y48).backward()
+    assert m._fast_plan is not None and m._fast_plan.geo == (1, 48, 48)
+    for _ in range(4):  # ... and back
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            F.l1_loss(m(x).float(), y).backward()
+    assert m._fast_plan.geo == (2, 32, 32) and all(p.grad is not None for p in m.parameters())
     # a snapshot (EMA / best-model copy) after fused steps: the plan is not copied, the copy builds its own on its first step
     import copy
 
