@@ -18,6 +18,7 @@ Activations kept for the backward live in per-block static buffers (one forward 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, List, Optional, Tuple
@@ -676,16 +677,15 @@ class BlockPlan:
         wg = _wg_stream(main.device) if WG_SIDE else None
         if wg is not None:  # the weight gradients only feed the stage's sr_tr_finalize_to: they leave the critical path of the backward pass
             _ev_wait(wg, _ev_record(main))
-            torch.cuda.set_stream(wg)
-        _wgrad([
-            dict(A=op.dqkvw.data_ptr(), B=op.n1w.data_ptr(), out=pp(self.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-            dict(A=op.dx1sw.data_ptr(), B=self.o.data_ptr(), out=pp(self.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
-            dict(A=op.dhw.data_ptr(), B=op.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-            dict(A=op.doutw.data_ptr(), B=op.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
-        ] + jobs)
+        with (torch.cuda.stream(wg) if wg is not None else contextlib.nullcontext()):
+            _wgrad([
+                dict(A=op.dqkvw.data_ptr(), B=op.n1w.data_ptr(), out=pp(self.f_qkv), lda=3 * CP, ldb=CP, Np=3 * CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=op.dx1sw.data_ptr(), B=self.o.data_ptr(), out=pp(self.f_proj), lda=CP, ldb=CP, Np=CP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=HD, ks=ks),
+                dict(A=op.dhw.data_ptr(), B=op.n2w.data_ptr(), out=pp(self.f_fc1), lda=HP, ldb=CP, Np=HP, Kp=CP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+                dict(A=op.doutw.data_ptr(), B=op.gw.data_ptr(), out=pp(self.f_fc2), lda=CP, ldb=HP, Np=CP, Kp=HP, T=T, taps=1, H=H, W=W, ones_col=-1, ks=ks),
+            ] + jobs)
         if wg is not None:
             sc.wg_busy[k] = _ev_record(wg)
-            torch.cuda.set_stream(main)
 
 
     def _cab_backward(self, st: "Stage", B: int, H: int, W: int, T: int, lib, wa, fa, sc, pp, op) -> List[dict]:
@@ -819,8 +819,10 @@ class Stage:
         """dout: gradient of the stage output; returns the gradient of x (one of the stage's two static buffers); fills G for the stage's parameters.
         join = False: the caller waits for the weight-gradient stream itself (backward_model: once, behind the last stage)."""
         B, H, W = self.geo
-        if join:
-            self.sc.turn, self.sc.wg_busy = 0, [None, None]
+        if WG_SIDE:  # a stage is self-contained (it is recorded as a launch plan of its own: no event may cross its border): the operand sets are free again
+            main = torch.cuda.current_stream()
+            _ev_wait(main, _ev_record(_wg_stream(main.device)))
+        self.sc.turn, self.sc.wg_busy = 0, [None, None]
         d = dout.contiguous()
         for i in range(len(self.blocks) - 1, -1, -1):
             h = self.blocks[i]
@@ -831,9 +833,8 @@ class Stage:
             main = torch.cuda.current_stream()
             wg = _wg_stream(main.device)
             _ev_wait(wg, _ev_record(main))  # (LayerNorm / bias-table / channel-attention partials come from the main-stream kernels)
-            torch.cuda.set_stream(wg)
-            self.fm.run(self.fp.G if G is None else G)
-            torch.cuda.set_stream(main)
+            with torch.cuda.stream(wg):
+                self.fm.run(self.fp.G if G is None else G)
             if join:
                 _ev_wait(main, _ev_record(wg))
         else:
