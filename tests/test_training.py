@@ -671,7 +671,7 @@ step(ddp, x[2 * rank: 2 * rank + 2], t[2 * rank: 2 * rank + 2])
 worst = 0.0
 for (n, p), a, b in zip(m.named_parameters(), *single):
     ref = (a + b) / 2
-    tol = 5e-2 if n.endswith("relative_position_bias_table") else 1e-4  # (the table gradient carries LDS-atomic ordering noise)
+    tol = 2e-3 if n.endswith("relative_position_bias_table") else 1e-4  # (the table gradient is summed with LDS atomics: order noise at fp32 level only)
     e = float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-9)
     assert e < tol, (n, e)
     worst = max(worst, e)
@@ -744,7 +744,7 @@ else:
 worst = 0.0
 for (n, p), a, b in zip(m.named_parameters(), *single):
     ref = (a + b) / 2
-    tol = 5e-2 if n.endswith("relative_position_bias_table") else 1e-4
+    tol = 2e-3 if n.endswith("relative_position_bias_table") else 1e-4
     e = float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-9)
     assert e < tol, (n, e)
     worst = max(worst, e)
