@@ -42,8 +42,11 @@ constexpr int BH = BT + 2;              // halo width
 // one-workgroup-per-CU kernel no longer fetches its whole halo before the first MFMA.
 // TC = bf16, or bf3 (round 5; compute type SR_BF16X3, precision "fp32x3": every operand a hi + lo bf16 pair, three MFMAs per product, fp32 input only): 32-byte image
 // cells, so K is walked in twice as many phases (192 channels: 2 x 96, 256: 4 x 64) and the tile stays within the same LDS footprint.
+#ifndef SR_BIG_OCC
+#define SR_BIG_OCC 1  // experiment knob (with SR_BIG_TH / SR_BIG_PH): workgroups per CU the register allocation is bounded for
+#endif
 template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
-__global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
+__global__ __launch_bounds__(256, SR_BIG_OCC) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     static_assert(!PIPE || sizeof(Frag<TC>) == 16, "the pipelined staging exists for bf16 operands only");
     constexpr int HH = TH + 2;                       // halo height
     constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
@@ -362,8 +365,9 @@ __global__ __launch_bounds__(256) void sr_conv3x3_big_kernel(SrConv3x3 c) {
 template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
 int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
-    constexpr int lds = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<TC>);  // >= 4 x 2 x 16 x (NW * 64 + 16) B of the epilogue's private tiles
-    static_assert(lds <= 160 * 1024 && lds >= 4 * 2 * 16 * (NW * 64 + 16), "halo tile must fit LDS and hold the epilogue's private tiles");
+    constexpr int lds_img = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<TC>), lds_priv = 4 * 2 * 16 * (NW * 64 + 16);  // halo image; the epilogue's private tiles overlay it
+    constexpr int lds = lds_img > lds_priv ? lds_img : lds_priv;
+    static_assert(lds <= 160 * 1024, "halo tile must fit LDS");
     static_assert(((KC / PH) * 4) % 8 == 0, "the staging moves 8 K-groups per wave instruction");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
@@ -381,6 +385,9 @@ int big_tiles(const SrConv3x3& c, int th) { return ((c.W + BT - 1) / BT) * ((c.H
 
 // tile height with the smaller (residency rounds on 256 CUs) x (rows per workgroup); ties go to the taller tile
 int big_tile_rows(const SrConv3x3& c) {
+#ifdef SR_BIG_TH
+    if (c.Cin_p == 192) return SR_BIG_TH;  // experiment: short tiles (several workgroups per CU) for the 192-channel conv
+#endif
     const int cost16 = ((big_tiles(c, 16) + 255) / 256) * 16, cost12 = ((big_tiles(c, 12) + 255) / 256) * 12;
     return cost12 < cost16 ? 12 : 16;
 }
@@ -390,6 +397,9 @@ int dispatch_big(const SrConv3x3& c, hipStream_t st) {
     // 192 input channels: one phase.  (Three software-pipelined phases of 64 channels -- template parameter PIPE, K walk phase-major -- were
     // measured and lost: 36.7 -> 40.6 us on the RSTB conv even with five chunks of weight look-ahead; vector loads return in order, so the
     // next phase's halo fetch sits in front of every weight fragment issued after it, and all 240 workgroups fetch at the same time anyway.)
+#ifdef SR_BIG_PH
+    if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf16, TIn, TH, 3, 6, SR_BIG_PH>(c, st);
+#endif
     if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf16, TIn, TH, 3, 6, 1>(c, st);
     if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, TH, 4, 8, 2>(c, st);
     return SR_EUNSUPPORTED;
@@ -424,6 +434,9 @@ bool sr_conv3x3_big_supported(const SrConv3x3& c) {
 }
 
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st) {
+#ifdef SR_BIG_TH
+    if (c.compute_dtype == SR_BF16 && big_tile_rows(c) == SR_BIG_TH) return c.x_dtype == SR_F32 ? dispatch_big<float, SR_BIG_TH>(c, st) : dispatch_big<bf16, SR_BIG_TH>(c, st);
+#endif
     if (c.compute_dtype == SR_BF16X3) return big_tile_rows(c) == 12 ? dispatch_big_x3<12>(c, st) : dispatch_big_x3<16>(c, st);
     if (big_tile_rows(c) == 12) return c.x_dtype == SR_F32 ? dispatch_big<float, 12>(c, st) : dispatch_big<bf16, 12>(c, st);
     return c.x_dtype == SR_F32 ? dispatch_big<float, 16>(c, st) : dispatch_big<bf16, 16>(c, st);
