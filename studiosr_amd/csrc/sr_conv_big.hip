@@ -45,8 +45,8 @@ constexpr int BH = BT + 2;              // halo width
 #ifndef SR_BIG_OCC
 #define SR_BIG_OCC 1  // experiment knob (with SR_BIG_TH / SR_BIG_PH): workgroups per CU the register allocation is bounded for
 #endif
-template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
-__global__ __launch_bounds__(256, SR_BIG_OCC) void sr_conv3x3_big_kernel(SrConv3x3 c) {
+template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false, int OCC = SR_BIG_OCC>
+__global__ __launch_bounds__(256, OCC) void sr_conv3x3_big_kernel(SrConv3x3 c) {
     static_assert(!PIPE || sizeof(Frag<TC>) == 16, "the pipelined staging exists for bf16 operands only");
     constexpr int HH = TH + 2;                       // halo height
     constexpr int BROWS = ((HH * BH + 7) / 8) * 8;   // halo pixels, padded to a multiple of 8
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, SR_BIG_OCC) void sr_conv3x3_big_kernel(SrConv3
     BSTAMP(4);
 }
 
-template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false>
+template <typename TC, typename TIn, int TH, int NW, int KC, int PH, bool PIPE = false, int OCC = SR_BIG_OCC>
 int launch_big(const SrConv3x3& c, hipStream_t st) {
     constexpr int BROWS = (((TH + 2) * BH + 7) / 8) * 8;
     constexpr int lds_img = (PIPE ? KC : KC / PH) * 4 * (BROWS | 1) * (int)sizeof(Frag<TC>), lds_priv = 4 * 2 * 16 * (NW * 64 + 16);  // halo image; the epilogue's private tiles overlay it
@@ -371,11 +371,11 @@ int launch_big(const SrConv3x3& c, hipStream_t st) {
     static_assert(((KC / PH) * 4) % 8 == 0, "the staging moves 8 K-groups per wave instruction");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE, OCC>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int tiles = ((c.W + BT - 1) / BT) * ((c.H + TH - 1) / TH) * c.B;
-    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_conv3x3_big_kernel<TC, TIn, TH, NW, KC, PH, PIPE, OCC>), dim3(tiles, c.Cout_p / (64 * NW)), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_conv3x3");
     return SR_OK;
 }
@@ -385,11 +385,27 @@ int big_tiles(const SrConv3x3& c, int th) { return ((c.W + BT - 1) / BT) * ((c.H
 
 // tile height with the smaller (residency rounds on 256 CUs) x (rows per workgroup); ties go to the taller tile
 int big_tile_rows(const SrConv3x3& c) {
+    // 256 input channels, bf16 operands (EDSR body and upsampler, edsr.py:34-37): 8-row tiles at TWO workgroups per CU (47 KiB of halo image, 128 accumulator registers) --
+    // the staging, MFMA and epilogue phases of the two overlap: EDSR x4 b16 6.16 -> 5.58 ms, b32 13.1 -> 11.1, b8 3.45 -> 3.38 (profiles/r05_conv_big_tiles.txt; 6-row tiles,
+    // four phases, three or four workgroups per CU: slower).  Same K order per pixel as every other tile height: same bits.
+    if (c.Cin_p == 256 && c.compute_dtype == SR_BF16) return 8;
 #ifdef SR_BIG_TH
     if (c.Cin_p == 192) return SR_BIG_TH;  // experiment: short tiles (several workgroups per CU) for the 192-channel conv
 #endif
+#ifdef SR_BIG_TH256
+    if (c.Cin_p == 256) return SR_BIG_TH256;  // ... and for the 256-channel conv (EDSR body)
+#endif
     const int cost16 = ((big_tiles(c, 16) + 255) / 256) * 16, cost12 = ((big_tiles(c, 12) + 255) / 256) * 12;
     return cost12 < cost16 ? 12 : 16;
+}
+
+template <typename TIn>
+int dispatch_big8(const SrConv3x3& c, hipStream_t st) {  // (256 channels only: see big_tile_rows)
+#ifdef SR_BIG_PH256
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, 8, 4, 8, SR_BIG_PH256, false, 2>(c, st);
+#endif
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, 8, 4, 8, 2, false, 2>(c, st);
+    return SR_EUNSUPPORTED;
 }
 
 template <typename TIn, int TH>
@@ -401,6 +417,9 @@ int dispatch_big(const SrConv3x3& c, hipStream_t st) {
     if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf16, TIn, TH, 3, 6, SR_BIG_PH>(c, st);
 #endif
     if (c.Cin_p == 192 && big_nw(c) == 3) return launch_big<bf16, TIn, TH, 3, 6, 1>(c, st);
+#ifdef SR_BIG_PH256
+    if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, TH, 4, 8, SR_BIG_PH256>(c, st);
+#endif
     if (c.Cin_p == 256 && big_nw(c) == 4) return launch_big<bf16, TIn, TH, 4, 8, 2>(c, st);
     return SR_EUNSUPPORTED;
 }
@@ -434,6 +453,10 @@ bool sr_conv3x3_big_supported(const SrConv3x3& c) {
 }
 
 int sr_conv3x3_big(const SrConv3x3& c, hipStream_t st) {
+#ifdef SR_BIG_TH256
+    if (c.compute_dtype == SR_BF16 && c.Cin_p == 256) return c.x_dtype == SR_F32 ? dispatch_big<float, SR_BIG_TH256>(c, st) : dispatch_big<bf16, SR_BIG_TH256>(c, st);
+#endif
+    if (c.compute_dtype == SR_BF16 && big_tile_rows(c) == 8) return c.x_dtype == SR_F32 ? dispatch_big8<float>(c, st) : dispatch_big8<bf16>(c, st);
 #ifdef SR_BIG_TH
     if (c.compute_dtype == SR_BF16 && big_tile_rows(c) == SR_BIG_TH) return c.x_dtype == SR_F32 ? dispatch_big<float, SR_BIG_TH>(c, st) : dispatch_big<bf16, SR_BIG_TH>(c, st);
 #endif
