@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""sr_swin_block (round-3 stream kernel) against the round-2 kernel and the oracle on one RSTB-sized problem; then timings of both."""
+"""sr_swin_block (the one-launch stream kernel) against the un-fused launch sequence (QKV GEMM, window attention, projection GEMM, MLP) and the oracle on one RSTB-sized
+problem; then its launch time.  (Until round 5 the second implementation was the round-2 kernel, deleted with C ABI v10.)"""
 import os
 import sys
 
@@ -52,15 +53,17 @@ def main():
         t[..., geo.C:] = 0
         for bi, bp in enumerate(lp["blocks"]):
             outs = {}
-            for k in ("v2", "v3"):
-                os.environ["SR_SWIN_BLOCK"] = k
-                o = torch.empty_like(t)
-                SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"])
-                torch.cuda.synchronize()
-                outs[k] = o
-            d = (outs["v3"] - outs["v2"]).abs()
-            ref = (outs["v2"] - t).abs().max().item()
-            print(f"B={B} {H}x{W} block {bi} shift {bp['shift']}: max|v3-v2| {d.max().item():.3e}  mean {d.mean().item():.3e}  (max|v2-x| {ref:.3e})  pad max {outs['v3'][..., geo.C:].abs().max().item():.1e}", flush=True)
+            o = torch.empty_like(t)
+            SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"])
+            outs["stream"] = o
+            o2 = torch.empty_like(t)
+            SW.run_window_msa(bp, None, geo, t, o2, t, ws_, cdt, bp["shift"])
+            SW.run_mlp(bp, None, geo, o2, ws_, cdt)
+            torch.cuda.synchronize()
+            outs["unfused"] = o2
+            d = (outs["stream"] - outs["unfused"]).abs()
+            ref = (outs["unfused"] - t).abs().max().item()
+            print(f"B={B} {H}x{W} block {bi} shift {bp['shift']}: max|stream-unfused| {d.max().item():.3e}  mean {d.mean().item():.3e}  (max|unfused-x| {ref:.3e})  pad max {outs['stream'][..., geo.C:].abs().max().item():.1e}", flush=True)
     # oracle check of the whole reduced model (fp32 reference)
     try:
         from oracle import models as OM
@@ -69,22 +72,16 @@ def main():
         cfg = m.get_model_config()
         ref = OM.swinir_forward(sd, x, cfg, training=False) if hasattr(OM, "swinir_forward") else None
         if ref is not None:
-            for k in ("v2", "v3"):
-                os.environ["SR_SWIN_BLOCK"] = k
-                y = m(x.to(dev)).cpu()
-                print(f"model vs oracle ({k}): max |d| {(y - ref).abs().max().item():.3e}", flush=True)
+            y = m(x.to(dev)).cpu()
+            print(f"model vs oracle: max |d| {(y - ref).abs().max().item():.3e}", flush=True)
     except Exception as e:  # the oracle API differs: the pytest suite covers it
         print("oracle check skipped:", repr(e)[:200])
     bp = lp["blocks"][1]
     for B in (1, 4, 8, 16):
         t = torch.randn(B, 72, 72, geo.Cp, device=dev)
         t[..., geo.C:] = 0
-        res = {}
-        for k in ("v2", "v3"):
-            os.environ["SR_SWIN_BLOCK"] = k
-            res[k] = timeit(lambda: SW.run_swin_block(bp, geo, t, t, ws_, cdt, bp["shift"]))
-        print(f"B={B:2d} windows={B * 81:5d}  v2={res['v2']:7.1f}us  v3={res['v3']:7.1f}us", flush=True)
-
+        us = timeit(lambda: SW.run_swin_block(bp, geo, t, t, ws_, cdt, bp["shift"]))
+        print(f"B={B:2d} windows={B * 81:5d}  sr_swin_block={us:7.1f}us", flush=True)
 
 if __name__ == "__main__":
     main()

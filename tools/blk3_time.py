@@ -17,13 +17,12 @@ cdt = torch.bfloat16
 lp = m._get_packed(cdt)["layers"][0]
 geo, bp = lp["geo"], lp["blocks"][1]
 ws_ = S.runtime.Workspace(dev)
-kinds = sys.argv[1:] or ["v3"]
+kinds = ["v3"]  # (one kernel since C ABI v10; the argument is accepted for old command lines)
 for B in [int(b) for b in os.environ.get("SR_BS", "1,8,16").split(",")]:
     t = torch.randn(B, 72, 72, geo.Cp, device=dev)
     t[..., geo.C:] = 0
     o = torch.empty_like(t)
     res = {}
     for k in kinds:
-        os.environ["SR_SWIN_BLOCK"] = k
         res[k] = min(timeit(lambda: SW.run_swin_block(bp, geo, t, o, ws_, cdt, bp["shift"]), iters=30) for _ in range(3))
     print(f"B={B:2d} windows={B * 81:5d} " + " ".join(f"{k}={v:7.1f}us" for k, v in res.items()), flush=True)
