@@ -110,10 +110,9 @@ typedef struct SrSwinBlock {
     int y_mode;            /* SR_Y_* */
     int compute_dtype;     /* SR_BF16: bf16 operands (wstream 48 * 12 * 64 * 8 bf16); SR_BF16X3: split operands hi + lo (precision "fp32x3": fp32-class
                             * accuracy, wstream 48 * 12 * 64 * 16 bf16 = per lane 8 hi | 8 lo, erf GELU, bias pre-scaled by log2(e) as for bf16) */
-    int max_workgroups;    /* ABI v10.  0: one workgroup per window while all windows are resident at once (bf16: 3 per CU), otherwise that many persistent
-                            * workgroups, each walking windows b, b + grid, ... with the next window's rows fetched under the current result stores;
-                            * > 0: at most this many workgroups (two batches in flight: half the device each); < 0: always one workgroup per window.
-                            * Results do not depend on it (a window's arithmetic is the same whoever computes it). */
+    int max_workgroups;    /* ABI v10.  0 (and -1): one workgroup per window (default: fastest at every size measured); > 0: at most this many PERSISTENT workgroups,
+                            * each walking windows b, b + grid, ... with the next window's rows fetched under the current result stores; -2: as many as the
+                            * device holds at once (bf16: 3 per CU).  Results do not depend on it (a window's arithmetic is the same whoever computes it). */
 } SrSwinBlock;
 int sr_swin_block_supported(int C, int Cp, int heads, int hd_p, int ws, int Hp, int compute_dtype);
 int sr_swin_block(const SrSwinBlock* a, void* stream);

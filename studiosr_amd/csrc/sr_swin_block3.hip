@@ -557,12 +557,13 @@ extern "C" int sr_swin_block(const SrSwinBlock* p, void* stream) {
     dv.div_nw = make_fastdiv((uint32_t)(nwx * nwy));
     dv.div_nwx = make_fastdiv((uint32_t)nwx);
     dv.nwin = a.B * nwx * nwy;
-    // grid: one workgroup per window while they are all resident at once; beyond that (or when the caller asks: two batches in flight share the
-    // CUs as two grids of half the device each) persistent workgroups that walk windows b, b + grid, ... and prefetch the next window's rows
+    // grid: one workgroup per window (default: the hardware dispatcher backfills, which measured 2 % FASTER than the persistent form on a 2048 x 2048 image -- 66 k windows --
+    // and equal everywhere else); max_workgroups > 0: at most that many persistent workgroups, each walking windows b, b + grid, ... with the next window's rows
+    // prefetched; -2: as many as the device holds at once (three per CU; one for split operands)
     int grid = dv.nwin;
     if (a.max_workgroups > 0)
         grid = a.max_workgroups < grid ? a.max_workgroups : grid;
-    else if (a.max_workgroups == 0) {
+    else if (a.max_workgroups == -2) {
         const int slots = resident_workgroups(cdt == SR_BF16X3 ? 1 : 3);
         grid = slots < grid ? slots : grid;
     }

@@ -12,7 +12,7 @@ KNOBS = {
     "SR_WS_GUARD": ("", "diag", "workspace: poison + check guard bands around every buffer"),
     "SR_WS_BUDGET_MB": ("16384", "tune", "workspace: refuse to grow beyond this many MiB"),
     # ---- SwinIR (config 3)
-    "SR_BLOCK_WGS": ("0", "tune", "sr_swin_block grid: 0 automatic (persistent workgroups beyond one residency round), N at most N workgroups, -1 one per window"),
+    "SR_BLOCK_WGS": ("0", "tune", "sr_swin_block grid: 0 one workgroup per window (default), N at most N persistent workgroups, -2 as many as are resident at once"),
     "SR_SWIN_LIGHT": ("1", "select", "embed-60 geometry: the one-launch sr_swin_light kernel (0: QKV / attention / tail launches; bit-compared in tests)"),
     "SR_SWIN_PARTS": ("0", "tune", "a batch as N part batches on the model's streams inside a graph capture (0: two from 16 tiles on)"),
     "SR_SWIN_QKV": ("1", "select", "stream-form QKV kernel (0: the generic GEMM with LayerNorm prologue)"),

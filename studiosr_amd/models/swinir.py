@@ -278,7 +278,7 @@ def run_swin_block(p: Dict, geo: SwinGeometry, t_in: Tensor, t_out: Tensor, ws_,
         ops.swin_block(
             x=t_in.data_ptr(), out=t_out.data_ptr(), wstream=p["stream"].data_ptr(), bias=p["bias_frag_l2"].data_ptr(), B=B, H=H, W=W, C=geo.C,
             Cp=Cp, ldx=Cp, heads=geo.heads, hd_p=geo.hd_p, ws=geo.ws, shift=shift, Hp=geo.hid_p, eps=1e-5, y_mode=y_mode, compute_dtype=want,
-            max_workgroups=int(knob("SR_BLOCK_WGS", "0")),  # 0: automatic (persistent workgroups beyond one residency round); see SrSwinBlock.max_workgroups
+            max_workgroups=int(knob("SR_BLOCK_WGS", "0")),  # 0: one workgroup per window; N / -2: persistent workgroups (SrSwinBlock.max_workgroups)
         )
         return
     if p.get("light_dtype", -2) == want and knob("SR_SWIN_LIGHT", "1") != "0" and ops.swin_light_supported(geo.C, Cp, geo.heads, geo.hd, geo.ws, geo.hidden, want):

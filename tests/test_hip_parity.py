@@ -1237,7 +1237,7 @@ def test_swin_block_persistent_workgroups_equal_one_workgroup_per_window(prec):
         x[..., geo.C:] = 0
         for bp in lp["blocks"]:
             outs = {}
-            for wgs in (-1, 45, 16, 7, 1):
+            for wgs in (-1, -2, 45, 16, 7, 1):
                 S.runtime.reset_knobs()
                 os.environ["SR_BLOCK_WGS"] = str(wgs)
                 try:

@@ -12,7 +12,6 @@ import studiosr_amd as S
 import studiosr_amd._lib as L
 from studiosr_amd.models import swinir as SW
 
-os.environ.setdefault("SR_BLOCK_WGS", "-1")  # one workgroup per window also at B = 16 (the lifetimes below are per window)
 import bench  # noqa: E402  (the hash bench.py checks the profile against)
 
 print(f"# kernel_src_sha16 = {bench.dominant_kernel_src_sha16()}")
