@@ -43,7 +43,8 @@ struct Geo {
 // time, so K and V (as operand fragments) and K^T (in the accumulator-as-operand key order) of the window are staged in LDS once per window walk step
 // (3 x KT KiB, two barriers per window) instead of being fetched from L2 by every wave -- at one wave per SIMD (288 registers of logits and gradient tiles)
 // those 108 fragment loads per window were exposed L2 round trips: 436 -> see profiles/r04_train_trace_HAT.txt.
-template <int KT, int VAR, bool LDSK = false>
+// WS = window side of the shift mask (16: HAT; 8: SwinIR, 64 keys = KT 4 -- a 16-key tile is then two window rows).
+template <int KT, int VAR, bool LDSK = false, int WS = 16>
 __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(SrTrAttnBwd a) {
     extern __shared__ __attribute__((aligned(16))) char smem_q[];  // LDSK: K | V | K^T fragments
     const Frag<bf16>* KL = reinterpret_cast<const Frag<bf16>*>(smem_q);
@@ -144,19 +145,20 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
             s[kt] = mma_z(kf, qf);  // S^T[key 16 kt + 4 lg + r][query lr]
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps hipcc from hoisting every operand load of the pass at once (spills)
         }
-        // + bias (+ shift mask: 16 x 16 windows, so key 16 kt + 4 lg + r sits at window row kt, column 4 lg + r)
+        // + bias (+ shift mask: key 16 kt + 4 lg + r sits at window row kt, column 4 lg + r of a 16 x 16 window; row 2 kt + (lg >> 1), column 4 (lg & 1) + r of an 8 x 8 one)
         const int win = bwin % (nwx * nwy);
         const int wy = win / nwx, wx = win - wy * nwx;
         const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
-        const int qrow = region(wy * 16 + (qi >> 4), a.H, 16, a.shift), qcol = region(wx * 16 + (qi & 15), a.W, 16, a.shift);
+        const int qrow = region(wy * WS + qi / WS, a.H, WS, a.shift), qcol = region(wx * WS + qi % WS, a.W, WS, a.shift);
+        const int kcol0 = WS == 16 ? lg * 4 : (lg & 1) * 4;
         bool cdiff[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != qcol;
+        for (int r = 0; r < 4; ++r) cdiff[r] = region(wx * WS + kcol0 + r, a.W, WS, a.shift) != qcol;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             if constexpr (!LDSK) s[kt] += *reinterpret_cast<const f32x4*>(bias + kt * 16 + lg * 4);
             if (masked) {
-                const bool rdiff = region(wy * 16 + kt, a.H, 16, a.shift) != qrow;
+                const bool rdiff = region(wy * WS + (WS == 16 ? kt : 2 * kt + (lg >> 1)), a.H, WS, a.shift) != qrow;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (rdiff || cdiff[r]) s[kt][r] += -100.0f;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
 }
 
 // ---- pass KV.  QT = query tiles (Nq / 16, even); every wave owns KPW consecutive key tiles, so each query-side fragment is loaded once per KPW tiles
-template <int QT, int KPW>
+template <int QT, int KPW, int WS = 16>
 __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
         kf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.k) + (bh * a.Nk + ki) * 32 + lg * 8);
         vf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.v) + (bh * a.Nk + ki) * 32 + lg * 8);
         biasT[u] = a.biasT + ((size_t)head * a.Nk + ki) * NQ;
-        krow[u] = region(wy * 16 + (ki >> 4), a.H, 16, a.shift);
-        const int kcol = region(wx * 16 + (ki & 15), a.W, 16, a.shift);
+        krow[u] = region(wy * WS + ki / WS, a.H, WS, a.shift);
+        const int kcol = region(wx * WS + ki % WS, a.W, WS, a.shift);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cdiff[u][r] = region(wx * 16 + lg * 4 + r, a.W, 16, a.shift) != kcol;
+        for (int r = 0; r < 4; ++r) cdiff[u][r] = region(wx * WS + (WS == 16 ? lg * 4 : (lg & 1) * 4) + r, a.W, WS, a.shift) != kcol;  // query 16 qt + 4 lg + r: its column
         dk[u][0] = dk[u][1] = dv[u][0] = dv[u][1] = (f32x4)(0.0f);
     }
 #ifndef SR_KV_UNROLL
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
             const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
             const int q0 = qt * 16 + lg * 4;
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + q0), d4 = *reinterpret_cast<const f32x4*>(delta + q0);
-            const int qrow = region(wy * 16 + qt, a.H, 16, a.shift);
+            const int qrow = region(wy * WS + (WS == 16 ? qt : 2 * qt + (lg >> 1)), a.H, WS, a.shift);
 #pragma unroll
             for (int u = 0; u < KPW; ++u) {
                 f32x4 s = mma_z(qf, kf[u]);          // S[query 16 qt + 4 lg + r][key lr]
@@ -551,19 +553,28 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
                    p->dtab_part && p->rpi,
                "sr_tr_attn_bwd: null pointer");
     const SrTrAttnBwd& a = *p;
-    SR_REQUIRE(a.hd_p == 32 && a.Nq == 256 && (a.Nk == 256 || a.Nk == 576) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 && a.groups <= a.n_bwin && a.ldo >= a.heads * 32 &&
-                   a.ldo % 8 == 0,
-               "sr_tr_attn_bwd: unsupported geometry (hd_p 32, Nq 256, Nk 256 / 576)");
-    SR_REQUIRE(a.shift == 0 || (a.Nk == a.Nq && a.ws == 16 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0),
-               "sr_tr_attn_bwd: the shift mask needs the window geometry");
-    SR_REQUIRE(a.shift == 0 || (a.ws > 0 && a.H > 0 && a.W > 0), "sr_tr_attn_bwd: geometry");
+    const bool w8 = a.Nq == 64;  // 8 x 8 windows (SwinIR, swinir.py:83-102): the two register passes with four key / query tiles
+    SR_REQUIRE(a.hd_p == 32 && ((a.Nq == 256 && (a.Nk == 256 || a.Nk == 576)) || (w8 && a.Nk == 64 && !a.toeplitz16 && !a.oca_rel)) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 &&
+                   a.groups <= a.n_bwin && a.ldo >= a.heads * 32 && a.ldo % 8 == 0,
+               "sr_tr_attn_bwd: unsupported geometry (hd_p 32; Nq 256 with Nk 256 / 576, or Nq = Nk = 64)");
+    SR_REQUIRE(a.shift == 0 || (a.Nk == a.Nq && a.ws * a.ws == a.Nq && a.H % a.ws == 0 && a.W % a.ws == 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0),
+               "sr_tr_attn_bwd: the shift mask needs the window geometry (ws * ws == Nq)");
+    SR_REQUIRE(a.shift == 0 || (a.ws > 0 && a.H > 0 && a.W > 0 && a.shift < a.ws), "sr_tr_attn_bwd: geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     SrTrAttnBwd b = a;
     if (b.shift == 0) {  // the kernels divide by the window geometry even when no mask applies
-        b.ws = 16;
-        b.H = b.W = 16;
+        b.ws = w8 ? 8 : 16;
+        b.H = b.W = b.ws;
     }
     SR_REQUIRE(a.T > 0 && a.T <= 1536 && a.Tpad >= a.T, "sr_tr_attn_bwd: the bias table has at most 1536 rows");
+    if (w8) {
+        const int items = a.groups * a.heads * 4;
+        hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<4, 0, false, 8>), dim3((items + 3) / 4), dim3(256), 0, st, b);
+        SR_CHECK_LAUNCH("sr_tr_attn_bwd (q, 8 x 8 windows)");
+        hipLaunchKernelGGL((sr_tr_attn_bwd_kv_kernel<4, 2, 8>), dim3((a.n_bwin * a.heads * 2 + 3) / 4), dim3(256), 0, st, b);
+        SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv, 8 x 8 windows)");
+        return SR_OK;
+    }
     if (sr_tr_attn_bwd_lds_usable(b)) return sr_tr_attn_bwd_lds(b, st);  // 16 x 16 windows, one table partial per (head, window): everything in LDS, one launch
     const int items_q = a.groups * a.heads * (a.Nq / 16);
     const int var = 1;  // (0: the generic index-map fold)

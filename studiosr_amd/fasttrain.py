@@ -34,6 +34,7 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
+W8_GROUPS = int(os.environ.get("SR_TR_W8_GROUPS", "128"))  # tuning knob: window groups of the attention backward's pass Q for 8 x 8 windows (SwinIR)
 BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
 _SIDE = {}
 
@@ -462,17 +463,20 @@ def pack_bias_rel(b: IM, rpi: np.ndarray, T: int) -> Optional[IM]:
 
 # --------------------------------------------------------------------------- one block (HAB or OCAB)
 class BlockPlan:
-    """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195) or OCAB (hat.py:107-118,239-293; oca = True: no CAB, no shift,
-    no DropPath, keys / values from the unfolded 24 x 24 neighbourhood)."""
+    """Offsets, maps and static buffers of one HAB (hat.py:95-104,153-195), one OCAB (hat.py:107-118,239-293; oca = True: no CAB, no shift,
+    no DropPath, keys / values from the unfolded 24 x 24 neighbourhood) or one SwinTransformerBlock of SwinIR (swinir.py:105-174; ws = 8: 64-token
+    windows, no conv branch -- the same four block kernels, which walk 64 window-order tokens per workgroup whatever the window)."""
 
-    def __init__(self, fp: FlatParams, blk, rpi: np.ndarray, rpi_dev: Tensor, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: "FinalMap", oca: bool = False) -> None:
-        self.shift, self.conv_scale, self.oca = shift, float(conv_scale), oca
+    def __init__(self, fp: FlatParams, blk, rpi: np.ndarray, rpi_dev: Tensor, conv_scale: float, shift: int, wa: Arena, fa: Arena, fm: "FinalMap", oca: bool = False,
+                 ws: int = 16) -> None:
+        self.shift, self.conv_scale, self.oca, self.ws = shift, float(conv_scale), oca, ws
         self._ev = None  # (fork, join) events of the backward's side stream
         self.fp, self.blk, self.fm, self.rpi_dev = fp, blk, fm, rpi_dev
         at = blk if oca else blk.attn  # OCAB holds qkv / proj / table itself
         mlp = blk.mlp
         self.at, self.mlp = at, mlp
-        self.nk = 576 if oca else 256
+        self.nq = ws * ws
+        self.nk = 576 if oca else self.nq
         self.o_qkvf = wa.add(pack_qkv_fwd(fp, at.qkv.weight, at.qkv.bias))
         self.o_tailf = wa.add(pack_tail_fwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
         self.o_tailb = wa.add(pack_tail_bwd(fp, at.proj.weight, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias))
@@ -481,14 +485,14 @@ class BlockPlan:
         self.o_g2, self.o_b2 = fa.add(pack_vec(fp, blk.norm2.weight, CP)), fa.add(pack_vec(fp, blk.norm2.bias, CP))
         self.o_bp = fa.add(pack_vec(fp, at.proj.bias, CP))
         self.table = at.relative_position_bias_table
-        b, bt, bf, b31 = pack_bias(fp, self.table, rpi, 256, self.nk)
+        b, bt, bf, b31 = pack_bias(fp, self.table, rpi, self.nq, self.nk)
         self.o_bias, self.o_biasT = fa.add(b), fa.add(bt)
         self.o_biasF = None if oca else fa.add(bf)
         self.o_bias31 = None if (oca or b31 is None or not ATTN_LDS) else fa.add(b31)
         rel = pack_bias_rel(b, rpi, self.table.shape[0]) if oca else None
         self.o_bias_rel = None if rel is None else fa.add(rel)
         self.cab = None
-        if not oca:
+        if not oca and hasattr(blk, "conv_block"):
             cab = blk.conv_block.cab
             ca = cab[3].attention
             self.cab, self.ca_mod = cab, ca
@@ -526,10 +530,16 @@ class BlockPlan:
     def prepare(self, B: int, H: int, W: int, dev, groups: int) -> None:
         """Geometry-dependent parts: gradient partial buffers that depend on the number of workgroups / images; static activations."""
         fp, fm = self.fp, self.fm
-        nbw_ = B * H * W // 256
+        nbw_ = B * H * W // self.nq
         # HAB with the LDS form of the attention backward (csrc/sr_tr_attn_lds.hip): one bias-table partial per (head, window), i.e. groups * 4 == windows;
-        # OCAB (and HABs without it): `groups` window groups whose pass-Q workgroups walk their windows with the gradient tiles in registers
-        self.groups = nbw_ // 4 if (not self.oca and nbw_ % 4 == 0 and ATTN_BWD_LDS) else groups
+        # OCAB (and HABs without it): `groups` window groups whose pass-Q workgroups walk their windows with the gradient tiles in registers;
+        # 8 x 8 windows: one workgroup of pass Q = (head, group, the window's 64 queries); W8_GROUPS groups at most (each walks nbw_ / groups windows)
+        if self.ws == 8:
+            self.groups = max(1, min(nbw_, W8_GROUPS))
+            while nbw_ % self.groups:
+                self.groups -= 1
+        else:
+            self.groups = nbw_ // 4 if (not self.oca and nbw_ % 4 == 0 and ATTN_BWD_LDS) else groups
         nwg = B * H * W // 64
         self.f_ln1, self.f_ln2 = fm.alloc(nwg * 2 * CP), fm.alloc(nwg * 2 * CP)
         for f, norm in ((self.f_ln1, self.blk.norm1), (self.f_ln2, self.blk.norm2)):
@@ -558,7 +568,7 @@ class BlockPlan:
             fm.put(fp.pidx(ca[3].bias), o + cr * C_REAL + cr + C_REAL * cr + np.arange(C_REAL), self.ca_stride, B)
         tb = self.table  # [T, heads]: one table-sized partial per pass-Q workgroup, a head's groups * 4 workgroups consecutive (sr_tr_attn_bwd)
         self.tpad = (tb.shape[0] + 63) // 64 * 64
-        nq_wg = self.groups * 4
+        nq_wg = self.groups * (self.nq // 64)
         self.f_tab = fm.alloc(HEADS * nq_wg * self.tpad)
         fm.put(fp.pidx(tb), self.f_tab + np.arange(HEADS)[None, :] * nq_wg * self.tpad + np.arange(tb.shape[0])[:, None], self.tpad, nq_wg)
         T = B * H * W
@@ -571,19 +581,21 @@ class BlockPlan:
             self.k, self.kT, self.v = e(n), e(n), e(n)  # the unfolded neighbourhoods
         else:
             self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(4))
-            self.n1, self.y = e(T, CP), e(T, CP)
-            self.mid_pre = e(T, 64) if CAB_MIDPRE else None  # conv1's pre-activation, kept by the forward (2 MB per block at 4 x 64 x 64) instead of being recomputed
-            self.n_tiles = ops.cab_pool_tiles(H, W)
-            self.pool = e(B, self.n_tiles, CP, dt=f32)
-            self.gate = e(B, CP, dt=f32)
+            self.n1 = None
+            if self.cab is not None:
+                self.n1, self.y = e(T, CP), e(T, CP)
+                self.mid_pre = e(T, 64) if CAB_MIDPRE else None  # conv1's pre-activation, kept by the forward (2 MB per block at 4 x 64 x 64) instead of being recomputed
+                self.n_tiles = ops.cab_pool_tiles(H, W)
+                self.pool = e(B, self.n_tiles, CP, dt=f32)
+                self.gate = e(B, CP, dt=f32)
 
     # ------------------------------------------------------------------ forward
     def forward(self, st: "Stage", cur: Tensor, out: Tensor, sc_i: Optional[Tensor]) -> None:
         B, H, W = st.geo
         wa, fa, sc = st.wa.buf, st.fa.buf, st.sc
         lib = L.lib()
-        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
-        nbw = B * H * W // 256
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=self.ws, eps=1e-5)
+        nbw = B * H * W // self.nq
         if self.oca:
             _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
                   wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=sc.dk.data_ptr(), kT=sc.dq.data_ptr(), v=sc.dv.data_ptr(),
@@ -598,10 +610,13 @@ class BlockPlan:
         else:
             _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
                   wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
-                  vT=self.vT.data_ptr(), n1=self.n1.data_ptr(), ldn=CP, shift=self.shift, **g)
+                  vT=self.vT.data_ptr(), n1=None if self.n1 is None else self.n1.data_ptr(), ldn=CP, shift=self.shift, **g)
             akw = dict(q=self.q.data_ptr(), k=self.k.data_ptr(), vt=self.vT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), out=self.o.data_ptr(), n_bwin=nbw,
-                       heads=HEADS, hd_p=HDP, ntok=256, H=H, W=W, ws=16, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
+                       heads=HEADS, hd_p=HDP, ntok=self.nq, H=H, W=W, ws=self.ws, shift=self.shift, dtype=L.SR_BF16, y_mode=L.Y_ROLL,
                        bias_frag=fa[self.o_biasF:].data_ptr(), qkv_frag=0, bias_tiles=None if self.o_bias31 is None else fa[self.o_bias31:].data_ptr())
+        if not self.oca and self.cab is None:  # SwinIR: attention only (swinir.py:146-163)
+            ops.window_attention(**akw)
+        elif not self.oca:
             ckw = dict(x=self.n1.data_ptr(), w1p=wa[self.o_c1:].data_ptr(), b1=fa[self.o_bc1:].data_ptr(), w2p=wa[self.o_c2:].data_ptr(), b2=fa[self.o_bc2:].data_ptr(),
                        y=self.y.data_ptr(), pool_partial=self.pool.data_ptr(), B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16,
                        mid_pre=None if self.mid_pre is None else self.mid_pre.data_ptr())
@@ -625,7 +640,7 @@ class BlockPlan:
         T = B * H * W
         wa, fa, sc, fm = st.wa.buf, st.fa.buf, st.sc, st.fm
         lib = L.lib()
-        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=16, eps=1e-5)
+        g = dict(B=B, H=H, W=W, C=C_REAL, Cp=CP, ldx=CP, heads=HEADS, hd_p=HDP, ws=self.ws, eps=1e-5)
         pp = lambda off: fm.part.data_ptr() + 4 * off  # noqa: E731
         s_a = None if sc_i is None else sc_i[0].data_ptr()
         s_m = None if sc_i is None else sc_i[1].data_ptr()
@@ -645,7 +660,7 @@ class BlockPlan:
               dhw=op.dhw.data_ptr(), dOw=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), dx1sw=op.dx1sw.data_ptr(), ln_part=pp(self.f_ln2), ldy=CP, shift=self.shift, Hp=HP, **kw, **g)
         # HAB: the CAB branch of the backward (channel attention, the two data-gradient convs, GELU') only shares sr_tr_tail_bwd's outputs with the attention
         # backward and joins it in sr_tr_qkv_bwd: it runs on a side stream beside sr_tr_attn_bwd (two event edges per block; SR_TR_BWD_DUAL=0: one stream)
-        dual = BWD_DUAL and not self.oca
+        dual = BWD_DUAL and self.cab is not None
         if dual:
             side = _side_stream(main.device)
             if self._ev is None:
@@ -656,8 +671,9 @@ class BlockPlan:
         dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
-              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // 256,
-              heads=HEADS, hd_p=HDP, Nq=256, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca), H=H, W=W, ws=16, shift=self.shift,
+              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // self.nq,
+              heads=HEADS, hd_p=HDP, Nq=self.nq, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca and self.ws == 16), H=H, W=W,
+              ws=self.ws, shift=self.shift,
               oca_rel=int(self.oca and self.o_bias_rel is not None))
         jobs = []
         ks = WG_KS
@@ -669,10 +685,10 @@ class BlockPlan:
         elif dual:
             _edge(side, main, self._ev[1])
             jobs += jobs_cab
-        else:
+        elif self.cab is not None:
             jobs += self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
         _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
-              dn1c=None if self.oca else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
+              dn1c=None if self.cab is None else sc.dn1c.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(), wstream=wa[self.o_qkvb:].data_ptr(), dx=dx.data_ptr(),
               n1w=op.n1w.data_ptr(), dqkvw=op.dqkvw.data_ptr(), ln_part=pp(self.f_ln1), ldn=CP, shift=self.shift, **g)
         wg = _wg_stream(main.device) if WG_SIDE else None
         if wg is not None:  # the weight gradients only feed the stage's sr_tr_finalize_to: they leave the critical path of the backward pass
@@ -710,7 +726,7 @@ class BlockPlan:
 class Scratch:
     """Backward scratch shared by all blocks of a model (one block's backward at a time)."""
 
-    def __init__(self, B: int, H: int, W: int, dev, groups: int) -> None:
+    def __init__(self, B: int, H: int, W: int, dev, groups: int, oca: bool = True) -> None:
         T = B * H * W
         bf, f32 = torch.bfloat16, torch.float32
         e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
@@ -720,11 +736,12 @@ class Scratch:
         self.dOT, self.dq, self.dk, self.dv = (e(T * CP) for _ in range(4))
         self.dqkvw = e(T, 3 * CP)
         self.dgate_part = e(T // 64, CP, dt=f32)
-        self.lse, self.delta = e(T // 256 * HEADS * 256, dt=f32), e(T // 256 * HEADS * 256, dt=f32)
+        self.lse, self.delta = e(T * HEADS, dt=f32), e(T * HEADS, dt=f32)
         self.groups = groups
         self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))
-        n = T // 256 * HEADS * 576 * 32  # OCAB: unfolded neighbourhoods
-        self.vwinT, self.dkwin, self.dvwin = e(n), e(n), e(n)
+        if oca:
+            n = T // 256 * HEADS * 576 * 32  # OCAB: unfolded neighbourhoods
+            self.vwinT, self.dkwin, self.dvwin = e(n), e(n), e(n)
         # The operands of the weight-gradient launches exist twice: consecutive blocks of a backward pass alternate between the two sets, so that a block's
         # sr_tr_wgrad can run on its own stream beside the NEXT block's kernels (which write the other set).  wg_busy[k]: the point on the weight-gradient
         # stream behind the last launch that reads set k (None: free); `turn` counts the blocks of the running backward pass.
@@ -778,7 +795,7 @@ def _call(fn, struct, what: str, **kw) -> None:
 class Stage:
     """The blocks of one RHAG (six HABs, then the OCAB) with their gradient map; forward / backward as launch sequences."""
 
-    def __init__(self, fp: FlatParams, habs, ocab, rpi_sa: Tensor, rpi_oca: Tensor, conv_scale: float, wa: Arena, fa: Arena, extra=None) -> None:
+    def __init__(self, fp: FlatParams, habs, ocab, rpi_sa: Optional[Tensor], rpi_oca: Optional[Tensor], conv_scale: float, wa: Arena, fa: Arena, extra=None, ws: int = 16) -> None:
         """extra: a module whose parameters join the stage's gradient map (the RHAG's closing conv, hat.py:356: its weight gradient is finalised with the stage's, so
         that a stage's backward leaves ALL of its layer's gradients complete -- what DistributedDataParallel's buckets need to start reducing)."""
         self.fp, self.wa, self.fa = fp, wa, fa
@@ -788,10 +805,12 @@ class Stage:
         p1 = max(fp.off(p) + (p.numel() + 3) // 4 * 4 for p in params)
         self.params = params
         self.fm = FinalMap(fp, p0, p1)
-        sa_dev, oca_dev = rpi_sa.detach().to(torch.int32).contiguous(), rpi_oca.detach().to(torch.int32).contiguous()
-        self.blocks = [BlockPlan(fp, b, rpi_sa.detach().cpu().numpy(), sa_dev, conv_scale, b.shift_size, wa, fa, self.fm) for b in habs]
+        self.blocks = []
+        for b in habs:  # the relative-position index: one buffer per model (HAT, hat.py:480-492) or per attention module (SwinIR, swinir.py:56-67)
+            r = rpi_sa if rpi_sa is not None else b.attn.relative_position_index
+            self.blocks.append(BlockPlan(fp, b, r.detach().cpu().numpy(), r.detach().to(torch.int32).contiguous(), conv_scale, b.shift_size, wa, fa, self.fm, ws=ws))
         if ocab is not None:
-            self.blocks.append(BlockPlan(fp, ocab, rpi_oca.detach().cpu().numpy(), oca_dev, 0.0, 0, wa, fa, self.fm, oca=True))
+            self.blocks.append(BlockPlan(fp, ocab, rpi_oca.detach().cpu().numpy(), rpi_oca.detach().to(torch.int32).contiguous(), 0.0, 0, wa, fa, self.fm, oca=True))
         self.n_habs = len(habs)
         self.geo = None
         self.gen = 0
@@ -1037,18 +1056,25 @@ def run_model(plan: "HatPlan", x: Tensor) -> Tensor:
 
 # --------------------------------------------------------------------------- whole-model plan
 class HatPlan:
-    """Fast-path plan of a HAT model: FlatParams, the two arenas, one Stage per RHAG (its six HABs)."""
+    """Fast-path plan of a HAT model (FlatParams, the two arenas, one Stage per RHAG: its six HABs and its OCAB) or -- round 5 -- of a SwinIR model of the
+    default geometry (swinir.py:258-339: one Stage per RSTB, 8 x 8 windows, no conv branch, no OCAB; everything outside the blocks is the same sequence)."""
 
     def __init__(self, model) -> None:
         self.model = model
+        self.swin = type(model).__name__ == "SwinIR"
+        self.ws = int(model.window_size)
         self.fp = FlatParams(model)
         dev = self.fp.P.device
         self.wa, self.fa = Arena(torch.bfloat16), Arena(torch.float32)
-        with_oca = os.environ.get("SR_FAST_OCAB", "1") != "0"
+        with_oca = not self.swin and os.environ.get("SR_FAST_OCAB", "1") != "0"
         self.with_oca = with_oca
-        self.full = with_oca and os.environ.get("SR_FAST_FULL", "1") != "0"  # the whole model on fused launches (forward_model / backward_model, or the node chain)
-        self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
-                             model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa, extra=layer.conv if self.full else None) for layer in model.layers]
+        self.full = (with_oca or self.swin) and os.environ.get("SR_FAST_FULL", "1") != "0"  # the whole model on fused launches (forward_model / backward_model, or the node chain)
+        if self.swin:
+            self.stages = [Stage(self.fp, list(layer.residual_group.blocks), None, None, None, 0.0, self.wa, self.fa, extra=layer.conv if self.full else None, ws=self.ws)
+                           for layer in model.layers]
+        else:
+            self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
+                                 model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa, extra=layer.conv if self.full else None) for layer in model.layers]
         # ---- everything outside the blocks (hat.py:519-554): conv_first, patch_embed.norm, the RHAG convs, norm, conv_after_body, the upsampling tail
         from . import packing
         from .models.swinir import final_affine, ingest_affine
@@ -1097,6 +1123,10 @@ class HatPlan:
     @staticmethod
     def supported(model) -> bool:
         try:
+            if type(model).__name__ == "SwinIR":  # the default (classical SR) geometry: embed 180, six heads, 8 x 8 windows, mlp ratio 2, 3x3 convs, pixelshuffle tail
+                return (len(set(model.depths)) == 1 and model.embed_dim == C_REAL and model.window_size == 8 and all(h == HEADS for h in model.num_heads) and
+                        int(model.embed_dim * model.mlp_ratio) == HID and model.upsampler == "pixelshuffle" and isinstance(model.conv_after_body, torch.nn.Conv2d) and
+                        all(isinstance(layer.conv, torch.nn.Conv2d) for layer in model.layers) and next(model.parameters()).is_cuda)
             return (type(model).__name__ == "HAT" and len(set(model.depths)) == 1 and model.embed_dim == C_REAL and model.window_size == 16 and all(h == HEADS for h in model.num_heads) and
                     int(model.embed_dim * model.mlp_ratio) == HID and int(model.window_size * model.overlap_ratio) == 8 and model.embed_dim // model.compress_ratio == 60 and model.embed_dim // model.squeeze_factor == CR and
                     next(model.parameters()).is_cuda)
@@ -1116,7 +1146,7 @@ class HatPlan:
         groups = max(1, min(nbw, int(os.environ.get("SR_TR_GROUPS", str(max(1, 256 // (HEADS * 4)))))))
         while nbw % groups:
             groups -= 1
-        self.scratch = Scratch(B, H, W, dev, groups)
+        self.scratch = Scratch(B, H, W, dev, groups, oca=self.with_oca)
         for c, st in zip(self.c_layers, self.stages):  # (before the stage finishes its map: the RHAG's closing conv is part of it)
             c.prepare(st.fm if self.full else fm, B, H, W)
         for s in self.stages:

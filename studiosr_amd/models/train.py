@@ -120,6 +120,12 @@ def swinir_forward(model, x: Tensor) -> Tensor:
     else:  # check_image_size_for_eval (swinir.py:249-255)
         Hp, Wp, pad_mode = (H // ws + 1) * ws, (W // ws + 1) * ws, L.PAD_EVAL_MIRROR
     ing, fin = _affines(model.img_range, model.n_colors, x.device)
+    if model.training:  # the whole step as fused launches (studiosr_amd/fasttrain.py) when the geometry is the default one, as HAT's
+        plan = _fast_plan(model, B, Hp, Wp)
+        if plan is not None and plan.full:
+            from .. import fasttrain
+
+            return fasttrain.run_model(plan, x)
     first = _conv(_ingest(x, Hp, Wp, pad_mode, *ing), model.conv_first, cin=model.n_colors)
     t = A.layer_norm(first, model.patch_embed.norm.weight, model.patch_embed.norm.bias)
     dpr = _drop_rates(model)
@@ -157,7 +163,7 @@ def _fast_plan(model, B: int, Hp: int, Wp: int):
         return None
     from .. import fasttrain
 
-    if Hp % 16 or Wp % 16:
+    if Hp % model.window_size or Wp % model.window_size:
         return None
     plan = fasttrain.get_plan(model)
     if plan is None:

@@ -297,9 +297,9 @@ def test_trainer_class_runs_saves_and_resumes(tmp_path):
 
 
 # --------------------------------------------------------------------------- fused training path (studiosr_amd/fasttrain.py, C ABI v7)
-def _default_width_hat(depths=(2,), drop_path_rate=0.0, scale=2):
+def _default_width_hat(depths=(2,), drop_path_rate=0.0, scale=2, kind="HAT"):
     torch.manual_seed(0)
-    m = S.HAT(scale=scale, depths=list(depths), num_heads=[6] * len(depths), drop_path_rate=drop_path_rate)
+    m = getattr(S, kind)(scale=scale, depths=list(depths), num_heads=[6] * len(depths), drop_path_rate=drop_path_rate)
     with torch.no_grad():
         for n_, p_ in m.named_parameters():
             if p_.ndim == 1:
@@ -331,14 +331,14 @@ def _rel(a, b):
     return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("size", [(32, 32), (24, 40)])
-def test_fused_training_path_matches_the_generic_engine(size):
+@pytest.mark.parametrize("size,kind", [((32, 32), "HAT"), ((24, 40), "HAT"), ((32, 32), "SwinIR"), ((20, 27), "SwinIR")])
+def test_fused_training_path_matches_the_generic_engine(size, kind):
     """The fused HAT step (one autograd node: sr_tr_* launches, bf16 operands as under the reference Trainer's autocast, trainer.py:80,102)
     against the generic engine whose gradients are pinned to the reference by the f15 fixtures: default block width (embed 180, 6 heads,
     16 x 16 windows incl. a shifted block, CAB, OCAB), two images.  Yardstick as test_gradients_under_bf16_autocast: both bf16 computations
     are compared with the exact-fp32 step; the fused one may not be noisier than the generic bf16 one (x 1.15 + 2e-3).  (24, 40): reflect
-    padding to 32 x 48 and a cropped output."""
-    m = _default_width_hat()
+    padding to 32 x 48 and a cropped output.  SwinIR (round 5): the same with 8 x 8 windows and no conv branch / OCAB (swinir.py:105-174,258-339); (20, 27) pads to 24 x 32."""
+    m = _default_width_hat(kind=kind)
     torch.manual_seed(3)
     x = torch.rand(2, 3, *size, device=DEV)
     y = torch.rand(2, 3, size[0] * 2, size[1] * 2, device=DEV)
@@ -367,19 +367,20 @@ _FUSED_GROUPS = {
 }
 
 
-@pytest.mark.parametrize("size", [(32, 32), (24, 40)])
-def test_fused_training_step_against_oracle_autograd(size):
+@pytest.mark.parametrize("size,kind", [((32, 32), "HAT"), ((24, 40), "HAT"), ((32, 32), "SwinIR"), ((20, 27), "SwinIR")])
+def test_fused_training_step_against_oracle_autograd(size, kind):
     """BASELINE config 5's PRODUCT path pinned to the oracle directly: the fused HAT training step (fasttrain.py: ONE autograd
     node of sr_tr_* launches, taken at the default block width under the reference Trainer's autocast, trainer.py:97-109 on hat.py:153-195,239-293)
     against torch autograd through the fp32 CPU oracle (pinned to the reference's own gradients by the f15 fixtures): default width (embed 180,
     6 heads, 16 x 16 windows, a shifted HAB, CAB, OCAB), batch 2, 32 x 32 and the reflect-padded 24 x 40.  Output, loss and EVERY parameter
     gradient; yardstick of test_gradients_under_bf16_autocast (bf16 operands, fp32 accumulate: whole gradient <= 4e-2, every tensor <= 0.15
-    relative L2), and the same bounds per producing kernel."""
-    m = _default_width_hat()
+    relative L2), and the same bounds per producing kernel.  SwinIR: the default-width RSTB (8 x 8 windows, a shifted block; swinir.py:105-174,391-402)
+    through the same kernels, against OM.swinir_forward."""
+    m = _default_width_hat(kind=kind)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     torch.manual_seed(3)
     x, y = torch.rand(2, 3, *size), torch.rand(2, 3, size[0] * 2, size[1] * 2)
-    ref_out, ref = _oracle_grads(OM.hat_forward, sd, x, y, m.get_model_config(), True)
+    ref_out, ref = _oracle_grads(OM.hat_forward if kind == "HAT" else OM.swinir_forward, sd, x, y, m.get_model_config(), True)
     ref_loss = float(F.l1_loss(ref_out, y))
     lf, gf, of = _train_step(m, x.to(DEV), y.to(DEV), True, True)
     assert m._fast_plan is not None and m._fast_plan.full  # the fused path really ran
@@ -401,6 +402,8 @@ def test_fused_training_step_against_oracle_autograd(size):
         per_group[hit[0]][1] += r2
     assert (num / den) ** 0.5 <= 4e-2, f"whole gradient: relative L2 {(num / den) ** 0.5:.3e}"
     for k, (e2, r2) in per_group.items():
+        if kind == "SwinIR" and "channel-attention" in k:
+            continue  # no conv branch in a SwinTransformerBlock
         assert r2 > 0, k
         print(f"{k}: relative L2 {(e2 / r2) ** 0.5:.3e}")
         assert (e2 / r2) ** 0.5 <= 6e-2, (k, (e2 / r2) ** 0.5)
@@ -760,14 +763,17 @@ os.write(1, f"\\nOVERLAP_OK_{{int(nodes)}}_R{{rank}} worst {{worst:.2e}} buckets
         assert p.returncode == 0 and all(f"OVERLAP_OK_{nodes}_R{r}" in p.stdout for r in (0, 1)), p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass")])
+@pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass"), (0, "w8"), (4, "w8"), (3, "w8")])
 def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
     """sr_tr_attn_bwd (swinir.py:83-102 / hat.py:90-107 under loss.backward()) on 16 x 16 windows against torch autograd of softmax(q k^T + table[rpi] + mask) v on
     the same bf16-rounded operands: dq, dk, dv and the relative_position_bias_table gradient.  "lds" = the one-launch LDS form (csrc/sr_tr_attn_lds.hip, taken when
-    groups * 4 == n_bwin: one table partial per (head, window)), "two-pass" = the register-only passes of csrc/sr_tr_attn.hip; masked windows included."""
+    groups * 4 == n_bwin: one table partial per (head, window)), "two-pass" = the register-only passes of csrc/sr_tr_attn.hip; masked windows included.
+    "w8" = SwinIR's 8 x 8 windows (64 keys: the register passes with four tiles, a 16-key tile = two window rows; groups < windows: a workgroup walks several)."""
     from studiosr_amd import _lib as L, autograd as A, fasttrain as FT
     from studiosr_amd.models.hat import rpi_sa
 
+    if form == "w8":
+        return _attention_backward_w8(shift)
     bf = torch.bfloat16
     torch.manual_seed(1)
     Bn, H, W = 2, 32, 48
@@ -806,4 +812,47 @@ def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
     assert rel(dq, q_.grad) <= 8e-3 and rel(dk, k_.grad) <= 8e-3 and rel(dv, v_.grad) <= 8e-3, (rel(dq, q_.grad), rel(dk, k_.grad), rel(dv, v_.grad))
     dtab = dtp.reshape(h, groups * 4, 1024).sum(1)[:, :961].t()
+    assert rel(dtab, table.grad) <= 2e-3, rel(dtab, table.grad)
+
+
+def _attention_backward_w8(shift):
+    from studiosr_amd import _lib as L, autograd as A, fasttrain as FT
+
+    bf = torch.bfloat16
+    torch.manual_seed(2)
+    Bn, H, W, ws = 2, 24, 40, 8
+    nb, h, N, T = Bn * (H // ws) * (W // ws), 6, 64, 225
+    q, k = torch.randn(nb, h, N, 32, device=DEV) * 0.4, torch.randn(nb, h, N, 32, device=DEV) * 0.4
+    v = torch.randn(nb, h, N, 32, device=DEV)
+    for t in (q, k, v):
+        t[..., 30:] = 0
+    rpi = S.SwinIR(depths=[2], num_heads=[6]).layers[0].residual_group.blocks[0].attn.relative_position_index.to(DEV)  # swinir.py:56-67
+    table = (torch.randn(T, h, device=DEV) * 0.3).requires_grad_(True)
+    dO = torch.randn(nb, N, h * 32, device=DEV)
+    qb, kb, vb, dOb = (t.to(bf) for t in (q, k, v, dO))
+    mask = A.shift_mask(H, W, ws, shift, DEV).repeat(Bn, 1, 1) if shift else None
+    q_, k_, v_ = (t.float().clone().requires_grad_(True) for t in (qb, kb, vb))
+    s = q_ @ k_.transpose(-1, -2) + table[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1)[None]
+    if mask is not None:
+        s = s + mask[:, None]
+    o = torch.softmax(s, -1) @ v_
+    o_rows = o.permute(0, 2, 1, 3).reshape(nb, N, h * 32)
+    o_rows.backward(dOb.float())
+    bias = table.detach()[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1).contiguous()
+    groups = 10  # 30 windows: three per group
+    dq, dk, dv = (torch.full((nb, h, N, 32), float("nan"), device=DEV).to(bf) for _ in range(3))
+    lse, delta = torch.zeros(nb, h, N, device=DEV), torch.zeros(nb, h, N, device=DEV)
+    dtp = torch.full((h * groups, 256), float("nan"), device=DEV)
+    qT, kT = qb.transpose(-1, -2).contiguous(), kb.transpose(-1, -2).contiguous()
+    dOT = dOb.reshape(nb, N, h, 32).permute(0, 2, 3, 1).contiguous()
+    ob = o_rows.detach().to(bf).contiguous()
+    rpi32 = rpi.to(torch.int32).contiguous()
+    FT._call(L.lib().sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=qb.data_ptr(), qT=qT.data_ptr(), k=kb.data_ptr(), kT=kT.data_ptr(), v=vb.data_ptr(), o=ob.data_ptr(),
+             dO=dOb.data_ptr(), dOT=dOT.data_ptr(), bias=bias.data_ptr(), biasT=bias.transpose(1, 2).contiguous().data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(),
+             dv=dv.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), dtab_part=dtp.data_ptr(), rpi=rpi32.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N,
+             ldo=h * 32, groups=groups, T=T, Tpad=256, toeplitz16=0, H=H, W=W, ws=ws, shift=shift)
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    assert rel(dq, q_.grad) <= 8e-3 and rel(dk, k_.grad) <= 8e-3 and rel(dv, v_.grad) <= 8e-3, (rel(dq, q_.grad), rel(dk, k_.grad), rel(dv, v_.grad))
+    dtab = dtp.reshape(h, groups, 256).sum(1)[:, :T].t()
     assert rel(dtab, table.grad) <= 2e-3, rel(dtab, table.grad)
