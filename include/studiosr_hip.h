@@ -540,7 +540,9 @@ typedef struct SrTrAttnBwd {
     void* dq; void* dk; void* dv;
     float* lse; float* delta; float* dtab_part; const int* rpi;
     int n_bwin, heads, hd_p, Nq, Nk, ldo, groups, T, Tpad;
-    int toeplitz16;        /* 1: rpi is the 16 x 16 self-attention index (yq - yk + 15) * 31 + (xq - xk + 15) (hat.py:480-492): the fold runs on lane rotations */
+    int toeplitz16;        /* 1: rpi is the standard window index (yq - yk + ws - 1) * (2 ws - 1) + (xq - xk + ws - 1) (hat.py:480-492, swinir.py:56-67): the fold runs on lane
+                            * rotations.  Nq = Nk = 64 (8 x 8 windows, ABI v10): with it and groups * 4 == n_bwin ONE launch does everything (a wave per (window, head)); otherwise
+                            * the two register passes with the index-map fold */
     int H, W, ws, shift;   /* mask geometry (shift == 0: no mask) */
     int oca_rel;           /* 1 (ABI v8; Nk = 576): bias[q][k] is a function of (ky - qy, kx - qx) only and rpi the overlapping-cross-attention index
                             * (ky - qy - 7) * 39 + (kx - qx - 7) with wrapping negatives (hat.py:494-517): pass Q then keeps the head's table in LDS beside the window's

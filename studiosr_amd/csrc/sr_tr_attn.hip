@@ -385,6 +385,253 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
     }
 }
 
+
+// ---- 8 x 8 windows (SwinIR, swinir.py:83-102), ONE pass: a wave owns a whole (window, head) -- 64 queries x 64 keys = sixteen logit tiles in 64 registers -- so nothing
+// travels between passes (no lse / delta round trip) and every operand is fetched once, in two rounds issued up front (the two register passes above, written for
+// 256 / 576 keys, leave a 64-key window as a chain of ~7 dependent L2 round trips: 35 + 17 us per SwinIR block at 4 x 64 x 64).  Orientation 1 (keys on registers,
+// queries on lanes, as pass Q): P, delta, dS -> dQ and the bias-table fold; orientation 2 (queries on registers, keys on lanes, as pass KV; P recomputed from the
+// wave's own log-sum-exp): dV, dK.  Workgroup = (head, four consecutive windows): one table partial per workgroup, i.e. groups * 4 == n_bwin.
+__global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_w8_kernel(SrTrAttnBwd a) {
+    constexpr int N = 64, WS = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int per_head = a.n_bwin >> 2;
+    const int head = blockIdx.x / per_head;
+    const int bwin = (blockIdx.x - head * per_head) * 4 + wave;
+    const size_t bh = (size_t)bwin * a.heads + head;
+    const bf16* q = reinterpret_cast<const bf16*>(a.q) + bh * N * 32;
+    const bf16* k = reinterpret_cast<const bf16*>(a.k) + bh * N * 32;
+    const bf16* v = reinterpret_cast<const bf16*>(a.v) + bh * N * 32;
+    const bf16* qT = reinterpret_cast<const bf16*>(a.qT) + bh * N * 32;
+    const bf16* kT = reinterpret_cast<const bf16*>(a.kT) + bh * N * 32;
+    const bf16* dOT = reinterpret_cast<const bf16*>(a.dOT) + bh * N * 32;
+
+    // ---- round 1 of operand loads: the row-major fragments (tile t: tokens 16 t + lr, features 8 lg ..) and the bias tiles of orientation 1
+    Frag<bf16> qf[4], kf[4], vf[4], dof[4], of[4];
+    f32x4 s[4][4];  // [query tile][key tile]: key 16 kt + 4 lg + r, query 16 qt + lr
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const size_t row = (size_t)(t * 16 + lr) * 32 + lg * 8;
+        qf[t] = *reinterpret_cast<const Frag<bf16>*>(q + row);
+        kf[t] = *reinterpret_cast<const Frag<bf16>*>(k + row);
+        vf[t] = *reinterpret_cast<const Frag<bf16>*>(v + row);
+        const size_t orow = ((size_t)bwin * N + t * 16 + lr) * a.ldo + head * 32 + lg * 8;
+        dof[t] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
+        of[t] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.o) + orow);
+    }
+    const float* bias = a.bias + (size_t)head * N * N;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[qt][kt] = *reinterpret_cast<const f32x4*>(bias + (size_t)(qt * 16 + lr) * N + kt * 16 + lg * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- round 2, in flight under orientation 1: transposed operands (d row 16 dt + lr, tokens 32 ks + 4 lg .. | + 16) and this lane's table rows
+    Frag<bf16> ktf[2][2], qtf[2][2], dotf[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const size_t off = (size_t)(dt * 16 + lr) * N + ks * 32 + lg * 4;
+            ktf[dt][ks] = load_2x4(kT + off, kT + off + 16);
+            qtf[dt][ks] = load_2x4(qT + off, qT + off + 16);
+            dotf[dt][ks] = load_2x4(dOT + off, dOT + off + 16);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    __shared__ float tabw[4 * 256];  // one table per wave (= window)
+
+    const int nwx = a.W / WS, nwy = a.H / WS;
+    const int win = bwin % (nwx * nwy);
+    const int wy = win / nwx, wx = win - wy * nwx;
+    const bool masked = a.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+    // shift-mask regions (common.py:250-274) of the positions this lane meets: as a query / key ON THE LANE (token 16 t + lr: row 2 t + (lr >> 3), column lr & 7)
+    // and ON THE REGISTERS (token 16 t + 4 lg + r: row 2 t + (lg >> 1), column 4 (lg & 1) + r)
+    const int col_lane = region(wx * WS + (lr & 7), a.W, WS, a.shift);
+    int col_reg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) col_reg[r] = region(wx * WS + 4 * (lg & 1) + r, a.W, WS, a.shift);
+    auto row_lane = [&](int t) { return region(wy * WS + 2 * t + (lr >> 3), a.H, WS, a.shift); };
+    auto row_reg = [&](int t) { return region(wy * WS + 2 * t + (lg >> 1), a.H, WS, a.shift); };
+
+    // ---- orientation 1: S^T = K Q^T + bias (+ mask), softmax over the keys, dS^T = P (V dO^T - delta)
+    float lse[4], dl[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt].v, qf[qt].v, s[qt][kt], 0, 0, 0);
+        if (masked) {
+            const int qrow = row_lane(qt);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bool rdiff = row_reg(kt) != qrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rdiff || col_reg[r] != col_lane) s[qt][kt][r] += -100.0f;
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+        mx = wave_max_xor(mx, 16);
+        mx = wave_max_xor(mx, 32);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[qt][kt][r] = __expf(s[qt][kt][r] - mx);
+                sum += s[qt][kt][r];
+            }
+        sum = wave_sum_xor(sum, 16);
+        sum = wave_sum_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        lse[qt] = mx + __logf(sum);
+        float d = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) d += (float)dof[qt].v[jj] * (float)of[qt].v[jj];
+        d = wave_sum_xor(d, 16);
+        d = wave_sum_xor(d, 32);
+        dl[qt] = d;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4 dp = mma_z(vf[kt], dof[qt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qt][kt][r] = s[qt][kt][r] * inv * (dp[r] - d);
+        }
+        // dQ[q][d] = sum_key dS[q][key] K[key][d]: the dS accumulators are the operand (keys 32 ks + 4 lg + r | + 16 per lane group), K^T from the transposed copy
+        f32x4 dq[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dq[dt] = mma_z(ktf[dt][0], pack_p(s[qt][0], s[qt][1]));
+            mma(ktf[dt][1], pack_p(s[qt][2], s[qt][3]), dq[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
+        }
+        bf16* dqp = reinterpret_cast<bf16*>(a.dq) + (bh * N + qt * 16 + lr) * 32 + lg * 4;
+        store4(dqp, dq[0]);
+        store4(dqp + 16, dq[1]);
+    }
+    // ---- relative_position_bias_table gradient of this window: dtab[(dy + 7) * 15 + dx + 7] = sum of dS over the (query, key) pairs with qy - ky = dy, qx - kx = dx
+    // (swinir.py:56-67).  No LDS atomics (64 ds_add_f32 per wave with 2-4 lanes per address: 35 us of a 62-us launch): lane = (key row parity kyl = bit 5, key column
+    // half kxh = bit 4, query row parity qyl = bit 3, query column qx = bits 0-2).  For register r the key column is kx = 4 kxh + r: rotating the eight query columns by kx
+    // (one ds_bpermute) puts dx = j (no wrap) or j - 8 (wrapped) on lane column j, so the x fold is a per-lane sum over r and over the tiles of one diagonal
+    // d = qt - kt (dy = 2 d + qyl - kyl); what is left are sums over lanes: kxh (xor 16) and the two (qyl, kyl) pairs of one dy (xor 40).
+    float fp[7], fn[7];  // [d + 3]: dx = j | dx = j - 8
+#pragma unroll
+    for (int i = 0; i < 7; ++i) fp[i] = fn[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kx = 4 * ((lane >> 4) & 1) + r;
+        const int src = (lane & 56) | ((lane + kx) & 7);
+        const bool nowrap = (lane & 7) + kx <= 7;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float w = __shfl(s[qt][kt][r], src, 64);
+                fp[qt - kt + 3] += nowrap ? w : 0.f;
+                fn[qt - kt + 3] += nowrap ? 0.f : w;
+            }
+    }
+    float up[9], un[9];  // the partner lane's sums (other (qyl, kyl) pair of the same row difference), index d + 4 with zeros at both ends
+    up[0] = un[0] = up[8] = un[8] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        fp[i] = wave_sum_xor(fp[i], 16);
+        fn[i] = wave_sum_xor(fn[i], 16);
+        up[i + 1] = __shfl_xor(fp[i], 40, 64);
+        un[i + 1] = __shfl_xor(fn[i], 40, 64);
+    }
+    {
+        // writers (kxh = 0): lane (qyl, kyl) = (0, 0): even rows dy = 2 d = own + partner (1, 1); lane (1, 0): odd rows dy = 2 d + 1 = own d (dy' = +1) + partner (0, 1)'s
+        // d + 1 (dy' = -1), d = -4 .. 3.  Every one of the 225 entries is written exactly once per wave.
+        float* tw = tabw + wave * 256;
+        const int j = lane & 7;
+        const bool even = (lane & 56) == 0, odd = (lane & 56) == 8;
+        if (even) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int row = (2 * (i - 3) + 7) * 15 + 7;
+                tw[row + j] = fp[i] + up[i + 1];
+                if (j >= 1) tw[row + j - 8] = fn[i] + un[i + 1];
+            }
+        }
+        if (odd) {
+#pragma unroll
+            for (int i = -1; i < 7; ++i) {  // d = i - 3
+                const int row = (2 * (i - 3) + 1 + 7) * 15 + 7;
+                const float mp = i >= 0 ? fp[i] : 0.f, mn = i >= 0 ? fn[i] : 0.f;
+                tw[row + j] = mp + up[i + 2];
+                if (j >= 1) tw[row + j - 8] = mn + un[i + 2];
+            }
+        }
+    }
+#ifdef SR_W8_NOO2
+    if (a.T > 0) { __syncthreads(); if ((int)threadIdx.x < a.T) a.dtab_part[(size_t)blockIdx.x * a.Tpad + threadIdx.x] = tabw[threadIdx.x]; return; }
+#endif
+
+    // ---- orientation 2: S = Q K^T + bias^T (+ mask), P = exp(S - lse), dS = P (dO V^T - delta); dV = P^T dO, dK = dS^T Q
+    f32x4 l4[4], d4[4];  // lse / delta of query 16 qt + 4 lg + r: held by lane 4 lg + r of orientation 1
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l4[qt][r] = __shfl(lse[qt], 4 * lg + r, 64);
+            d4[qt][r] = __shfl(dl[qt], 4 * lg + r, 64);
+        }
+    const float* biasT = a.biasT + (size_t)head * N * N;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        f32x4 bt[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) bt[qt] = *reinterpret_cast<const f32x4*>(biasT + (size_t)(kt * 16 + lr) * N + qt * 16 + lg * 4);
+        const int krow = row_lane(kt);
+        f32x4 dk[2], dv[2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qt = 2 * qs + h;
+                f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt].v, kf[kt].v, bt[qt], 0, 0, 0);  // S[query 16 qt + 4 lg + r][key 16 kt + lr]
+                const f32x4 dp = mma_z(dof[qt], vf[kt]);
+                if (masked) {
+                    const bool rdiff = row_reg(qt) != krow;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rdiff || col_reg[r] != col_lane) sv[r] += -100.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[h][r] = __expf(sv[r] - l4[qt][r]);
+                    ds[h][r] = p[h][r] * (dp[r] - d4[qt][r]);
+                }
+            }
+            const Frag<bf16> pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);  // row = key lr, k = queries 32 qs + 4 lg + r | + 16
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                if (qs == 0) {
+                    dv[dt] = mma_z(dotf[dt][0], pf);  // C[d = 16 dt + 4 lg + r][key lr]
+                    dk[dt] = mma_z(qtf[dt][0], dsf);
+                } else {
+                    mma(dotf[dt][1], pf, dv[dt]);
+                    mma(qtf[dt][1], dsf, dk[dt]);
+                }
+            }
+        }
+        bf16* dkp = reinterpret_cast<bf16*>(a.dk) + (bh * N + kt * 16 + lr) * 32 + lg * 4;
+        bf16* dvp = reinterpret_cast<bf16*>(a.dv) + (bh * N + kt * 16 + lr) * 32 + lg * 4;
+        store4(dkp, dk[0]);
+        store4(dkp + 16, dk[1]);
+        store4(dvp, dv[0]);
+        store4(dvp + 16, dv[1]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 225)
+        a.dtab_part[(size_t)blockIdx.x * a.Tpad + threadIdx.x] = (tabw[threadIdx.x] + tabw[256 + threadIdx.x]) + (tabw[512 + threadIdx.x] + tabw[768 + threadIdx.x]);
+}
+
 // ---- overlapping cross attention (hat.py:239-293), training forward: softmax(q k^T + bias) v with Nk = 16 KT keys per window from the unfolded
 //      neighbourhood (sr_tr_oca_unfold); one wave = (window, head, 16 queries), everything in registers as in pass Q
 template <int KT>
@@ -554,7 +801,7 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
                "sr_tr_attn_bwd: null pointer");
     const SrTrAttnBwd& a = *p;
     const bool w8 = a.Nq == 64;  // 8 x 8 windows (SwinIR, swinir.py:83-102): the two register passes with four key / query tiles
-    SR_REQUIRE(a.hd_p == 32 && ((a.Nq == 256 && (a.Nk == 256 || a.Nk == 576)) || (w8 && a.Nk == 64 && !a.toeplitz16 && !a.oca_rel)) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 &&
+    SR_REQUIRE(a.hd_p == 32 && ((a.Nq == 256 && (a.Nk == 256 || a.Nk == 576)) || (w8 && a.Nk == 64 && !a.oca_rel)) && a.heads > 0 && a.n_bwin > 0 && a.groups > 0 &&
                    a.groups <= a.n_bwin && a.ldo >= a.heads * 32 && a.ldo % 8 == 0,
                "sr_tr_attn_bwd: unsupported geometry (hd_p 32; Nq 256 with Nk 256 / 576, or Nq = Nk = 64)");
     SR_REQUIRE(a.shift == 0 || (a.Nk == a.Nq && a.ws * a.ws == a.Nq && a.H % a.ws == 0 && a.W % a.ws == 0 && a.n_bwin % ((a.H / a.ws) * (a.W / a.ws)) == 0),
@@ -567,6 +814,11 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
         b.H = b.W = b.ws;
     }
     SR_REQUIRE(a.T > 0 && a.T <= 1536 && a.Tpad >= a.T, "sr_tr_attn_bwd: the bias table has at most 1536 rows");
+    if (w8 && a.groups * 4 == a.n_bwin && a.toeplitz16 && a.T == 225) {  // standard index, one table partial per (head, four windows): the one-pass kernel
+        hipLaunchKernelGGL(sr_tr_attn_bwd_w8_kernel, dim3(a.heads * a.groups), dim3(256), 0, st, b);
+        SR_CHECK_LAUNCH("sr_tr_attn_bwd (8 x 8 windows)");
+        return SR_OK;
+    }
     if (w8) {
         const int items = a.groups * a.heads * 4;
         hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<4, 0, false, 8>), dim3((items + 3) / 4), dim3(256), 0, st, b);

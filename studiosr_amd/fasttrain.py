@@ -34,7 +34,6 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
-W8_GROUPS = int(os.environ.get("SR_TR_W8_GROUPS", "128"))  # tuning knob: window groups of the attention backward's pass Q for 8 x 8 windows (SwinIR)
 BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
 _SIDE = {}
 
@@ -486,6 +485,9 @@ class BlockPlan:
         self.o_bp = fa.add(pack_vec(fp, at.proj.bias, CP))
         self.table = at.relative_position_bias_table
         b, bt, bf, b31 = pack_bias(fp, self.table, rpi, self.nq, self.nk)
+        cy, cx = np.divmod(np.arange(self.nq), ws)  # is rpi the standard relative-position index of a ws x ws window (hat.py:480-492, swinir.py:56-67)?
+        std = (cy[:, None] - cy[None, :] + ws - 1) * (2 * ws - 1) + (cx[:, None] - cx[None, :] + ws - 1)
+        self.std_rpi = (not oca) and (ws == 16 or np.array_equal(np.asarray(rpi, dtype=np.int64).reshape(self.nq, self.nq), std))
         self.o_bias, self.o_biasT = fa.add(b), fa.add(bt)
         self.o_biasF = None if oca else fa.add(bf)
         self.o_bias31 = None if (oca or b31 is None or not ATTN_LDS) else fa.add(b31)
@@ -533,11 +535,10 @@ class BlockPlan:
         nbw_ = B * H * W // self.nq
         # HAB with the LDS form of the attention backward (csrc/sr_tr_attn_lds.hip): one bias-table partial per (head, window), i.e. groups * 4 == windows;
         # OCAB (and HABs without it): `groups` window groups whose pass-Q workgroups walk their windows with the gradient tiles in registers;
-        # 8 x 8 windows: one workgroup of pass Q = (head, group, the window's 64 queries); W8_GROUPS groups at most (each walks nbw_ / groups windows)
+        # 8 x 8 windows: groups * 4 == windows selects the one-pass kernel (one wave per (window, head), one table partial per four windows of a head);
+        # a window count that is not a multiple of four takes the two register passes with one window per group
         if self.ws == 8:
-            self.groups = max(1, min(nbw_, W8_GROUPS))
-            while nbw_ % self.groups:
-                self.groups -= 1
+            self.groups = nbw_ // 4 if (nbw_ % 4 == 0 and self.std_rpi) else nbw_
         else:
             self.groups = nbw_ // 4 if (not self.oca and nbw_ % 4 == 0 and ATTN_BWD_LDS) else groups
         nwg = B * H * W // 64
@@ -672,7 +673,7 @@ class BlockPlan:
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
               dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // self.nq,
-              heads=HEADS, hd_p=HDP, Nq=self.nq, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca and self.ws == 16), H=H, W=W,
+              heads=HEADS, hd_p=HDP, Nq=self.nq, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca and self.std_rpi), H=H, W=W,
               ws=self.ws, shift=self.shift,
               oca_rel=int(self.oca and self.o_bias_rel is not None))
         jobs = []

@@ -50,7 +50,6 @@ KNOBS = {
     "SR_TR_OCA_LDS": ("1", "select", "OCAB pass Q in LDS form"),
     "SR_TR_MIDPRE": ("1", "select", "the CAB's conv1 pre-activation kept by the forward (0: recomputed in the backward)"),
     "SR_TR_GROUPS": ("10", "tune", "window groups of the OCAB's pass Q (default 256 // (6 heads x 4))"),
-    "SR_TR_W8_GROUPS": ("128", "tune", "window groups of the attention backward's pass Q for 8 x 8 windows (fused SwinIR training)"),
     "SR_WG_KS": ("16", "tune", "token slices of the weight-gradient GEMMs"),
     "SR_WG_HALO": ("1", "select", "3x3 weight gradients on 2-D patches with one staged halo for all nine taps"),
     "SR_WG_HALO_STEPS": ("16", "tune", "patches per slice of the halo form"),

@@ -763,17 +763,18 @@ os.write(1, f"\\nOVERLAP_OK_{{int(nodes)}}_R{{rank}} worst {{worst:.2e}} buckets
         assert p.returncode == 0 and all(f"OVERLAP_OK_{nodes}_R{r}" in p.stdout for r in (0, 1)), p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass"), (0, "w8"), (4, "w8"), (3, "w8")])
+@pytest.mark.parametrize("shift,form", [(0, "lds"), (8, "lds"), (8, "two-pass"), (0, "w8"), (4, "w8"), (3, "w8"), (4, "w8-two-pass")])
 def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
     """sr_tr_attn_bwd (swinir.py:83-102 / hat.py:90-107 under loss.backward()) on 16 x 16 windows against torch autograd of softmax(q k^T + table[rpi] + mask) v on
     the same bf16-rounded operands: dq, dk, dv and the relative_position_bias_table gradient.  "lds" = the one-launch LDS form (csrc/sr_tr_attn_lds.hip, taken when
     groups * 4 == n_bwin: one table partial per (head, window)), "two-pass" = the register-only passes of csrc/sr_tr_attn.hip; masked windows included.
-    "w8" = SwinIR's 8 x 8 windows (64 keys: the register passes with four tiles, a 16-key tile = two window rows; groups < windows: a workgroup walks several)."""
+    "w8" = SwinIR's 8 x 8 windows, the one-pass kernel (one wave per (window, head); groups * 4 == n_bwin); "w8-two-pass" = the register passes with four tiles
+    (a 16-key tile = two window rows; a workgroup walks the five windows of its group)."""
     from studiosr_amd import _lib as L, autograd as A, fasttrain as FT
     from studiosr_amd.models.hat import rpi_sa
 
-    if form == "w8":
-        return _attention_backward_w8(shift)
+    if form.startswith("w8"):
+        return _attention_backward_w8(shift, form == "w8")
     bf = torch.bfloat16
     torch.manual_seed(1)
     Bn, H, W = 2, 32, 48
@@ -815,12 +816,12 @@ def test_window_attention_backward_kernels_against_torch_autograd(shift, form):
     assert rel(dtab, table.grad) <= 2e-3, rel(dtab, table.grad)
 
 
-def _attention_backward_w8(shift):
+def _attention_backward_w8(shift, one_pass):
     from studiosr_amd import _lib as L, autograd as A, fasttrain as FT
 
     bf = torch.bfloat16
     torch.manual_seed(2)
-    Bn, H, W, ws = 2, 24, 40, 8
+    Bn, H, W, ws = 2, 32, 40, 8
     nb, h, N, T = Bn * (H // ws) * (W // ws), 6, 64, 225
     q, k = torch.randn(nb, h, N, 32, device=DEV) * 0.4, torch.randn(nb, h, N, 32, device=DEV) * 0.4
     v = torch.randn(nb, h, N, 32, device=DEV)
@@ -839,7 +840,7 @@ def _attention_backward_w8(shift):
     o_rows = o.permute(0, 2, 1, 3).reshape(nb, N, h * 32)
     o_rows.backward(dOb.float())
     bias = table.detach()[rpi.reshape(-1)].reshape(N, N, h).permute(2, 0, 1).contiguous()
-    groups = 10  # 30 windows: three per group
+    groups = 10 if one_pass else 8  # 40 windows: four per group = the one-pass kernel; five per group = the two register passes
     dq, dk, dv = (torch.full((nb, h, N, 32), float("nan"), device=DEV).to(bf) for _ in range(3))
     lse, delta = torch.zeros(nb, h, N, device=DEV), torch.zeros(nb, h, N, device=DEV)
     dtp = torch.full((h * groups, 256), float("nan"), device=DEV)
@@ -850,7 +851,7 @@ def _attention_backward_w8(shift):
     FT._call(L.lib().sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=qb.data_ptr(), qT=qT.data_ptr(), k=kb.data_ptr(), kT=kT.data_ptr(), v=vb.data_ptr(), o=ob.data_ptr(),
              dO=dOb.data_ptr(), dOT=dOT.data_ptr(), bias=bias.data_ptr(), biasT=bias.transpose(1, 2).contiguous().data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(),
              dv=dv.data_ptr(), lse=lse.data_ptr(), delta=delta.data_ptr(), dtab_part=dtp.data_ptr(), rpi=rpi32.data_ptr(), n_bwin=nb, heads=h, hd_p=32, Nq=N, Nk=N,
-             ldo=h * 32, groups=groups, T=T, Tpad=256, toeplitz16=0, H=H, W=W, ws=ws, shift=shift)
+             ldo=h * 32, groups=groups, T=T, Tpad=256, toeplitz16=int(one_pass), H=H, W=W, ws=ws, shift=shift)
     torch.cuda.synchronize()
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
     assert rel(dq, q_.grad) <= 8e-3 and rel(dk, k_.grad) <= 8e-3 and rel(dv, v_.grad) <= 8e-3, (rel(dq, q_.grad), rel(dk, k_.grad), rel(dv, v_.grad))
