@@ -12,6 +12,7 @@
 #include "sr_host.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -380,6 +381,149 @@ __global__ __launch_bounds__(256) void sr_tr_wgrad_kernel(WgradJobs J) {
 }
 
 
+#ifndef SR_WGW_NF
+#define SR_WGW_NF 6
+#endif
+#ifndef SR_WGW_KF
+#define SR_WGW_KF 3
+#endif
+#ifndef SR_WGW_STAGES
+#define SR_WGW_STAGES 3
+#endif
+// ---- nn.Linear weight gradients on WIDE tiles (round 5; tools/wgrad_time.py: one SwinIR / HAT block's four jobs over 16 k tokens 37.9 -> 28.6 us at ks = 16).
+// The 64 x 64 tiles above load 128 operand columns per token for 4,096 MACs: the four GEMMs of a block (qkv 576 x 192, proj 192 x 192, fc1 384 x 192, fc2 192 x 384)
+// pull 302 MB through the L2 -> LDS path per launch, and each 64-token step is a dependent chain global -> registers -> LDS -> barrier -> MFMA whose register
+// prefetch is one step deep in effect (the copy ra1 = ra2 at the end of a step waits for the load issued at its start).  Here a workgroup owns 32 NF x 32 KF outputs
+// (192 x 96: 2 x 2 waves of 96 x 48; 18 MFMAs per wave and 32-token step from 9 transposed fragments) and the operands travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no waiting copy) into a ring of three stages (61 KB: two workgroups per CU), two steps ahead of the MFMAs; one
+// barrier per step.  A staged row is the tile's columns + 32 bytes of padding (conflict-free transposed reads), i.e. 26 / 14 sixteen-byte slots: the 32 rows of a
+// step are 13 + 7 wave-wide DMA instructions whose lanes on padding slots are switched off.  Every slice must consist of whole steps (T a multiple of 32 ks); the
+// bias column (ones_col) is patched into the fragment in registers.  Same token order inside a slice as the 64 x 64 path: the partial sums differ by tile shape only.
+// What bounds it (variant builds): the launch without its MFMAs AND without the fragment reads 13.6 us (of which ~5 us are the 18.9 MB of fp32 partials, ~3 us the
+// launch), + DMA 5 us, + fragment reads and MFMAs 15 us: 36 ds_read_b64_tr_b16 per wave and step = 74 KB per CU and step against 18 MFMAs per SIMD -- the LDS, not
+// the matrix cores.  Deeper rings (4 / 7 stages) and a software pipeline of the fragment reads: +-0 / worse; two workgroups per CU (ks = 32: 512 workgroups) 21.8 us
+// but twice the partials for sr_tr_finalize_to.
+template <int NF, int KF>
+__global__ __launch_bounds__(256, 2) void sr_tr_wgrad_wide_kernel(WgradJobs J) {
+    constexpr int TN = 32 * NF, TK = 32 * KF;
+    constexpr int SA = TN / 8 + 2, SB = TK / 8 + 2;      // 16-byte slots per staged row (data + padding)
+    constexpr int LDA = SA * 16, LDB = SB * 16;
+    static_assert((LDA / 32) % 2 == 1 && (LDB / 32) % 2 == 1, "conflict-free transposed reads need a row stride that is an odd multiple of 32 bytes");
+    constexpr int TILE_A = WG_STEP * LDA, TILE_B = WG_STEP * LDB, STAGE = TILE_A + TILE_B;
+    static_assert(TILE_A % 1024 == 0 && TILE_B % 1024 == 0, "whole wave-wide DMA instructions per tile");
+    constexpr int NIA = TILE_A / 1024, NI = STAGE / 1024;  // DMA instructions per step: [0, NIA) operand A, [NIA, NI) operand B
+    static_assert(NI % 4 == 0, "the same number of DMA instructions per wave (vmcnt bookkeeping)");
+    constexpr int U = NI / 4, STAGES = SR_WGW_STAGES, D = STAGES - 1;  // the DMA runs D steps ahead
+    static_assert(D * U <= 60, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    int jb = 0;
+#pragma unroll
+    for (int i = 1; i < WG_MAXJOBS; ++i)
+        if (i < J.n && (int)blockIdx.x >= J.wg0[i]) jb = i;
+    const SrTrWgradJob& j = J.j[jb];
+    int rem = blockIdx.x - J.wg0[jb];
+    {   // XCD-aware order, as sr_tr_wgrad_kernel: each of the eight residue classes of the block id takes a contiguous eighth of the items (= its own token slices)
+        const int per = (J.wg0[jb + 1] - J.wg0[jb]) >> 3;
+        rem = (rem & 7) * per + (rem >> 3);
+        if (rem >= J.nwg[jb]) return;
+    }
+    const int tk = rem % J.tiles_k[jb];
+    rem /= J.tiles_k[jb];
+    const int tn = rem % J.tiles_n[jb];
+    const int slice = rem / J.tiles_n[jb];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w >> 1, wk = w & 1;
+    const int lg = lane >> 4;
+    const int chunk = j.T / j.ks;  // (a multiple of WG_STEP: launcher)
+    const int t_beg = slice * chunk, nsteps = chunk / WG_STEP;
+    const int n0 = tn * TN, k0 = tk * TK;
+    // this wave's DMA instructions g = w + 4 u: per lane the byte offset of its 16-byte piece relative to the step's first token row (or -1: a padding slot)
+    int voff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int g = w + 4 * u;
+        if (g < NIA) {
+            const int slot = g * 64 + lane, row = slot / SA, c = slot - row * SA;
+            voff[u] = c < TN / 8 ? (row * j.lda + n0 + c * 8) * 2 : -1;
+        } else {
+            const int slot = (g - NIA) * 64 + lane, row = slot / SB, c = slot - row * SB;
+            voff[u] = c < TK / 8 ? (row * j.ldb + k0 + c * 8) * 2 : -1;
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_w;
+    const bf16* A = reinterpret_cast<const bf16*>(j.A) + (size_t)t_beg * j.lda;
+    const bf16* Bm = reinterpret_cast<const bf16*>(j.B) + (size_t)t_beg * j.ldb;
+    auto issue = [&](int step) {  // the WG_STEP token rows of `step` -> ring stage step % STAGES
+        const unsigned dst = lds0 + (unsigned)(step % STAGES) * STAGE;
+        const bf16* ar = A + (size_t)step * WG_STEP * j.lda;
+        const bf16* br = Bm + (size_t)step * WG_STEP * j.ldb;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int g = w + 4 * u;
+            const bf16* base = g < NIA ? ar : br;  // (wave-uniform)
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(dst + g * 1024);
+            unsigned keep;
+            // lanes on padding slots keep their address register harmless and are switched off through the exec mask of the branch
+            if (voff[u] >= 0)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[u]), "s"(base), "s"(m0v) : "memory");
+        }
+    };
+    f32x4 acc[NF][KF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < KF; ++b) acc[a][b] = (f32x4)(0.0f);
+    // bias column: B[:, ones_col] reads as one (dW[:, ones_col] = column sums of A): the lane that holds that column sets its fragment to ones
+    const int ones_rel = j.ones_col - k0 - wk * 16 * KF;  // relative to this wave's columns
+    const int ones_b = (j.ones_col >= 0 && ones_rel >= 0 && ones_rel < 16 * KF) ? ones_rel >> 4 : -1;
+    const bool ones_lane = (lane & 15) == (ones_rel & 15);
+
+    auto wait_younger = [&](int c) {  // wait until at most c steps' DMA instructions of this wave are in flight (s_waitcnt takes an immediate)
+        switch (c > 0 ? c : 0) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * U) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * U <= 63 ? 2 * U : 63) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * U <= 63 ? 3 * U : 63) : "memory"); break;
+        }
+    };
+    static_assert(D <= 4, "wait_younger covers up to three younger steps");
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nsteps) issue(i);
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+        wait_younger(min(sidx + D - 1, nsteps - 1) - sidx);  // step sidx has landed for this wave (DMA completes in issue order) ... and, behind the barrier, for all four
+        __syncthreads();                                      // also: every wave is through step sidx - 1, whose stage the next issue overwrites
+        if (sidx + D < nsteps) issue(sidx + D);
+        const char* ta = smem_w + (sidx % STAGES) * STAGE;
+        const char* tb = ta + TILE_A;
+        Frag<bf16> xa[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            xa[i] = frag2(tr_read<LDA>(ta, 4 * lg, wn * 16 * NF + 16 * i, lane), tr_read<LDA>(ta, 16 + 4 * lg, wn * 16 * NF + 16 * i, lane));
+#pragma unroll
+        for (int b = 0; b < KF; ++b) {
+            Frag<bf16> yb = frag2(tr_read<LDB>(tb, 4 * lg, wk * 16 * KF + 16 * b, lane), tr_read<LDB>(tb, 16 + 4 * lg, wk * 16 * KF + 16 * b, lane));
+            if (b == ones_b && ones_lane) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yb.v[e] = (bf16)1.0f;
+            }
+#pragma unroll
+            for (int a = 0; a < NF; ++a) mma(xa[a], yb, acc[a][b]);
+        }
+    }
+    // acc[a][b]: n = n0 + 16 NF wn + 16 a + 4 lg + r, k = k0 + 16 KF wk + 16 b + (lane & 15)
+    float* out = j.out + (size_t)slice * j.Np * j.Kp;
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < KF; ++b) {
+            const int k = k0 + wk * 16 * KF + 16 * b + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(n0 + wn * 16 * NF + 16 * a + 4 * lg + r) * j.Kp + k] = acc[a][b][r];
+        }
+}
+
 // nn.PixelShuffle(r) backward on NHWC bf16 for a conv whose packed output rows are n = (i r + j) cps + c (common.py:124-137): the gradient of
 // the conv's packed output [B,H,W,r*r*cps] from the gradient of the shuffled tensor [B,H*r,W*r,cps]: 16-byte pieces
 __global__ __launch_bounds__(256) void sr_tr_unshuffle_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int cps, int r) {
@@ -473,25 +617,26 @@ extern "C" int sr_tr_finalize_to(const float* arena, const long long* src, const
 
 extern "C" long long sr_tr_wgrad_out_floats(const SrTrWgradJob* j) { return j ? (long long)j->ks * j->taps * j->Np * j->Kp : 0; }
 
-extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
-    SR_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAXJOBS, "sr_tr_wgrad: 1..%d jobs per launch", WG_MAXJOBS);
+static bool wgrad_wide_job(const SrTrWgradJob& j) {
+    return j.taps == 1 && !j.a_f32 && !j.b_f32 && j.Np % (32 * SR_WGW_NF) == 0 && j.Kp % (32 * SR_WGW_KF) == 0 && j.T % (WG_STEP * j.ks) == 0 &&
+           (long long)WG_STEP * (j.lda > j.ldb ? j.lda : j.ldb) * 2 < (1ll << 30);
+}
+
+// one launch over a set of jobs: wide = the nn.Linear jobs on sr_tr_wgrad_wide_kernel, otherwise the 64 x 64 / halo kernel
+static int wgrad_launch(const SrTrWgradJob* const* jobs, int njobs, bool wide, hipStream_t st) {
     WgradJobs J;
     J.n = njobs;
-    const int xcd = 1;  // XCD-aware work order (0 = block ids in item order: 65.2 -> 73.1 us per HAB launch, round 4)
-    J.xcd = xcd;
+    J.xcd = 1;  // XCD-aware work order (0 = block ids in item order: 65.2 -> 73.1 us per HAB launch, round 4)
     int wg = 0;
     for (int i = 0; i < njobs; ++i) {
-        const SrTrWgradJob& j = jobs[i];
-        SR_REQUIRE(j.A && j.B && j.out && j.T > 0 && j.Np > 0 && j.Kp > 0 && j.Np % 8 == 0 && j.Kp % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.lda >= j.Np &&
-                       j.ldb >= j.Kp && j.ks > 0 && (j.taps == 1 || j.taps == 9) && j.ones_col < j.Kp,
-                   "sr_tr_wgrad: bad job %d", i);
-        SR_REQUIRE(j.taps == 1 || (j.H > 0 && j.W > 0 && j.T % (j.H * j.W) == 0), "sr_tr_wgrad: a 3x3 job needs H, W with T = B*H*W");
-        SR_REQUIRE((((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0, "sr_tr_wgrad: operands must be 16-byte aligned");
-        SR_REQUIRE((j.a_f32 == 0 || j.a_f32 == 1) && (j.b_f32 == 0 || j.b_f32 == 1), "sr_tr_wgrad: a_f32 / b_f32 are flags");
+        const SrTrWgradJob& j = *jobs[i];
         J.j[i] = j;
-        SR_REQUIRE(!j.halo || (j.taps == 9 && j.H % 4 == 0 && j.W % 8 == 0), "sr_tr_wgrad: the halo form needs 9 taps, H %% 4 == 0, W %% 8 == 0");
         J.wg0[i] = wg;
-        if (j.halo) {
+        if (wide) {
+            J.tiles_n[i] = j.Np / (32 * SR_WGW_NF);
+            J.tiles_k[i] = j.Kp / (32 * SR_WGW_KF);
+            J.nwg[i] = J.tiles_n[i] * J.tiles_k[i] * j.ks;
+        } else if (j.halo) {
             J.tiles_n[i] = (j.Np + 31) / 32;
             J.tiles_k[i] = (j.Kp + 63) / 64;
             J.nwg[i] = J.tiles_n[i] * J.tiles_k[i] * j.ks;
@@ -500,7 +645,7 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
             J.tiles_k[i] = (j.Kp + WG_TK - 1) / WG_TK;
             J.nwg[i] = J.tiles_n[i] * J.tiles_k[i] * j.taps * j.ks;
         }
-        wg += J.xcd ? (J.nwg[i] + 7) & ~7 : J.nwg[i];
+        wg += (J.nwg[i] + 7) & ~7;
     }
     J.wg0[njobs] = wg;
     for (int i = njobs; i < WG_MAXJOBS; ++i) {
@@ -509,8 +654,45 @@ extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
         J.nwg[i] = 0;
         J.wg0[i + 1 <= WG_MAXJOBS ? i + 1 : i] = wg;
     }
-    hipLaunchKernelGGL(sr_tr_wgrad_kernel, dim3(wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), J);
+    if (wide) {
+        constexpr int lds = SR_WGW_STAGES * WG_STEP * ((32 * SR_WGW_NF) * 2 + 32 + (32 * SR_WGW_KF) * 2 + 32);
+        static SrDeviceOnce once;
+        const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_tr_wgrad_wide_kernel<SR_WGW_NF, SR_WGW_KF>, lds); });
+        SR_REQUIRE(e == hipSuccess, "sr_tr_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sr_tr_wgrad_wide_kernel<SR_WGW_NF, SR_WGW_KF>), dim3(wg), dim3(256), lds, st, J);
+    } else {
+        hipLaunchKernelGGL(sr_tr_wgrad_kernel, dim3(wg), dim3(256), 0, st, J);
+    }
     SR_CHECK_LAUNCH("sr_tr_wgrad");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_wgrad(const SrTrWgradJob* jobs, int njobs, void* stream) {
+    SR_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAXJOBS, "sr_tr_wgrad: 1..%d jobs per launch", WG_MAXJOBS);
+    static const bool wide_on = !(getenv("SR_WG_WIDE") && atoi(getenv("SR_WG_WIDE")) == 0);  // A/B switch: nn.Linear jobs on the wide-tile kernel
+    const SrTrWgradJob* wide[WG_MAXJOBS];
+    const SrTrWgradJob* rest[WG_MAXJOBS];
+    int nw = 0, nr = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SrTrWgradJob& j = jobs[i];
+        SR_REQUIRE(j.A && j.B && j.out && j.T > 0 && j.Np > 0 && j.Kp > 0 && j.Np % 8 == 0 && j.Kp % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.lda >= j.Np &&
+                       j.ldb >= j.Kp && j.ks > 0 && (j.taps == 1 || j.taps == 9) && j.ones_col < j.Kp,
+                   "sr_tr_wgrad: bad job %d", i);
+        SR_REQUIRE(j.taps == 1 || (j.H > 0 && j.W > 0 && j.T % (j.H * j.W) == 0), "sr_tr_wgrad: a 3x3 job needs H, W with T = B*H*W");
+        SR_REQUIRE((((uintptr_t)j.A | (uintptr_t)j.B) & 15) == 0, "sr_tr_wgrad: operands must be 16-byte aligned");
+        SR_REQUIRE((j.a_f32 == 0 || j.a_f32 == 1) && (j.b_f32 == 0 || j.b_f32 == 1), "sr_tr_wgrad: a_f32 / b_f32 are flags");
+        SR_REQUIRE(!j.halo || (j.taps == 9 && j.H % 4 == 0 && j.W % 8 == 0), "sr_tr_wgrad: the halo form needs 9 taps, H %% 4 == 0, W %% 8 == 0");
+        if (wide_on && wgrad_wide_job(j))
+            wide[nw++] = &j;
+        else
+            rest[nr++] = &j;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nw) {
+        const int rc = wgrad_launch(wide, nw, true, st);
+        if (rc != SR_OK) return rc;
+    }
+    if (nr) return wgrad_launch(rest, nr, false, st);
     return SR_OK;
 }
 

@@ -424,7 +424,13 @@ def test_weight_gradient_kernel_against_torch():
     FT._wgrad([dict(A=A.data_ptr(), B=Bm.data_ptr(), out=out.data_ptr(), lda=Np, ldb=Kp, Np=Np, Kp=Kp, T=T, taps=1, H=1, W=1, ones_col=180, ks=ks)])
     Bo = Bm.float().clone()
     Bo[:, 180] = 1.0  # the bias column: dW[:, 180] = column sums of A = the bias gradient
-    assert _rel(out.sum(0)[0], A.float().t() @ Bo) <= 1e-5
+    assert _rel(out.sum(0)[0], A.float().t() @ Bo) <= 1e-5  # (576 x 192 over 4096 tokens: the wide-tile kernel, sr_tr_wgrad_wide_kernel)
+    # the 64 x 64 tiles (shapes the wide tiles do not divide) and a ragged last slice (T not a multiple of 32 * ks)
+    for T2, N2, K2 in ((4096, 64, 192), (1000, 576, 96), (3000, 192, 384)):
+        A2, B2 = (torch.randn(T2, N2, device=DEV) * 0.5).to(bf), (torch.randn(T2, K2, device=DEV) * 0.5).to(bf)
+        out2 = torch.full((ks, 1, N2, K2), float("nan"), device=DEV)
+        FT._wgrad([dict(A=A2.data_ptr(), B=B2.data_ptr(), out=out2.data_ptr(), lda=N2, ldb=K2, Np=N2, Kp=K2, T=T2, taps=1, H=1, W=1, ones_col=-1, ks=ks)])
+        assert _rel(out2.sum(0)[0], A2.float().t() @ B2.float()) <= 1e-5, (T2, N2, K2)
     Bn, H, W, Co, Ci = 2, 16, 32, 64, 192
     T = Bn * H * W
     dy = (torch.randn(Bn, H, W, Co, device=DEV) * 0.5).to(bf)

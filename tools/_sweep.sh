@@ -1,5 +1,4 @@
-timeout -k 10 300 python -m pytest tests/test_training.py -x -q -m gpu -k "window_attention_backward" 2>&1 | tail -3
-for v in shipped w8noo2; do
-  if [ "$v" = shipped ]; then unset SR_LIB_PATH; else export SR_LIB_PATH="$PWD/studiosr_amd/lib/variants/$v.so"; fi
-  for sh in 0 4; do echo "$v: $(python tools/attn_bwd_w8_time.py 64 $sh 2>/dev/null | tail -1)"; done
-done
+timeout -k 10 600 python -m pytest tests/test_training.py -x -q -m gpu -k "weight_gradient_kernel or fused_training_step_against or fused_training_path_matches or ddp or overlap or flat_adam" 2>&1 | tail -2
+for m in swinir hat; do for wv in 1 0; do
+  echo "$m SR_WG_WIDE=$wv: $(SR_WG_WIDE=$wv timeout -k 10 200 python bench.py --mode train --model $m --skip-cpu 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d["ms_per_step"])')"
+done; done
