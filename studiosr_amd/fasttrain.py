@@ -15,6 +15,9 @@ Host-side design:
   * The adjoint, sr_tr_finalize, turns the weight-gradient GEMMs' partial sums (and the LayerNorm / channel-attention / bias-table
     partials) into G through index maps of the same kind: one launch per stage.
 Activations kept for the backward live in per-block static buffers (one forward in flight per model, checked).
+
+Round 5: the same plan covers SwinIR's default geometry (swinir.py:105-174,258-339: 8 x 8 windows, no conv branch, no OCAB): per block
+    forward   sr_tr_qkv_fwd -> sr_window_attention -> sr_tr_tail_fwd                       backward  sr_tr_tail_bwd -> sr_tr_attn_bwd (one pass) -> sr_tr_qkv_bwd -> sr_tr_wgrad (4 jobs)
 """
 from __future__ import annotations
 

@@ -648,8 +648,9 @@ def test_fused_training_path_sees_parameter_updates_that_bump_no_version_counter
     assert torch.equal(y1, y2) and not torch.equal(y1, y0)  # inference after training runs on the trained weights
 
 
-def test_fused_training_path_under_ddp_two_ranks_gloo(tmp_path):
-    """trainer.py:89-91 with the fused path: DistributedDataParallel around a default-width HAT under autocast, two ranks (both on this GPU, gloo).
+@pytest.mark.parametrize("kind", ["HAT", "SwinIR"])
+def test_fused_training_path_under_ddp_two_ranks_gloo(tmp_path, kind):
+    """trainer.py:89-91 with the fused path: DistributedDataParallel around a default-width HAT (or SwinIR: the same plan on 8 x 8 windows) under autocast, two ranks (both on this GPU, gloo).
     The one autograd node of the fused step returns every parameter gradient as a view of the flat buffer; DDP's reducer must see all of them
     (its hooks fire) and the averaged gradients must equal the mean of the two single-process fused gradients."""
     script = tmp_path / "ddp_fused.py"
@@ -661,7 +662,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 rank = int(os.environ["RANK"]); dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("gloo")
 torch.manual_seed(0)
-m = S.HAT(scale=2, depths=[1], num_heads=[6], drop_path_rate=0.0).to(dev).train()
+m = S.{kind}(scale=2, depths=[1], num_heads=[6], drop_path_rate=0.0).to(dev).train()
 g = torch.Generator().manual_seed(5)
 x, t = torch.rand(4, 3, 32, 32, generator=g).to(dev), torch.rand(4, 3, 64, 64, generator=g).to(dev)
 def step(net, xs, ts):
@@ -689,7 +690,7 @@ dist.barrier(); dist.destroy_process_group(); print("DDP_OK", worst)
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29627", str(script)],
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29627" if kind == "HAT" else "29629", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.count("DDP_OK") == 2, p.stdout[-2000:] + p.stderr[-4000:]
 
