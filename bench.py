@@ -159,9 +159,9 @@ TRAIN_KERNEL_SOURCES = ("studiosr_amd/csrc/sr_tr_block.hip", "studiosr_amd/csrc/
 
 
 def profiled_train_traffic():
-    """HBM bytes per launch of the training step's largest kernel -- sr_tr_wgrad_kernel, the launch that holds a HAB's six weight-gradient jobs (grid 1536) -- from
-    the committed PMC passes (profiles/*_train_hbm_counters_HAT.txt, tools/pmc_train.sh; FETCH_SIZE doubled per the gfx950 rule).  None when absent or taken on
-    other kernel sources (the profile's first line carries their hash)."""
+    """HBM bytes per launch of the training step's largest kernel -- sr_tr_wgrad_wide_kernel, the launch that holds a block's four nn.Linear weight-gradient jobs (grid 256;
+    before the wide tiles: sr_tr_wgrad_kernel with a HAB's six jobs, grid 1536) -- from the committed PMC passes (profiles/*_train_hbm_counters_HAT.txt, tools/pmc_train.sh;
+    FETCH_SIZE doubled per the gfx950 rule).  None when absent or taken on other kernel sources (the profile's first line carries their hash)."""
     import glob
     import hashlib
     import re
@@ -176,11 +176,16 @@ def profiled_train_traffic():
     m0 = re.search(r"#\s*kernel_src_sha16\s*=\s*([0-9a-f]+)", text)
     stale = not m0 or m0.group(1) != h.hexdigest()[:16]
     vals = {}
-    for m in re.finditer(r"\('tr_wgrad_kernel[^\n]*, 1536\)\n\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", text):
+    name = "sr_tr_wgrad_wide_kernel (one block's four nn.Linear weight-gradient jobs, 42 launches per step)"
+    for m in re.finditer(r"\('tr_wgrad_wide_kernel[^\n]*, 256\)\n\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", text):
         vals[m.group(1)] = float(m.group(2))
     if len(vals) != 2:
+        vals, name = {}, "sr_tr_wgrad_kernel (one HAB's weight-gradient jobs, 36 launches per step)"
+        for m in re.finditer(r"\('tr_wgrad_kernel[^\n]*, 1536\)\n\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", text):
+            vals[m.group(1)] = float(m.group(2))
+    if len(vals) != 2:
         return None
-    return dict(kernel="sr_tr_wgrad_kernel (one HAB's weight-gradient jobs, 36 launches per step)", bytes=None if stale else int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
+    return dict(kernel=name, bytes=None if stale else int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
                 fetch_kib_raw=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"], source=os.path.relpath(files[-1], ROOT), stale=stale)
 
 

@@ -157,6 +157,19 @@ class FlatParams:
             self.G2 = torch.zeros_like(self.G)
         return self.G2
 
+    def pass_target(self, pass_id: int) -> Tensor:
+        """grad_target() decided ONCE per backward pass, for passes made of several autograd nodes that each complete a part of the parameters (the per-stage nodes of
+        SR_FAST_FULL=0 / SR_FAST_OCAB=0): the first node of pass `pass_id` to run picks the buffer that no existing .grad is a view of, the others follow it.  (Asking
+        per node would send the second node to G2 because the first node's gradients were just adopted as views of G -- and the next accumulating pass would then
+        overwrite G2 under the .grad tensors that alias it.)"""
+        if getattr(self, "_pass", (None, None))[0] != pass_id:
+            g0 = self.G.untyped_storage().data_ptr()
+            on_g = any(p.grad is not None and p.grad.untyped_storage().data_ptr() == g0 for p in self.params)
+            if on_g and getattr(self, "G2", None) is None:
+                self.G2 = torch.zeros_like(self.G)
+            self._pass = (pass_id, self.G2 if on_g else self.G)
+        return self._pass[1]
+
     def pidx(self, p: Tensor) -> np.ndarray:
         return (self._off[id(p)] + np.arange(p.numel(), dtype=np.int64)).reshape(tuple(p.shape))
 
@@ -818,6 +831,7 @@ class Stage:
         self.n_habs = len(habs)
         self.geo = None
         self.gen = 0
+        self.first = False  # the model's first stage (set by the plan): its forward opens a pass
 
     def prepare(self, B: int, H: int, W: int, dev, scratch: Scratch) -> None:
         if self.geo == (B, H, W):
@@ -870,7 +884,9 @@ class _StageFn(torch.autograd.Function):
     def forward(ctx, x, stage, scales, *params):
         x = x.contiguous()
         stage.gen += 1
-        ctx.stage, ctx.gen, ctx.scales = stage, stage.gen, scales
+        if stage.first:  # a forward pass begins: its backward pass decides once where the gradients go (FlatParams.pass_target)
+            stage.fp.pass_id = getattr(stage.fp, "pass_id", 0) + 1
+        ctx.stage, ctx.gen, ctx.scales, ctx.pass_id = stage, stage.gen, scales, getattr(stage.fp, "pass_id", 0)
         ctx.save_for_backward(x)
         out = stage.forward(x, scales)
         return out.view(out.shape)  # a fresh alias of the stage's static output buffer
@@ -881,7 +897,7 @@ class _StageFn(torch.autograd.Function):
         if stage.gen != ctx.gen:
             raise RuntimeError("studiosr_amd fast training path: another forward ran before this backward (one forward in flight per model)")
         (x,) = ctx.saved_tensors
-        G = stage.fp.grad_target()
+        G = stage.fp.pass_target(ctx.pass_id)
         dx = stage.backward(x, dout, ctx.scales, G).clone()  # (the stage's own buffer is static: autograd gets a tensor of its own)
         grads = stage.fp.grad_views(stage.params, G)
         return (dx, None, None) + grads
@@ -1079,6 +1095,7 @@ class HatPlan:
         else:
             self.stages = [Stage(self.fp, list(layer.residual_group.blocks), layer.residual_group.overlap_attn if with_oca else None, model.relative_position_index_SA,
                                  model.relative_position_index_OCA, model.conv_scale, self.wa, self.fa, extra=layer.conv if self.full else None) for layer in model.layers]
+        self.stages[0].first = True
         # ---- everything outside the blocks (hat.py:519-554): conv_first, patch_embed.norm, the RHAG convs, norm, conv_after_body, the upsampling tail
         from . import packing
         from .models.swinir import final_affine, ingest_affine

@@ -490,6 +490,38 @@ def test_fused_training_path_drop_path_and_accumulation():
     plan.scales_override = None
 
 
+def test_stage_node_mode_accumulates_gradients_over_two_backward_passes():
+    """SR_FAST_FULL=0 (only the RHAGs on fused launches: one autograd node per RHAG, the rest on the generic engine): the nodes of ONE backward pass write one
+    gradient buffer (decided by the first of them, FlatParams.pass_target), so that a second, accumulating pass cannot overwrite a buffer that .grad tensors of the
+    first pass are views of (per-node decisions sent the second node to the spare buffer and the next pass then doubled instead of added)."""
+    prev = os.environ.get("SR_FAST_FULL")
+    os.environ["SR_FAST_FULL"] = "0"
+    try:
+        m = _default_width_hat(depths=(1, 1))
+        torch.manual_seed(5)
+        xs = [torch.rand(2, 3, 32, 32, device=DEV) for _ in range(2)]
+        ys = [torch.rand(2, 3, 64, 64, device=DEV) for _ in range(2)]
+        singles = []
+        for x, y in zip(xs, ys):
+            _, g, _ = _train_step(m, x, y, True, True)
+            singles.append(g)
+        assert m._fast_plan is not None and not m._fast_plan.full
+        m.zero_grad(set_to_none=True)
+        for x, y in zip(xs, ys):  # two backward passes, no zero_grad in between
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.l1_loss(m(x).float(), y)
+            loss.backward()
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            ref = singles[0][n] + singles[1][n]
+            assert _rel(p.grad, ref) <= 1e-5, (n, _rel(p.grad, ref))
+    finally:
+        if prev is None:
+            os.environ.pop("SR_FAST_FULL", None)
+        else:
+            os.environ["SR_FAST_FULL"] = prev
+
+
 def test_fused_training_path_guards():
     """One forward in flight per model (static activation buffers): a second forward before the first backward is an error at that backward;
     other geometries / no autocast / eval fall back to the other paths."""

@@ -10,4 +10,8 @@ timeout -k 10 300 python tools/model_bench.py EDSR SwinIR RCAN HAT SwinIR-light 
 MB_PREC=fp32x3 timeout -k 10 300 python tools/model_bench.py EDSR SwinIR RCAN HAT SwinIR-light 2>/dev/null >> gpurun_out/r05_model_bench.jsonl
 timeout -k 10 200 python bench.py --mode train 2>/dev/null | tail -1 > gpurun_out/r05_bench_train.json
 timeout -k 10 300 python bench.py --mode train --model swinir --steps 10 2>/dev/null | tail -1 >> gpurun_out/r05_bench_train.json
+bash tools/trace_train.sh HAT:4 > /dev/null 2>&1
+bash tools/trace_train.sh SwinIR:4 > /dev/null 2>&1
+bash tools/pmc_train.sh > /dev/null 2>&1
+cd "$ROOT"
 tail -2 gpurun_out/r05_bench.json | cut -c1-600; cat gpurun_out/r05_block_kernel_clock.txt | head -4; cut -c1-170 gpurun_out/r05_model_bench.jsonl; cut -c1-260 gpurun_out/r05_bench_train.json
