@@ -37,6 +37,7 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
+CONV_WG_SIDE = os.environ.get("SR_TR_CONV_WG_SIDE", "1") != "0"  # A/B knob: the CAB convs' weight-gradient launch on the backward's side stream
 BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
 _SIDE = {}
 
@@ -681,7 +682,7 @@ class BlockPlan:
         if dual:
             side = _side_stream(main.device)
             if self._ev is None:
-                self._ev = (torch.cuda.Event(), torch.cuda.Event())
+                self._ev = tuple(torch.cuda.Event() for _ in range(4))
             _edge(main, side, self._ev[0])
             with torch.cuda.stream(side):
                 jobs_cab = self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
@@ -701,7 +702,13 @@ class BlockPlan:
             L.check(lib.sr_tr_oca_fold(C.byref(a), 0, _st()), "sr_tr_oca_fold")
         elif dual:
             _edge(side, main, self._ev[1])
-            jobs += jobs_cab
+            if CONV_WG_SIDE:  # the CAB convs' weight gradients (a 384-workgroup launch of its own since the nn.Linear jobs moved to the wide-tile kernel: 46 us that do not
+                # fill the chip) go back to the side stream, beside sr_tr_qkv_bwd and the nn.Linear weight gradients; joined at the end of the block
+                _edge(main, side, self._ev[2])
+                with torch.cuda.stream(side):
+                    _wgrad(jobs_cab)
+            else:
+                jobs += jobs_cab
         elif self.cab is not None:
             jobs += self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
         _call(lib.sr_tr_qkv_bwd, L.SrTrQkvBwd, "sr_tr_qkv_bwd", dx1=sc.dx1.data_ptr(), x=xin.data_ptr(), dq=sc.dq.data_ptr(), dk=sc.dk.data_ptr(), dv=sc.dv.data_ptr(),
@@ -719,6 +726,8 @@ class BlockPlan:
             ] + jobs)
         if wg is not None:
             sc.wg_busy[k] = _ev_record(wg)
+        if dual and CONV_WG_SIDE:
+            _edge(side, main, self._ev[3])  # the next block's sr_tr_tail_bwd overwrites the operands of the conv weight gradients
 
 
     def _cab_backward(self, st: "Stage", B: int, H: int, W: int, T: int, lib, wa, fa, sc, pp, op) -> List[dict]:
