@@ -438,7 +438,7 @@ def main() -> None:
                     help="tiles: the headline metric (independent 64x64 tiles); strips: BASELINE config 4, ONE large LR image cut into one row strip per GPU with per-layer halo exchange; "
                          "train: BASELINE config 5, HAT x4 training step, per-rank batch 4, DistributedDataParallel over RCCL")
     ap.add_argument("--size", type=int, default=2048, help="--mode strips: LR image side")
-    ap.add_argument("--model", choices=["hat", "swinir"], default="hat", help="--mode train: HAT x4 (BASELINE config 5) or SwinIR x4 (swinir.py:391-402; generic engine)")
+    ap.add_argument("--model", choices=["hat", "swinir"], default="hat", help="--mode train: HAT x4 (BASELINE config 5) or SwinIR x4 (swinir.py:391-402); both on the fused path of studiosr_amd/fasttrain.py")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
