@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 10
+#define SR_ABI_VERSION 11
 
 enum { SR_OK = 0, SR_EINVAL = -1, SR_ELAUNCH = -2, SR_EUNSUPPORTED = -3 };
 enum { SR_F32 = 0, SR_BF16 = 1 };                                 /* element types */
@@ -276,6 +276,8 @@ typedef struct SrRcab {
     const float* gate_b2;      /* [C] */
     float* x_out;              /* NHWC [B,H,W,64] fp32 */
     int gate_C, gate_Cr;
+    int compute_dtype;         /* ABI v11.  0 or SR_BF16: bf16 operands; SR_BF16X3: split operands hi + lo (precision "fp32x3": w1p / w2p packed hi | lo, x / y / gate_y fp32;
+                                * 152 KB of LDS images, one workgroup per CU) -- the conv family of the reference-precision path (common.py:36-48) */
 } SrRcab;
 int sr_rcab_conv_pair(const SrRcab* a, void* stream);
 int sr_rcab_pool_tiles(int H, int W); /* n_tiles of pool_partial */

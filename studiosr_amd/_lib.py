@@ -25,7 +25,7 @@ EPI_STD, EPI_QKV, EPI_QKV_OCA = 0, 1, 2
 OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_FINAL_NCHW = 0, 1, 2
 Y_ROLL, Y_STRIP, Y_STRIP_LAST = 0, 1, 2
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 
@@ -111,7 +111,7 @@ class SrRcab(C.Structure):
         ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("C_p", _i), ("x_dtype", _i), ("y_dtype", _i),
         ("gate_y", _vp), ("gate_pool", _vp), ("gate_w1", _vp), ("gate_b1", _vp), ("gate_w2", _vp), ("gate_b2", _vp), ("x_out", _vp),
-        ("gate_C", _i), ("gate_Cr", _i),
+        ("gate_C", _i), ("gate_Cr", _i), ("compute_dtype", _i),
     ]
 
 

@@ -33,11 +33,11 @@ constexpr int MID_ROWS = 264;      // 1 margin cell + 256 intermediate pixels + 
 #ifndef SR_RCAB_RING
 #define SR_RCAB_RING 6  // five chunks of weight look-ahead (16 MFMAs each): RCAN x4 b16 5.92 -> 5.20 ms, b32 8.26 -> 7.69 ms against 3 slots; 8 / 10 slots: 6.4 ms
 #endif
-constexpr int RRING = SR_RCAB_RING;
+constexpr int RRING_BF16 = SR_RCAB_RING;
 #ifndef SR_RCAB_RING1
 #define SR_RCAB_RING1 5
 #endif
-constexpr int R1RING = SR_RCAB_RING1;  // conv1's ring: 4 fragments per slot
+constexpr int R1RING_BF16 = SR_RCAB_RING1;  // conv1's ring: 4 fragments per slot
 
 #ifndef SR_RCAB_XCD
 #define SR_RCAB_XCD 1  // RCAN x4 b8 3.91 -> 3.65 ms, b16 4.85 -> 4.79, b32 7.38 -> 7.20 (0: tiles in block-id order)
@@ -54,13 +54,31 @@ __device__ unsigned long long sr_dbg_rcab[16];
 #define RSTAMP(i) do { } while (0)
 #endif
 
+// 4 fp32 values into the 8-byte half `half` of a split-operand image cell (8 hi | 8 lo)
+SR_DEV void st_half_x3(Frag<bf3>* cell, int half, const f32x4& v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h[r] = (bf16)v[r];
+        l[r] = (bf16)(v[r] - (float)h[r]);
+    }
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + half * 8) = h;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(cell) + 16 + half * 8) = l;
+}
+SR_DEV void st_half_x3(Frag<bf16>*, int, const f32x4&) {}  // (never called: keeps the bf16 instantiation well-formed)
+
 constexpr int GATE_SCRATCH = (8 * RC + RC + 8 + RC) * (int)sizeof(float);  // slice sums | mean | hidden | gate
 
-template <typename TIn, typename TOut, bool GATED>
-__global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two workgroups per CU: <= 256 VGPRs (the gated form sits at the limit)
+// TC = bf16: bf16 operands, two workgroups per CU.  TC = bf3 (compute type SR_BF16X3, precision "fp32x3" = what inference() runs; round 5, ABI v11): every operand a hi + lo
+// bf16 pair, every product hi*hi + hi*lo + lo*hi; the two images are 32-byte cells (152 KB: one workgroup per CU, 512 registers: shorter weight rings of wider fragments),
+// x / y / the skip stream fp32.  Same K walk per output element as the split-operand sr_conv3x3.
+template <typename TC, typename TIn, typename TOut, bool GATED>
+__global__ __launch_bounds__(256, sizeof(Frag<TC>) == 16 ? 2 : 1) void sr_rcab_kernel(SrRcab c) {  // bf16: two workgroups per CU: <= 256 VGPRs (the gated form sits at the limit)
+    constexpr bool X3 = sizeof(Frag<TC>) == 32;
+    constexpr int RRING = X3 ? 4 : ::RRING_BF16, R1RING = X3 ? 3 : ::R1RING_BF16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [RKG][IN_ROWS]
-    Frag<bf16>* Amid = Ain + RKG * IN_RS;                     // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
+    Frag<TC>* Ain = reinterpret_cast<Frag<TC>*>(smem);   // [RKG][IN_ROWS]
+    Frag<TC>* Amid = Ain + RKG * IN_RS;                     // [RKG][MID_ROWS], pixel p of the 16 x 16 tile at row 1 + p
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,10 +99,10 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
     const int x0 = tx * TO, y0 = ty * TO;  // output tile origin; intermediate tile origin = (y0 - 1, x0 - 1), halo origin = (y0 - 2, x0 - 2)
 
     RSTAMP(0);
-    const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wn * 2) * RKCT * 64 + lane;
-    Frag<bf16> br[RRING][2];     // conv2: this wave's two channel tiles
-    Frag<bf16> b1r[R1RING][4];   // conv1: all four channel tiles (see there)
-    const Frag<bf16>* W1a = reinterpret_cast<const Frag<bf16>*>(c.w1p) + lane;
+    const Frag<TC>* W2 = reinterpret_cast<const Frag<TC>*>(c.w2p) + (size_t)(wn * 2) * RKCT * 64 + lane;
+    Frag<TC> br[RRING][2];     // conv2: this wave's two channel tiles
+    Frag<TC> b1r[R1RING][4];   // conv1: all four channel tiles (see there)
+    const Frag<TC>* W1a = reinterpret_cast<const Frag<TC>*>(c.w1p) + lane;
 #pragma unroll
     for (int s = 0; s < R1RING - 1; ++s)
 #pragma unroll
@@ -119,9 +137,9 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
                     if constexpr (sizeof(TOut) == 4) {
                         load8f(reinterpret_cast<const float*>(yin) + off[u], yv[u]);
                     } else {
-                        const Frag<bf16> fy = *reinterpret_cast<const Frag<bf16>*>(yin + off[u]);
+                        const Frag<bf16> fy_ = *reinterpret_cast<const Frag<bf16>*>(yin + off[u]);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) yv[u][i] = (float)fy.v[i];
+                        for (int i = 0; i < 8; ++i) yv[u][i] = (float)fy_.v[i];
                     }
                 }
             };
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
                         store4(c.x_out + off[u], f32x4{e[0], e[1], e[2], e[3]});
                         store4(c.x_out + off[u] + 4, f32x4{e[4], e[5], e[6], e[7]});
                     }
-                    if (p < IN_ROWS) Ain[kq * IN_RS + p] = frag_keep_if(valid[u], frag_from8(e));
+                    if (p < IN_ROWS) Ain[kq * IN_RS + p] = frag_keep_if(valid[u], frag_make<TC>(e));
                 }
             };
             issue(wave * 8);
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
         } else {
             const TIn* xin = reinterpret_cast<const TIn*>(c.x);
             for (int pb = wave * 8; pb < IN_ROWS; pb += 32 * NPASS) {
-                Frag<bf16> f[NPASS];
+                Frag<TC> f[NPASS];
                 bool valid[NPASS];
 #pragma unroll
                 for (int u = 0; u < NPASS; ++u) {
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
                     const int gy = y0 - 2 + py, gx = x0 - 2 + px;
                     valid[u] = p < TIN * TIN && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
                     const TIn* src = xin + ((size_t)(b * c.H + (valid[u] ? gy : 0)) * c.W + (valid[u] ? gx : 0)) * RC + kq * 8;
-                    f[u] = load_group<bf16, TIn>(src);
+                    f[u] = load_group<TC, TIn>(src);
                 }
 #pragma unroll
                 for (int u = 0; u < NPASS; ++u) {
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
             }
         }
         if (threadIdx.x < 2 * RKG) {  // margin cells of the intermediate image (read by discarded edge columns only; keep them finite)
-            Frag<bf16> z;
+            Frag<TC> z;
             frag_zero(z);
             Amid[(threadIdx.x >> 1) * MID_ROWS + ((threadIdx.x & 1) ? 1 + TI * TI : 0)] = z;
         }
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4)(0.0f);
-        const Frag<bf16>* abase0 = Ain + (wave * 4) * TIN + ar + ag * IN_RS;
+        const Frag<TC>* abase0 = Ain + (wave * 4) * TIN + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < RKCT; ++tt) {
             const int tap = tt / RKC, kc = tt - tap * RKC;
@@ -277,10 +295,10 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
 #pragma unroll
                 for (int n = 0; n < 2; ++n) br[tt + R1RING - 1 - RKCT][n] = W2[((size_t)n * RKCT + tt + R1RING - 1 - RKCT) * 64];
             }
-            const Frag<bf16>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_RS;
+            const Frag<TC>* arow = abase0 + (tap / 3) * TIN + (tap % 3) + kc * 4 * IN_RS;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const Frag<bf16> a = arow[m * TIN];
+                const Frag<TC> a = arow[m * TIN];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) mma(b1r[tt % R1RING][n], a, acc[m][n]);
             }
@@ -302,12 +320,18 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 f32x4 v = acc[m][n] + bias[n];
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? fmaxf(v[r], 0.0f) : 0.0f);
                 const int kg = n * 2 + (ag >> 1);
-                char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TI + ar) + (ag & 1) * 8;
-                *reinterpret_cast<bf16x4*>(dst) = o;
+                if constexpr (X3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(v[r], 0.0f) : 0.0f;
+                    st_half_x3(Amid + kg * MID_ROWS + 1 + iy * TI + ar, ag & 1, v);
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? fmaxf(v[r], 0.0f) : 0.0f);
+                    char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TI + ar) + (ag & 1) * 8;
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
             }
         }
     }
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
             acc[m][1] = (f32x4)(0.0f);
         }
         // tap (ky, kx) of output (oy, ox) reads intermediate (oy + ky - 1, ox + kx - 1) = cell 1 + (oy + ky - 1) * 16 + ox + kx - 1
-        const Frag<bf16>* abase0 = Amid + (wm * 7) * TI + ar + ag * MID_ROWS;
+        const Frag<TC>* abase0 = Amid + (wm * 7) * TI + ar + ag * MID_ROWS;
 #pragma unroll
         for (int tt = 0; tt < RKCT; ++tt) {
             const int tap = tt / RKC, kc = tt - tap * RKC;
@@ -331,10 +355,10 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
 #pragma unroll
                 for (int n = 0; n < 2; ++n) br[(tt + RRING - 1) % RRING][n] = W2[((size_t)n * RKCT + tt + RRING - 1) * 64];
             }
-            const Frag<bf16>* arow = abase0 + (tap / 3) * TI + (tap % 3) + kc * 4 * MID_ROWS;
+            const Frag<TC>* arow = abase0 + (tap / 3) * TI + (tap % 3) + kc * 4 * MID_ROWS;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
-                const Frag<bf16> a = arow[m * TI];
+                const Frag<TC> a = arow[m * TI];
                 mma(br[tt % RRING][0], a, acc[m][0]);
                 mma(br[tt % RRING][1], a, acc[m][1]);
             }
@@ -405,16 +429,17 @@ __global__ __launch_bounds__(256, 2) void sr_rcab_kernel(SrRcab c) {  // two wor
     RSTAMP(9);
 }
 
-template <typename TIn, typename TOut, bool GATED>
+template <typename TC, typename TIn, typename TOut, bool GATED>
 int launch_rcab(const SrRcab& c, hipStream_t st) {
-    constexpr int lds = (RKG * IN_RS + RKG * MID_ROWS) * (int)sizeof(Frag<bf16>) + (GATED ? GATE_SCRATCH : 0);
+    constexpr int lds = (RKG * IN_RS + RKG * MID_ROWS) * (int)sizeof(Frag<TC>) + (GATED ? GATE_SCRATCH : 0);
+    static_assert(lds <= 160 * 1024, "LDS");
     static SrDeviceOnce attr_once;  // one flag per template instantiation, one bit per device
     {
-        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TIn, TOut, GATED>, lds); });
+        const hipError_t e = sr_once_per_device(attr_once, [&] { return sr_allow_lds(sr_rcab_kernel<TC, TIn, TOut, GATED>, lds); });
         SR_REQUIRE(e == hipSuccess, "sr_rcab_conv_pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int tiles = ((c.W + TO - 1) / TO) * ((c.H + TO - 1) / TO) * c.B;
-    hipLaunchKernelGGL((sr_rcab_kernel<TIn, TOut, GATED>), dim3(tiles), dim3(256), lds, st, c);
+    hipLaunchKernelGGL((sr_rcab_kernel<TC, TIn, TOut, GATED>), dim3(tiles), dim3(256), lds, st, c);
     SR_CHECK_LAUNCH("sr_rcab_conv_pair");
     return SR_OK;
 }
@@ -434,13 +459,24 @@ extern "C" int sr_rcab_conv_pair(const SrRcab* p, void* stream) {
     const SrRcab& c = *p;
     SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.C_p == RC, "sr_rcab_conv_pair: bad geometry (64 padded channels only)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c.compute_dtype == SR_BF16X3) {  // split operands (ABI v11): fp32 tensors throughout
+        SR_REQUIRE(c.x_dtype == SR_F32 && c.y_dtype == SR_F32, "sr_rcab_conv_pair: SR_BF16X3 needs fp32 x / y");
+        if (c.gate_y) {
+            SR_REQUIRE(c.gate_pool && c.gate_w1 && c.gate_b1 && c.gate_w2 && c.gate_b2 && c.x_out, "sr_rcab_conv_pair: gated input: null pointer");
+            SR_REQUIRE(c.gate_C > 0 && c.gate_C <= RC && c.gate_Cr > 0 && c.gate_Cr <= 8, "sr_rcab_conv_pair: gated input: C <= 64 and Cr <= 8");
+            SR_REQUIRE(c.x_out != c.x && c.x_out != c.y && c.gate_y != c.y && c.gate_pool != c.pool_partial, "sr_rcab_conv_pair: gated input: buffers alias");
+            return launch_rcab<bf3, float, float, true>(c, st);
+        }
+        return launch_rcab<bf3, float, float, false>(c, st);
+    }
+    SR_REQUIRE(c.compute_dtype == 0 || c.compute_dtype == SR_BF16, "sr_rcab_conv_pair: compute_dtype must be SR_BF16 (or 0) or SR_BF16X3");
     if (c.gate_y) {
         SR_REQUIRE(c.x_dtype == SR_F32, "sr_rcab_conv_pair: the gated input needs fp32 x / gate_y");
         SR_REQUIRE(c.gate_pool && c.gate_w1 && c.gate_b1 && c.gate_w2 && c.gate_b2 && c.x_out, "sr_rcab_conv_pair: gated input: null pointer");
         SR_REQUIRE(c.gate_C > 0 && c.gate_C <= RC && c.gate_Cr > 0 && c.gate_Cr <= 8, "sr_rcab_conv_pair: gated input: C <= 64 and Cr <= 8");
         SR_REQUIRE(c.x_out != c.x && c.x_out != c.y && c.gate_y != c.y && c.gate_pool != c.pool_partial, "sr_rcab_conv_pair: gated input: buffers alias");
-        return c.y_dtype == SR_F32 ? launch_rcab<float, float, true>(c, st) : launch_rcab<float, bf16, true>(c, st);
+        return c.y_dtype == SR_F32 ? launch_rcab<bf16, float, float, true>(c, st) : launch_rcab<bf16, float, bf16, true>(c, st);
     }
-    if (c.x_dtype == SR_F32) return c.y_dtype == SR_F32 ? launch_rcab<float, float, false>(c, st) : launch_rcab<float, bf16, false>(c, st);
-    return c.y_dtype == SR_F32 ? launch_rcab<bf16, float, false>(c, st) : launch_rcab<bf16, bf16, false>(c, st);
+    if (c.x_dtype == SR_F32) return c.y_dtype == SR_F32 ? launch_rcab<bf16, float, float, false>(c, st) : launch_rcab<bf16, float, bf16, false>(c, st);
+    return c.y_dtype == SR_F32 ? launch_rcab<bf16, bf16, float, false>(c, st) : launch_rcab<bf16, bf16, bf16, false>(c, st);
 }

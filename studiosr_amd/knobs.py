@@ -37,6 +37,7 @@ KNOBS = {
     # ---- convs / RCAN
     "SR_CONV_BIG_MIN": ("224", "tune", "library: the wide-tile conv kernel from this many tiles on"),
     "SR_CONV_TH4_BELOW": ("256", "tune", "library: 4-row conv tiles below this many 8-row tiles"),
+    "SR_RCAB_X3": ("1", "select", "precision fp32x3: the RCAB's conv pair as ONE split-operand launch (0: two sr_conv3x3 launches; compared in tests)"),
     "SR_RCAN_PARTS": ("0", "tune", "RCAN batch as N part batches (0: automatic inside a graph capture)"),
     # ---- training (config 5)
     "SR_FAST_TRAIN": ("1", "select", "fused HAT training path (0: the generic engine, the exact-fp32 parity path; compared in tests)"),

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, packing
-from ..runtime import capturing_or_warming_up, compute_dtype, sr_dtype
+from ..runtime import capturing_or_warming_up, compute_dtype, knob, sr_dtype
 from .common import Model, Upsampler, conv2d, conv_call, pack_upsampler, run_upsampler
 from .edsr import MeanShift, mean_shift_affine
 
@@ -95,8 +95,10 @@ class RCAN(Model):
         keep_all: every group output gets its own buffer (HAN's layer attention reads all of them)."""
         B, H, W, Fp = h.shape
         f32 = torch.float32
-        # bf16, 64 (padded) channels: conv-ReLU-conv of an RCAB is ONE launch (sr_rcab_conv_pair, the intermediate stays in LDS)
-        fused_pair = cdt == torch.bfloat16 and Fp == 64
+        # bf16 or split operands ("fp32x3", round 5), 64 (padded) channels: conv-ReLU-conv of an RCAB is ONE launch (sr_rcab_conv_pair, the intermediate stays in LDS)
+        from ..runtime import x3_active
+
+        fused_pair = (cdt == torch.bfloat16 or (x3_active() and knob("SR_RCAB_X3", "1") != "0")) and Fp == 64
         n_tiles = ops.rcab_pool_tiles(H, W) if fused_pair else ops.conv_pool_tiles(H, W, Fp, sr_dtype(cdt))
         pool = ws_.get("pool", (B, n_tiles, Fp), f32)
         mid = ws_.get("mid", (B, H, W, Fp), cdt)

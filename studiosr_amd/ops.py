@@ -153,6 +153,10 @@ def conv3x3(**kw) -> None:
 
 
 def rcab_conv_pair(**kw) -> None:
+    from .runtime import x3_active
+
+    if x3_active():  # precision "fp32x3": split-operand form (ABI v11; fp32 tensors, weights packed hi | lo)
+        kw.setdefault("compute_dtype", L.SR_BF16X3)
     a = L.SrRcab()
     for k, v in kw.items():
         setattr(a, k, v)

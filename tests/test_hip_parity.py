@@ -495,7 +495,7 @@ def test_swin_qkv_and_tail_kernels_equal_the_gemm_path(monkeypatch):
     assert float((y1 - y0).abs().max()) <= 0.5 * BF16_TOL * scale  # same operands, same products: only the summation order differs
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("prec,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp32x3", 3e-4)])
 def test_rcan_full_width_against_oracle(prec, tol):
     """Default-width RCAN (64 features: in bf16 the conv-ReLU-conv of every RCAB is the one-launch sr_rcab_conv_pair with its
     14 x 14 tiles, zero-padded intermediate and per-tile pooling) on an image that is not a multiple of the tile."""
@@ -531,6 +531,48 @@ def test_rcab_pair_equals_two_conv_launches_bit_for_bit():
                        pool_partial=pool.data_ptr(), B=B, H=H, W=W, C_p=Cc, x_dtype=L.SR_F32, y_dtype=L.SR_F32)
     assert torch.equal(got, want)
     torch.testing.assert_close(pool.sum(dim=1), want.sum(dim=(1, 2)), rtol=1e-4, atol=1e-2)
+
+
+def test_split_operand_rcab_pair_against_two_split_operand_conv_launches_and_conv2d():
+    """ABI v11, precision "fp32x3" (what inference() runs, common.py:36-48): sr_rcab_conv_pair with compute_dtype SR_BF16X3 (every operand a hi + lo bf16 pair, 32-byte image
+    cells, one workgroup per CU) against (a) the two split-operand sr_conv3x3 launches it replaces -- same K walk: identical bits -- and (b) torch conv2d in fp32
+    (fp32-class accuracy); plus the gated form (the previous block's channel-attention tail folded into the halo staging) against sr_channel_attention + the plain pair."""
+    from studiosr_amd.models.rcan import pack_ca, run_channel_attention
+    from studiosr_amd.runtime import X3_KEY, x3_mode
+
+    torch.manual_seed(13)
+    B, H, W, Cc, Cr = 2, 30, 41, 64, 4
+    w1, w2 = torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05, torch.randn(Cc, Cc, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(Cc, device=DEV) * 0.1, torch.randn(Cc, device=DEV) * 0.1
+    ident = packing.identity_idx(Cc, Cc)
+    c1, c2 = packing.pack_conv3x3(w1, b1, Cc, ident, X3_KEY), packing.pack_conv3x3(w2, b2, Cc, ident, X3_KEY)
+    x = torch.randn(B, H, W, Cc, device=DEV)
+    n_tiles = ops.rcab_pool_tiles(H, W)
+    kw = dict(w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(), B=B, H=H, W=W, C_p=Cc, x_dtype=L.SR_F32, y_dtype=L.SR_F32)
+    with x3_mode(True):
+        mid, want = torch.empty(B, H, W, Cc, device=DEV), torch.empty(B, H, W, Cc, device=DEV)
+        conv_call(x, *c1, mid, torch.float32, act=L.ACT_RELU)
+        conv_call(mid, *c2, want, torch.float32)
+        got, pool = torch.full_like(want, float("nan")), torch.zeros(B, n_tiles, Cc, device=DEV)
+        ops.rcab_conv_pair(x=x.data_ptr(), y=got.data_ptr(), pool_partial=pool.data_ptr(), **kw)
+        assert torch.equal(got, want), f"max diff {float((got - want).abs().max()):.3e}, nan {int(torch.isnan(got).sum())}"
+        torch.testing.assert_close(pool.sum(dim=1), want.sum(dim=(1, 2)), rtol=1e-4, atol=1e-2)
+        ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w1, b1, padding=1)), w2, b2, padding=1).permute(0, 2, 3, 1)
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        # gated form
+        ca = pack_ca(torch.randn(Cr, Cc, 1, 1, device=DEV) * 0.3, torch.randn(Cr, device=DEV) * 0.1, torch.randn(Cc, Cr, 1, 1, device=DEV) * 0.3,
+                     torch.randn(Cc, device=DEV) * 0.1)
+        x_want = torch.empty_like(x)
+        run_channel_attention(ca, got, pool, n_tiles, Cc, x_want, skip=x)
+        y_want, pool_want = torch.empty_like(x), torch.zeros_like(pool)
+        ops.rcab_conv_pair(x=x_want.data_ptr(), y=y_want.data_ptr(), pool_partial=pool_want.data_ptr(), **kw)
+        x_got, y_got, pool_got = torch.full_like(x, float("nan")), torch.full_like(x, float("nan")), torch.zeros_like(pool)
+        w1c, b1c, w2c, b2c = ca
+        ops.rcab_conv_pair(x=x.data_ptr(), gate_y=got.data_ptr(), gate_pool=pool.data_ptr(), gate_w1=w1c.data_ptr(), gate_b1=b1c.data_ptr(), gate_w2=w2c.data_ptr(),
+                           gate_b2=b2c.data_ptr(), x_out=x_got.data_ptr(), gate_C=Cc, gate_Cr=Cr, y=y_got.data_ptr(), pool_partial=pool_got.data_ptr(), **kw)
+        assert torch.equal(x_got, x_want), f"x_out: max diff {float((x_got - x_want).abs().max()):.3e}"
+        assert torch.equal(y_got, y_want), f"y: max diff {float((y_got - y_want).abs().max()):.3e}"
+        assert torch.equal(pool_got, pool_want)
 
 
 def test_gated_rcab_equals_channel_attention_then_conv_pair():

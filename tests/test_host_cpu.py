@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/studiosr_hip.h but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in studiosr_amd/_lib.py"
     assert sorted(L.SYMBOLS) == names
-    assert lib.sr_abi_version() == L.ABI_VERSION == 10
+    assert lib.sr_abi_version() == L.ABI_VERSION == 11
 
 
 def test_ctypes_struct_sizes_match_the_c_header(tmp_path):
