@@ -449,14 +449,15 @@ def test_weight_gradient_kernel_against_torch():
     assert _rel(o2.sum(0), ref2) <= 1e-5
 
 
-def test_fused_training_path_drop_path_and_accumulation():
-    """DropPath in the fused path (hat.py:148,192-193: per block, per branch, per image scale in {0, 1 / keep}): with the SAME scales forced into
+@pytest.mark.parametrize("kind", ["HAT", "SwinIR"])
+def test_fused_training_path_drop_path_and_accumulation(kind):
+    """DropPath in the fused path (hat.py:148,192-193 / swinir.py:137,171-172: per block, per branch, per image scale in {0, 1 / keep}): with the SAME scales forced into
     both paths the fused gradients match the generic engine's; a dropped branch (scale 0) contributes nothing; and a second backward onto
     existing .grad tensors accumulates (the gradient buffer of the first is not overwritten)."""
     from studiosr_amd import autograd as A
     from studiosr_amd import fasttrain
 
-    m = _default_width_hat(drop_path_rate=0.3)
+    m = _default_width_hat(drop_path_rate=0.3, kind=kind)
     torch.manual_seed(5)
     x, y = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
     scales = torch.tensor([[[[0.0, 1.25], [1.25, 1.25]], [[1.0 / 0.7, 0.0], [0.0, 1.0 / 0.7]]]], device=DEV)  # [stage 1][block 2][branch 2][image 2]
