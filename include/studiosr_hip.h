@@ -294,7 +294,8 @@ typedef struct SrCab {
     void* y;              /* NHWC [B,H,W,Cout_p] bf16; must not alias x */
     float* pool_partial;  /* optional [B, sr_cab_pool_tiles(H, W), Cout_p] */
     int B, H, W, Cin_p, Cmid_p, Cout_p;  /* 192, 64, 192 */
-    int dtype;            /* SR_BF16 */
+    int dtype;            /* SR_BF16; or SR_BF16X3 (ABI v11, sr_cab_fused only): split operands hi + lo (precision "fp32x3"): x, y fp32, weights packed hi | lo, erf GELU to 1.5e-7,
+                           * 103 KB of LDS images on the two-phase K walk, one workgroup per CU; mid_pre must be NULL */
     void* mid_pre;        /* optional side output (ABI v8; training): conv1(x) + b1 BEFORE the GELU, NHWC [B,H,W,Cmid_p] bf16 -- what the backward needs for GELU' and for conv2's
                            * weight gradient, so that it does not run conv1 again (trainer.py:104 loss.backward() through hat.py:41-49) */
     int tile_rows;        /* (ABI v9) output rows per workgroup tile (14 columns): 0 or 6, or 8 in sr_hab_mid (large launches: fewer workgroups, less halo recomputation);

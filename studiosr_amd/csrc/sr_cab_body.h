@@ -23,7 +23,7 @@ constexpr int TINW = 18, TINH = TOH + 4; // input halo
 constexpr int IN_ROWS = (TINW * TINH + 7) / 8 * 8;  // halo pixels (18 x 10 = 180 -> 184), padded to a multiple of 8
 constexpr int IN_RS = IN_ROWS + 1;    // odd cell stride: the 8 K-groups of one pixel (8 adjacent lanes of the staging writes) hit 8 bank groups
 constexpr int MID_ROWS = (2 + TIW * TIH + 7) / 8 * 8;  // 1 margin cell + the intermediate pixels + 1 margin cell, padded to a multiple of 8
-constexpr int RING1 = 6, RING2 = 4;
+constexpr int SR_CAB_NS_RING1 = 6, SR_CAB_NS_RING2 = 4;  // weight rings (bf16; the split-operand form: 3 / 3)
 // K phases of conv1: PH = 2 keeps only 96 of the 192 input channels of the halo resident (52 KiB of LDS instead of 88: two workgroups per CU
 // where the launch is several residency rounds, e.g. HAT x4 b16: 880 workgroups); the second phase's halo loads fly under the first phase's MFMAs
 #ifndef SR_CAB_PH
@@ -35,6 +35,7 @@ constexpr int LP = KG_RES / 3, PPI = 64 / LP;            // staging: lanes per p
 constexpr int UNITS = (IN_ROWS + PPI - 1) / PPI * 3, NU = (UNITS + 3) / 4;  // (pixel group, pass) units; per wave
 static_assert(KG_IN % PH == 0 && KG_RES % 3 == 0 && (LP == 8 || LP == 4), "phase geometry");
 constexpr int LDS_BYTES = (KG_RES * IN_RS + KG_MID * MID_ROWS) * 16;
+constexpr int LDS_BYTES_X3 = (KG_RES * IN_RS + KG_MID * MID_ROWS) * 32;  // split-operand images
 constexpr int R1 = TIH / 2;           // intermediate rows per wave pair in conv1
 static_assert(TINW * TINH <= IN_ROWS && 2 + TIW * TIH <= MID_ROWS && TIH % 2 == 0, "image sizes");
 
@@ -42,9 +43,14 @@ static_assert(TINW * TINH <= IN_ROWS && 2 + TIW * TIH <= MID_ROWS && TIH % 2 == 
 #define SR_CAB_WGS (SR_CAB_PH == 1 ? 1 : 2)
 #endif
 // the work of one workgroup (256 threads, LDS_BYTES of dynamic LDS at `smem`): tile `block_id` of B * tiles_y * tiles_x
+// TC = bf16 (x, y bf16) or bf3 (round 5, compute type SR_BF16X3 = precision "fp32x3": every operand a hi + lo bf16 pair, 32-byte image cells -- LDS_BYTES_X3, which needs the
+// two K phases; x, y fp32; erf GELU; shorter weight rings of the wider fragments)
+template <typename TC = bf16, typename TIn = bf16, typename TOut = bf16>
 SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
-    Frag<bf16>* Ain = reinterpret_cast<Frag<bf16>*>(smem);   // [KG_RES][IN_RS]
-    Frag<bf16>* Amid = Ain + KG_RES * IN_RS;                   // [KG_MID][MID_ROWS], pixel p of the 16 x 8 tile at cell 1 + p
+    constexpr bool X3 = sizeof(Frag<TC>) == 32;
+    constexpr int RING1 = X3 ? 3 : SR_CAB_NS_RING1, RING2 = X3 ? 3 : SR_CAB_NS_RING2;
+    Frag<TC>* Ain = reinterpret_cast<Frag<TC>*>(smem);   // [KG_RES][IN_RS]
+    Frag<TC>* Amid = Ain + KG_RES * IN_RS;                   // [KG_MID][MID_ROWS], pixel p of the 16 x 8 tile at cell 1 + p
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -58,11 +64,11 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
     const int b = t / tiles_y;
     const int x0 = tx * TOW, y0 = ty * TOH;  // output tile origin; intermediate origin (y0 - 1, x0 - 1), halo origin (y0 - 2, x0 - 2)
 
-    const Frag<bf16>* W1 = reinterpret_cast<const Frag<bf16>*>(c.w1p) + (size_t)(wn * 2) * KCT1 * 64 + lane;
-    const Frag<bf16>* W2 = reinterpret_cast<const Frag<bf16>*>(c.w2p) + (size_t)(wave * 3) * KCT2 * 64 + lane;
+    const Frag<TC>* W1 = reinterpret_cast<const Frag<TC>*>(c.w1p) + (size_t)(wn * 2) * KCT1 * 64 + lane;
+    const Frag<TC>* W2 = reinterpret_cast<const Frag<TC>*>(c.w2p) + (size_t)(wave * 3) * KCT2 * 64 + lane;
     // conv1 walks K phase-major: step t = (phase, tap, chunk in phase) -> packed chunk index tap * KC_IN + phase * KC_PH + chunk (PH = 1: t itself)
     auto chunk_of = [](int t) { return ((t % (9 * KC_PH)) / KC_PH) * KC_IN + (t / (9 * KC_PH)) * KC_PH + t % KC_PH; };
-    Frag<bf16> r1[RING1][2];
+    Frag<TC> r1[RING1][2];
 #pragma unroll
     for (int s = 0; s < RING1 - 1; ++s)
 #pragma unroll
@@ -71,8 +77,8 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
     // ---- stage the input halo: PPI pixels x LP K-groups per wave instruction, K-group on the fast lane axis (the LP lanes of a pixel read 16 LP
     //      contiguous bytes); unit u = (pixel group, pass), UNITS over 4 waves
     const int kq = lane & (LP - 1), rp = lane / LP;
-    const bf16* xin = reinterpret_cast<const bf16*>(c.x);
-    auto issue = [&](int ph, int k0, int nk, Frag<bf16>* f, bool* valid) {  // units k0 .. k0 + nk - 1 of this wave
+    const TIn* xin = reinterpret_cast<const TIn*>(c.x);
+    auto issue = [&](int ph, int k0, int nk, Frag<TC>* f, bool* valid) {  // units k0 .. k0 + nk - 1 of this wave
 #pragma unroll
         for (int k = 0; k < nk; ++k) {
             const int u = 4 * (k0 + k) + wave;
@@ -81,11 +87,11 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
             const int py = p / TINW, px = p - py * TINW;
             const int gy = y0 - 2 + py, gx = x0 - 2 + px;
             valid[k] = u < UNITS && p < TINW * TINH && gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;
-            const bf16* src = xin + ((size_t)(b * c.H + (valid[k] ? gy : 0)) * c.W + (valid[k] ? gx : 0)) * CI + (ph * KG_RES + j * LP + kq) * 8;
-            f[k] = *reinterpret_cast<const Frag<bf16>*>(src);
+            const TIn* src = xin + ((size_t)(b * c.H + (valid[k] ? gy : 0)) * c.W + (valid[k] ? gx : 0)) * CI + (ph * KG_RES + j * LP + kq) * 8;
+            f[k] = load_group<TC, TIn>(src);
         }
     };
-    auto commit = [&](int k0, int nk, const Frag<bf16>* f, const bool* valid) {
+    auto commit = [&](int k0, int nk, const Frag<TC>* f, const bool* valid) {
 #pragma unroll
         for (int k = 0; k < nk; ++k) {
             const int u = 4 * (k0 + k) + wave;
@@ -98,23 +104,23 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
         constexpr int NP = PH == 1 ? 6 : NU;  // loads in flight
 #pragma unroll
         for (int k0 = 0; k0 < NU; k0 += NP) {
-            Frag<bf16> f[NP];
+            Frag<TC> f[NP];
             bool valid[NP];
             issue(0, k0, NP, f, valid);
             commit(k0, NP, f, valid);
         }
         if (threadIdx.x < 2 * KG_MID) {  // margin cells of the intermediate image (read by discarded edge columns only; keep them finite)
-            Frag<bf16> z;
+            Frag<TC> z;
             frag_zero(z);
             Amid[(threadIdx.x >> 1) * MID_ROWS + ((threadIdx.x & 1) ? 1 + TIW * TIH : 0)] = z;
         }
     }
-    Frag<bf16> f1[PH == 1 ? 1 : NU];  // phase 1 of the halo: requested now, written to LDS between the phases
+    Frag<TC> f1[PH == 1 ? 1 : NU];  // phase 1 of the halo: requested now, written to LDS between the phases
     bool v1[PH == 1 ? 1 : NU];
     if constexpr (PH == 2) issue(1, 0, NU, f1, v1);
     __syncthreads();
 
-    Frag<bf16> r2[RING2][3];
+    Frag<TC> r2[RING2][3];
     // ---- conv1 + bias + GELU -> intermediate image.  Wave (wm, wn): rows [R1 wm, R1 wm + R1) x channels [32 wn, 32 wn + 32)
     {
         f32x4 acc[R1][2];
@@ -123,7 +129,7 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
             acc[m][0] = (f32x4)(0.0f);
             acc[m][1] = (f32x4)(0.0f);
         }
-        const Frag<bf16>* abase0 = Ain + (wm * R1) * TINW + ar + ag * IN_RS;
+        const Frag<TC>* abase0 = Ain + (wm * R1) * TINW + ar + ag * IN_RS;
 #pragma unroll
         for (int tt = 0; tt < KCT1; ++tt) {
             const int tp = tt % (9 * KC_PH), tap = tp / KC_PH, kc = tp - tap * KC_PH;
@@ -140,10 +146,10 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
 #pragma unroll
                 for (int n = 0; n < 3; ++n) r2[s][n] = W2[((size_t)n * KCT2 + s) * 64];
             }
-            const Frag<bf16>* arow = abase0 + (tap / 3) * TINW + (tap % 3) + kc * 4 * IN_RS;
+            const Frag<TC>* arow = abase0 + (tap / 3) * TINW + (tap % 3) + kc * 4 * IN_RS;
 #pragma unroll
             for (int m = 0; m < R1; ++m) {
-                const Frag<bf16> a = arow[m * TINW];
+                const Frag<TC> a = arow[m * TINW];
                 mma(r1[tt % RING1][0], a, acc[m][0]);
                 mma(r1[tt % RING1][1], a, acc[m][1]);
             }
@@ -157,7 +163,21 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
             const bool inside = gy >= 0 && gy < c.H && gx >= 0 && gx < c.W;  // outside the image the intermediate is conv2's zero padding
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+                f32x4 v = acc[m][n] + (n == 0 ? bias0 : bias1);
+                const int kg = (wn * 2 + n) * 2 + (ag >> 1);
+                if constexpr (X3) {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = inside ? gelu_fast(v[r]) : 0.0f;
+                        h[r] = (bf16)g;
+                        l[r] = (bf16)(g - (float)h[r]);
+                    }
+                    char* cell = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TIW + ar);
+                    *reinterpret_cast<bf16x4*>(cell + (ag & 1) * 8) = h;
+                    *reinterpret_cast<bf16x4*>(cell + 16 + (ag & 1) * 8) = l;
+                    continue;
+                }
                 if (c.mid_pre && inside && iy >= 1 && iy <= TOH && ar >= 1 && ar <= TOW) {  // the tile's own pixels (every pixel once): the pre-activation for the backward
                     bf16x4 pre;
 #pragma unroll
@@ -167,7 +187,6 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? gelu_fast(v[r]) : 0.0f);
-                const int kg = (wn * 2 + n) * 2 + (ag >> 1);
                 char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TIW + ar) + (ag & 1) * 8;
                 *reinterpret_cast<bf16x4*>(dst) = o;
             }
@@ -183,7 +202,7 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4)(0.0f);
         // tap (ky, kx) of output (oy, ox) reads intermediate (oy + ky - 1, ox + kx - 1) = cell 1 + (oy + ky - 1) * 16 + ox + kx - 1, oy = 1 + m
-        const Frag<bf16>* abase0 = Amid + ar + ag * MID_ROWS;
+        const Frag<TC>* abase0 = Amid + ar + ag * MID_ROWS;
 #pragma unroll
         for (int tt = 0; tt < KCT2; ++tt) {
             const int tap = tt / KC_MID, kc = tt - tap * KC_MID;
@@ -191,10 +210,10 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
 #pragma unroll
                 for (int n = 0; n < 3; ++n) r2[(tt + RING2 - 1) % RING2][n] = W2[((size_t)n * KCT2 + tt + RING2 - 1) * 64];
             }
-            const Frag<bf16>* arow = abase0 + (tap / 3) * TIW + (tap % 3) + kc * 4 * MID_ROWS;
+            const Frag<TC>* arow = abase0 + (tap / 3) * TIW + (tap % 3) + kc * 4 * MID_ROWS;
 #pragma unroll
             for (int m = 0; m < TOH; ++m) {
-                const Frag<bf16> a = arow[m * TIW];
+                const Frag<TC> a = arow[m * TIW];
 #pragma unroll
                 for (int n = 0; n < 3; ++n) mma(r2[tt % RING2][n], a, acc[m][n]);
             }
@@ -206,11 +225,12 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
         const int gx = x0 - 1 + ar;
         const bool xin_tile = ar >= 1 && ar <= TOW && gx < c.W;
         f32x4 pool[3] = {(f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f)};
-        bf16* y = reinterpret_cast<bf16*>(c.y);
+        TOut* y = reinterpret_cast<TOut*>(c.y);
         // Coalesced store: one row of 16 pixels x this wave's 48 channels at a time through a wave-private fp32 tile in the (dead) input image:
-        // accumulator layout in (pixel on the lane axis), 16-byte pieces (8 bf16) out with adjacent lanes on adjacent addresses of ONE pixel.
+        // accumulator layout in (pixel on the lane axis), 16-byte pieces (8 bf16 / 4 fp32) out with adjacent lanes on adjacent addresses of ONE pixel.
         constexpr int S = 48 * 4 + 16;   // bytes per pixel row of the private tile
-        constexpr int PP = 6;            // 16-byte pieces per pixel (48 channels bf16)
+        constexpr int NV = 16 / (int)sizeof(TOut);               // channels per 16-byte piece
+        constexpr int PP = 48 / NV, NI = (16 * PP + 63) / 64;    // 16-byte pieces per pixel (48 channels), store instructions per row
         char* priv = smem + wave * (16 * S);
 #pragma unroll
         for (int m = 0; m < TOH; ++m) {
@@ -223,17 +243,23 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
                 *reinterpret_cast<f32x4*>(priv + ar * S + (n * 16 + ag * 4) * 4) = v;
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < NI; ++k) {
                 const int idx = k * 64 + lane, px = idx / PP, pc = idx - px * PP;
                 if (idx < 16 * PP) {
                     const int gxp = x0 - 1 + px;
-                    const float* src = reinterpret_cast<const float*>(priv + px * S) + pc * 8;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+                    const float* src = reinterpret_cast<const float*>(priv + px * S) + pc * NV;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
                     if (px >= 1 && px <= TOW && gxp < c.W && gy < c.H) {
-                        bf16x8 o;
+                        TOut* dst = y + ((size_t)(b * c.H + gy) * c.W + gxp) * CO + wave * 48 + pc * NV;
+                        if constexpr (sizeof(TOut) == 2) {
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+                            bf16x8 o;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (bf16)lo[q], o[4 + q] = (bf16)hi[q];
-                        *reinterpret_cast<bf16x8*>(y + ((size_t)(b * c.H + gy) * c.W + gxp) * CO + wave * 48 + pc * 8) = o;
+                            for (int q = 0; q < 4; ++q) o[q] = (bf16)lo[q], o[4 + q] = (bf16)hi[q];
+                            *reinterpret_cast<bf16x8*>(dst) = o;
+                        } else {
+                            store4(dst, lo);
+                        }
                     }
                 }
             }
@@ -262,8 +288,8 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
 static inline int cab_check(const SrCab* p, const char* who) {
     SR_REQUIRE(p && p->x && p->w1p && p->b1 && p->w2p && p->b2 && p->y, "%s: null pointer (CAB operands)", who);
     const SrCab& c = *p;
-    SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.Cin_p == CI && c.Cmid_p == CM && c.Cout_p == CO && c.dtype == SR_BF16,
-               "%s: bad CAB geometry (192 -> 64 -> 192 padded channels, bf16 only)", who);
+    SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.Cin_p == CI && c.Cmid_p == CM && c.Cout_p == CO && (c.dtype == SR_BF16 || c.dtype == SR_BF16X3),
+               "%s: bad CAB geometry (192 -> 64 -> 192 padded channels; bf16, or SR_BF16X3 on fp32 tensors)", who);
     SR_REQUIRE(c.x != c.y, "%s: y must not alias x (halo reads)", who);
     SR_REQUIRE((long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B < (1l << 31), "%s: too many tiles", who);
     return SR_OK;

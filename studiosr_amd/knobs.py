@@ -24,6 +24,7 @@ KNOBS = {
     "SR_ATTN_LDS": ("1", "select", "window attention with K / V^T / distinct bias tiles staged in LDS (0: flash form; compared in tests)"),
     "SR_ATTN_QKV": ("auto", "tune", "attention workgroups project their own head's q / k / v (auto: up to 128 (window, head) items)"),
     "SR_OCA_LDS": ("1", "select", "overlapping cross attention with K / V^T / table in LDS (0: flash form; compared in tests)"),
+    "SR_CAB_X3": ("0", "select", "precision fp32x3: the CAB's two convs as ONE split-operand launch (tested; measured slower than the two sr_conv3x3 launches at HAT's sizes: off)"),
     "SR_CAB_FUSED": ("1", "select", "the CAB's two convs as one launch (0: two sr_conv3x3 launches)"),
     "SR_CAB_ROWS8_FROM": ("16384", "tune", "CAB tiles of 14 x 8 outputs from this many pixels on"),
     "SR_TAIL_GATE": ("1", "select", "channel-attention gate recomputed inside sr_swin_tail (0: sr_channel_gate launch)"),

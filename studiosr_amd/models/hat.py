@@ -297,7 +297,13 @@ class HAT(Model):
         # small batches: 4-row conv tiles (twice the workgroups) also for the conv with the pool side output
         th = 4 if (cdt == torch.bfloat16 and ((W + 15) // 16) * ((H + 7) // 8) * B < 256) else 0
         # conv -> GELU -> conv as ONE launch (sr_cab_fused; SR_CAB_FUSED=0: two sr_conv3x3 launches)
-        cab_fused = cdt == torch.bfloat16 and knob("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, L.SR_BF16)
+        # (round 5, ABI v11: sr_cab_fused also has a split-operand form for precision "fp32x3"; it is correct and tested but one workgroup per CU -- 103 KB of images -- and at
+        # HAT's sizes SLOWER than the two split-operand sr_conv3x3 launches: x4 b4 6.71 vs 6.26 ms, b16 21.8 vs 20.7: SR_CAB_X3=1 selects it)
+        from ..runtime import x3_active
+
+        cab_x3 = cdt == torch.float32 and x3_active() and knob("SR_CAB_X3", "0") != "0"
+        cab_code = L.SR_BF16X3 if cab_x3 else L.SR_BF16
+        cab_fused = (cdt == torch.bfloat16 or cab_x3) and knob("SR_CAB_FUSED", "1") != "0" and ops.cab_supported(Cp, P["c3p"], Cp, cab_code)
         # The conv branch (LayerNorm1, 2 convs, gate) and the attention branch (QKV GEMM, attention) only share their input, and at the
         # tile sizes of this model every launch is a fraction of the chip: the conv branch runs on a side stream beside the attention
         # branch and joins before the projection GEMM -- the first writer of t (which may be t_in) and the consumer of the conv branch.
@@ -316,7 +322,7 @@ class HAT(Model):
                     and swin_qkv_usable(next_oca, geo, Cp, cdt) and P["border"] % 4 == 0 and knob("SR_TAIL_OCA", "1") != "0" and bp["shift"] % 4 == 0)
 
         # attention + CAB as ONE launch (sr_hab_mid, ABI v8): no second stream, no fork / join edges in the captured graph (SR_HAB_MID=0: two launches)
-        mid_fused = (unfused and cab_fused and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
+        mid_fused = (unfused and cab_fused and not cab_x3 and gate_in_tail and knob("SR_HAB_MID", "1") != "0" and (qkv_ready or swin_qkv_usable(bp, geo, Cp, cdt))
                      and ops.hab_mid_supported(geo.ntok, geo.hd_p, geo.ws, L.SR_BF16, Cp, P["c3p"], Cp, L.SR_BF16))
         # the attention workgroups of sr_hab_mid project their own head from the stream (LayerNorm1 + QKV inside the attention role: no QKV stage on the tail's chain)
         qkv_in_attn = (mid_fused and not qkv_ready and "bias_tiles" in bp and bp.get("qkv_dtype") == L.SR_BF16 and geo.heads == 6 and geo.C == 180
@@ -341,7 +347,7 @@ class HAT(Model):
                 else:
                     ops.layernorm(t_in, n1, *bp["ln1"], self.embed_dim)
         cab_kw = dict(x=n1.data_ptr(), w1p=bp["cab1"][0].data_ptr(), b1=bp["cab1"][1].data_ptr(), w2p=bp["cab2"][0].data_ptr(), b2=bp["cab2"][1].data_ptr(),
-                      y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=L.SR_BF16, tile_rows=cab_rows)
+                      y=y.data_ptr(), pool_partial=pool.data_ptr(), B=B, H=H, W=W, Cin_p=Cp, Cmid_p=P["c3p"], Cout_p=Cp, dtype=cab_code, tile_rows=cab_rows)
 
         def conv_branch():
             if mid_fused:

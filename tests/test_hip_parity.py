@@ -575,6 +575,37 @@ def test_split_operand_rcab_pair_against_two_split_operand_conv_launches_and_con
         assert torch.equal(pool_got, pool_want)
 
 
+def test_split_operand_cab_against_two_split_operand_conv_launches_and_conv2d():
+    """ABI v11, precision "fp32x3": sr_cab_fused with dtype SR_BF16X3 (HAT's CAB, hat.py:41-49: conv 180 -> 60, GELU, conv 60 -> 180 on fp32 tensors, every operand a hi + lo
+    bf16 pair, two-phase K walk) against the two split-operand sr_conv3x3 launches it replaces (their GELU is erff, the fused kernel's the 1.5e-7 erf: fp32-level
+    agreement, not bits) and against torch conv2d + GELU in fp32; pool partials = sums of y.  An image that is no multiple of the 14 x 6 tile."""
+    from studiosr_amd.runtime import X3_KEY, x3_mode
+
+    torch.manual_seed(14)
+    B, H, W, Ci, Cm = 2, 33, 45, 180, 60
+    w1, w2 = torch.randn(Cm, Ci, 3, 3, device=DEV) * 0.03, torch.randn(Ci, Cm, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(Cm, device=DEV) * 0.1, torch.randn(Ci, device=DEV) * 0.1
+    c1 = packing.pack_conv3x3(w1, b1, 192, packing.identity_idx(Cm, 64), X3_KEY)
+    c2 = packing.pack_conv3x3(w2, b2, 64, packing.identity_idx(Ci, 192), X3_KEY)
+    x = torch.zeros(B, H, W, 192, device=DEV)
+    x[..., :Ci] = torch.randn(B, H, W, Ci, device=DEV)
+    with x3_mode(True):
+        mid, want = torch.empty(B, H, W, 64, device=DEV), torch.empty(B, H, W, 192, device=DEV)
+        conv_call(x, *c1, mid, torch.float32, act=L.ACT_GELU)
+        conv_call(mid, *c2, want, torch.float32)
+        assert ops.cab_supported(192, 64, 192, L.SR_BF16X3)
+        n_tiles = ops.cab_pool_tiles_rows(H, W, 0)
+        got, pool = torch.full_like(want, float("nan")), torch.zeros(B, n_tiles, 192, device=DEV)
+        ops.cab_fused(x=x.data_ptr(), w1p=c1[0].data_ptr(), b1=c1[1].data_ptr(), w2p=c2[0].data_ptr(), b2=c2[1].data_ptr(), y=got.data_ptr(), pool_partial=pool.data_ptr(),
+                      B=B, H=H, W=W, Cin_p=192, Cmid_p=64, Cout_p=192, dtype=L.SR_BF16X3, tile_rows=0)
+    assert not bool(torch.isnan(got).any())
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= 5e-6 * scale, float((got - want).abs().max())
+    ref = torch.nn.functional.conv2d(torch.nn.functional.gelu(torch.nn.functional.conv2d(x[..., :Ci].permute(0, 3, 1, 2), w1, b1, padding=1)), w2, b2, padding=1).permute(0, 2, 3, 1)
+    assert float((got[..., :Ci] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(pool.sum(dim=1), got.sum(dim=(1, 2)), rtol=1e-4, atol=1e-2)
+
+
 def test_gated_rcab_equals_channel_attention_then_conv_pair():
     """ABI v4 gated input of sr_rcab_conv_pair: x_eff = x + gate * y_prev folded into the halo staging must give the bits of the
     two-launch sequence (sr_channel_attention -> plain sr_rcab_conv_pair): same skip tensor (x_out), same y, same pool partials."""
