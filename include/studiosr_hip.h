@@ -316,7 +316,8 @@ typedef struct SrWindowAttn {
     void* out;            /* [bwin*ntok][heads*hd_p] T (window-order rows) */
     int n_bwin, heads, hd_p, ntok;
     int H, W, ws, shift;  /* mask geometry (shift == 0 -> no mask) */
-    int dtype;
+    int dtype;             /* SR_F32 (exact fp32 MFMAs), SR_BF16, or -- ABI v11 -- SR_BF16X3: fp32 q / k / vt / out, every product as split-operand bf16 (precision "fp32x3"); needs
+                            * bias_frag, ws % 4 == 0, hd_p 32, 64 / 256 tokens, row-major operands */
     int y_mode;           /* SR_Y_* */
     const float* bias_frag; /* optional: the same bias in accumulator-fragment order [heads][qt][kt][lane][4]
                              * (element = bias[h][16 qt + (lane & 15)][16 kt + 4 (lane >> 4) + r]); selects the flash-form kernel */

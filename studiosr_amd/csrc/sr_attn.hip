@@ -194,6 +194,13 @@ int launch_attn(const SrWindowAttn& a, hipStream_t st) {
     return SR_OK;
 }
 
+// SR_BF16X3 (ABI v11): fp32 tensors, split-operand MFMAs -- the flash form only (fragment-ordered bias, head_dim <= 32)
+static bool attn_x3_usable(const SrWindowAttn& a) { return a.bias_frag && a.ws % 4 == 0 && a.hd_p == 32 && (a.ntok == 256 || a.ntok == 64) && !a.qkv_frag && !a.bias_tiles && !a.x; }
+static int dispatch_attn_x3(const SrWindowAttn& a, hipStream_t st) {
+    if (a.ntok == 256) return launch_flash<bf3, 16, 2, 1>(a, st);
+    return launch_flash<bf3, 4, 4, 1>(a, st);
+}
+
 template <typename TC>
 int dispatch_attn(const SrWindowAttn& a, hipStream_t st) {
     if (a.bias_frag && a.ws % 4 == 0) {  // fragment-ordered bias available: flash form
@@ -234,6 +241,10 @@ extern "C" int sr_window_attention(const SrWindowAttn* p, void* stream) {
                        ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.wqkv)) & 15) == 0,
                    "sr_window_attention: the fused QKV form needs x, wqkv, bias_tiles, bf16, 16 x 16 windows, 6 heads of <= 32, C = 180 in >= 192 padded channels");
         return launch_qkv_lds(a, st);
+    }
+    if (a.dtype == SR_BF16X3) {
+        SR_REQUIRE(attn_x3_usable(a), "sr_window_attention: SR_BF16X3 needs bias_frag, ws %% 4 == 0, hd_p 32, 64 / 256 tokens, row-major q / k / vt");
+        return dispatch_attn_x3(a, st);
     }
     return a.dtype == SR_BF16 ? dispatch_attn<bf16>(a, st) : dispatch_attn<float>(a, st);
 }

@@ -8,8 +8,8 @@ namespace {
 
 SR_DEV int region(int v, int size, int ws, int shift) { return v < size - ws ? 0 : (v < size - shift ? 1 : 2); }
 
-template <typename TC>
-SR_DEV Frag<TC> load_vt(const TC* p0, const TC* p1);
+template <typename TC, typename TS = TC>
+SR_DEV Frag<TC> load_vt(const TS* p0, const TS* p1);
 template <>
 SR_DEV Frag<bf16> load_vt<bf16>(const bf16* p0, const bf16* p1) {
     bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
@@ -26,8 +26,32 @@ SR_DEV Frag<float> load_vt<float>(const float* p0, const float* p1) {
     return f;
 }
 
+// Storage type of q / k / v^T / out for a compute fragment type: the split-operand form (bf3, compute type SR_BF16X3 = precision "fp32x3", round 5) works on fp32 tensors --
+// every operand fragment is split into hi + lo bf16 as it is loaded, P as it is packed; three bf16 MFMAs per product instead of the eight 16x16x4 fp32 MFMAs of TC = float.
+template <typename TC>
+struct WaStore {
+    typedef TC type;
+};
+template <>
+struct WaStore<bf3> {
+    typedef float type;
+};
+template <>
+SR_DEV Frag<bf3> load_vt<bf3, float>(const float* p0, const float* p1) {
+    float v[8];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p0), b = *reinterpret_cast<const f32x4*>(p1);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return frag_make<bf3>(v);
+}
+
 template <typename TC>
 SR_DEV Frag<TC> pack_p(const f32x4& a, const f32x4& b);
+template <>
+SR_DEV Frag<bf3> pack_p<bf3>(const f32x4& a, const f32x4& b) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return frag_make<bf3>(v);
+}
 template <>
 SR_DEV Frag<bf16> pack_p<bf16>(const f32x4& a, const f32x4& b) {
     Frag<bf16> f;
@@ -79,9 +103,11 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
     constexpr int hd_p = DC * 32;
     const int lr = lane & 15, lg = lane >> 4;
 
-    const TC* q = reinterpret_cast<const TC*>(a.q) + (size_t)bh * NTOK * hd_p;
-    const TC* k = reinterpret_cast<const TC*>(a.k) + (size_t)bh * NTOK * hd_p;
-    const TC* vt = reinterpret_cast<const TC*>(a.vt) + (size_t)bh * NTOK * hd_p;
+    typedef typename WaStore<TC>::type TS;
+    static_assert(!FR || sizeof(TS) == 2, "fragment order: bf16 storage");
+    const TS* q = reinterpret_cast<const TS*>(a.q) + (size_t)bh * NTOK * hd_p;
+    const TS* k = reinterpret_cast<const TS*>(a.k) + (size_t)bh * NTOK * hd_p;
+    const TS* vt = reinterpret_cast<const TS*>(a.vt) + (size_t)bh * NTOK * hd_p;
     const f32x4* bfrag = reinterpret_cast<const f32x4*>(a.bias_frag) + ((size_t)(head * KT + qb * QT) * KT) * 64 + lane;  // [qt][kt][lane]
 
     Frag<TC> qf[QT][DC];
@@ -90,9 +116,9 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
             if constexpr (FR)
-                qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 64 + lane) * 8);
+                qf[t][c] = load_group<TC, TS>(q + (size_t)((qb * QT + t) * 64 + lane) * 8);
             else
-                qf[t][c] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
+                qf[t][c] = load_group<TC, TS>(q + (size_t)((qb * QT + t) * 16 + lr) * hd_p + c * 32 + lg * 8);
         }
 
     // shift mask (common.py:250-274): label(q) != label(k)  <=>  the row halves differ (last window row only) or the column
@@ -136,9 +162,9 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 if constexpr (FR)
-                    kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 64 + lane) * 8);
+                    kf[j][c] = load_group<TC, TS>(k + (size_t)((kb * 4 + j) * 64 + lane) * 8);
                 else
-                    kf[j][c] = *reinterpret_cast<const Frag<TC>*>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
+                    kf[j][c] = load_group<TC, TS>(k + (size_t)((kb * 4 + j) * 16 + lr) * hd_p + c * 32 + lg * 8);
             }
         }
     };
@@ -150,13 +176,13 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
         if constexpr (PF) {
 #pragma unroll
             for (int dt = 0; dt < 2 * DC; ++dt) {
-                const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
+                const TS* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if constexpr (FR)
-                        vf[dt][ks] = *reinterpret_cast<const Frag<TC>*>(vt + (size_t)(((kb * 2 + dt) * 2 + ks) * 64 + lane) * 8);
+                        vf[dt][ks] = load_group<TC, TS>(vt + (size_t)(((kb * 2 + dt) * 2 + ks) * 64 + lane) * 8);
                     else
-                        vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+                        vf[dt][ks] = load_vt<TC, TS>(vrow + ks * 32, vrow + ks * 32 + 16);
                 }
             }
             if (kb + 1 < KT / 4) fetch(kb + 1, bb[(kb + 1) & 1], kk[(kb + 1) & 1]);
@@ -223,10 +249,10 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
         // ---- O^T += V^T P^T  (32-key steps; key order inside a step as in the kernel above)
 #pragma unroll
         for (int dt = 0; dt < 2 * DC; ++dt) {
-            const TC* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
+            const TS* vrow = vt + (size_t)(dt * 16 + lr) * NTOK + lg * 4 + kb * 64;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (!PF) vf[dt][ks] = load_vt<TC>(vrow + ks * 32, vrow + ks * 32 + 16);
+                if constexpr (!PF) vf[dt][ks] = load_vt<TC, TS>(vrow + ks * 32, vrow + ks * 32 + 16);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     const Frag<TC> pf = pack_p<TC>(s[2 * ks][t], s[2 * ks + 1][t]);
@@ -236,7 +262,7 @@ SR_DEV void wattn_flash_block(const SrWindowAttn& a, const int block_id) {  // t
         }
     }
 
-    TC* out = reinterpret_cast<TC*>(a.out);
+    TS* out = reinterpret_cast<TS*>(a.out);
     const int ldo = a.heads * hd_p;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {

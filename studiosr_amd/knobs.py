@@ -21,6 +21,7 @@ KNOBS = {
     "SR_STRIPS_OVERLAP": ("1", "select", "row strips: SW-MSA halo exchange on a side stream beside the interior windows (0: serial order; same bits)"),
     # ---- HAT inference
     "SR_HAB_MID": ("1", "select", "window attention + CAB as ONE launch (sr_hab_mid); also read by the training forward"),
+    "SR_ATTN_X3": ("1", "select", "precision fp32x3: window attention on split-operand bf16 MFMAs (0: exact fp32 MFMAs; compared in tests)"),
     "SR_ATTN_LDS": ("1", "select", "window attention with K / V^T / distinct bias tiles staged in LDS (0: flash form; compared in tests)"),
     "SR_ATTN_QKV": ("auto", "tune", "attention workgroups project their own head's q / k / v (auto: up to 128 (window, head) items)"),
     "SR_OCA_LDS": ("1", "select", "overlapping cross attention with K / V^T / table in LDS (0: flash form; compared in tests)"),

@@ -168,6 +168,12 @@ def rcab_pool_tiles(H: int, W: int) -> int:
 
 
 def window_attention(**kw) -> None:
+    from .runtime import knob, x3_active
+
+    # precision "fp32x3": the flash form has a split-operand instantiation (ABI v11) -- fp32 tensors, three bf16 MFMAs per product instead of eight fp32 ones
+    if (kw.get("dtype") == L.SR_F32 and x3_active() and kw.get("bias_frag") and kw.get("hd_p") == 32 and kw.get("ntok") in (64, 256) and kw.get("ws", 0) % 4 == 0
+            and not kw.get("qkv_frag") and not kw.get("bias_tiles") and not kw.get("x") and knob("SR_ATTN_X3", "1") != "0"):
+        kw["dtype"] = L.SR_BF16X3
     a = L.SrWindowAttn()
     for k, v in kw.items():
         setattr(a, k, v)

@@ -928,6 +928,47 @@ def test_hab_mid_one_launch_equals_the_attention_and_cab_launches(frag):
         ops.hab_mid(akw, dict(x=x.data_ptr()))
 
 
+@pytest.mark.parametrize("ws,shift", [(16, 0), (16, 8), (8, 4)])
+def test_window_attention_split_operand_form_against_exact_fp32_and_torch(ws, shift):
+    """ABI v11: sr_window_attention with dtype SR_BF16X3 (precision "fp32x3", what inference() runs: fp32 q / k / v^T / out, every product hi*hi + hi*lo + lo*hi on the bf16
+    matrix cores, fp32 softmax) against the exact-fp32 instantiation of the same flash kernel and against torch in fp64 (swinir.py:83-102, hat.py:85-110 incl. the shift mask)."""
+    from oracle import functional as OF
+    from studiosr_amd.models.hat import rpi_sa
+    from studiosr_amd.runtime import x3_mode
+
+    torch.manual_seed(44)
+    B, H, W, heads, hd_p = 2, 32, 48, 6, 32
+    ntok, nb = ws * ws, B * (H // ws) * (W // ws)
+    q = torch.randn(nb, heads, ntok, hd_p, device=DEV) * 0.4
+    k = torch.randn(nb, heads, ntok, hd_p, device=DEV)
+    vt = torch.randn(nb, heads, hd_p, ntok, device=DEV)
+    for t_ in (q, k):
+        t_[..., 30:] = 0
+    table = torch.randn((2 * ws - 1) ** 2, heads, device=DEV)
+    rpi = rpi_sa(ws) if ws == 16 else S.SwinIR(depths=[2], num_heads=[6]).layers[0].residual_group.blocks[0].attn.relative_position_index
+    bias = packing.gather_bias(table, rpi, ntok, ntok)
+    bias_frag = packing.bias_fragments(bias)
+
+    def run(x3):
+        o = torch.full((nb * ntok, heads * hd_p), float("nan"), device=DEV)
+        with x3_mode(x3):
+            ops.window_attention(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), bias=bias.data_ptr(), out=o.data_ptr(), n_bwin=nb, heads=heads, hd_p=hd_p, ntok=ntok,
+                                 H=H, W=W, ws=ws, shift=shift, dtype=L.SR_F32, y_mode=L.Y_ROLL, bias_frag=bias_frag.data_ptr(), qkv_frag=0, bias_tiles=None)
+        torch.cuda.synchronize()
+        return o
+
+    new, old = run(True), run(False)
+    assert not torch.isnan(new).any()
+    scale = float(old.abs().max())
+    assert float((new - old).abs().max()) <= 2e-5 * scale, float((new - old).abs().max()) / scale
+    s64 = torch.einsum("bhqd,bhkd->bhqk", q.double(), k.double()) + bias[None].double()
+    if shift:
+        mask = OF.calculate_mask(H, W, ws, shift).to(DEV).double()
+        s64 = (s64.reshape(B, -1, heads, ntok, ntok) + mask[None, :, None]).reshape(nb, heads, ntok, ntok)
+    ref = torch.einsum("bhqk,bhdk->bqhd", torch.softmax(s64, -1), vt.double()).reshape(nb * ntok, heads * hd_p).float()
+    assert float((new - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("frag,shift,y_mode", [(0, 0, "roll"), (0, 8, "roll"), (1, 8, "roll"), (1, 4, "strip")])
 def test_window_attention_lds_form_equals_the_flash_form(frag, shift, y_mode):
     """sr_window_attention with SrWindowAttn.bias_tiles (ABI v8: K / V^T / the 31 distinct bias tiles of a head staged in LDS once per (window, head)) against the
