@@ -14,6 +14,7 @@
 // (Plain window attention keeps the register-only flash kernel of sr_attn.hip: with 256 keys it is as fast without LDS.)
 #include "sr_common.h"
 #include "sr_host.h"
+#include <type_traits>
 
 namespace {
 
@@ -63,6 +64,28 @@ SR_DEV Frag<float> vt_pair(const float* p0, const float* p1) {
     return f;
 }
 
+// Storage type of q / k / v^T / out: the split-operand form (bf3, compute type SR_BF16X3 = precision "fp32x3"; round 5, ABI v11) works on fp32 tensors -- operand fragments are
+// split into hi + lo bf16 as they are loaded, P as it is packed: three bf16 MFMAs per product instead of the eight 16x16x4 fp32 MFMAs of TC = float.
+template <typename TC>
+struct FlStore {
+    typedef TC type;
+};
+template <>
+struct FlStore<bf3> {
+    typedef float type;
+};
+template <>
+SR_DEV Frag<bf3> pack_pf<bf3>(const f32x4& a, const f32x4& b) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return frag_make<bf3>(v);
+}
+template <typename TC>
+SR_DEV Frag<TC> fl_convert(const Frag<TC>& f) { return f; }
+SR_DEV Frag<bf3> fl_split(const Frag<float>& f) {
+    const float v[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+    return frag_make<bf3>(v);
+}
+
 struct FlashArgs {
     const void *q, *k, *vt;
     const float* bias_frag;  // [heads][qt][ktp][lane][4]
@@ -77,7 +100,8 @@ struct FlashArgs {
 // keys of the (ws + 2 pad)^2 neighbourhood of a window, read in place from the zero-bordered image / planes
 template <typename TC, bool ALIGN4>
 struct OcaKeys {
-    const TC *kimg, *vplane;
+    typedef typename FlStore<TC>::type TS;
+    const TS *kimg, *vplane;
     int wse, nk, Wp2, HP, lr, lg;
     size_t plane;
     SR_DEV OcaKeys(const FlashArgs& a, int bwin, int head, int lane) {
@@ -93,22 +117,25 @@ struct OcaKeys {
         lg = lane >> 4;
         const int oy = wy * a.ws - a.pad + a.border, ox = wx * a.ws - a.pad + a.border;  // neighbourhood origin, bordered coordinates
         plane = (size_t)Hp2 * Wp2;
-        kimg = reinterpret_cast<const TC*>(a.k) + ((size_t)b * plane + (size_t)oy * Wp2 + ox) * HP + head * 32 + lg * 8;
-        vplane = reinterpret_cast<const TC*>(a.vt) + (((size_t)b * a.heads + head) * 32 + lr) * plane + (size_t)oy * Wp2 + ox;
+        kimg = reinterpret_cast<const TS*>(a.k) + ((size_t)b * plane + (size_t)oy * Wp2 + ox) * HP + head * 32 + lg * 8;
+        vplane = reinterpret_cast<const TS*>(a.vt) + (((size_t)b * a.heads + head) * 32 + lr) * plane + (size_t)oy * Wp2 + ox;
     }
     SR_DEV Frag<TC> kfrag(int kt) const {
         int key = kt * 16 + lr;
         if (key >= nk) key = nk - 1;  // padded key: any valid row (its bias column is -1e30)
         const int ky = key / wse, kx = key - ky * wse;
-        return *reinterpret_cast<const Frag<TC>*>(kimg + ((size_t)ky * Wp2 + kx) * HP);
+        return load_group<TC, TS>(kimg + ((size_t)ky * Wp2 + kx) * HP);
     }
     SR_DEV Frag<TC> vfrag(int dt, int ks) const {
         int ka = ks * 32 + lg * 4, kb = ka + 16;
         if (ka >= nk) ka = 0;  // padded keys carry p == 0; keep the address in bounds
         if (kb >= nk) kb = 0;
         const int kay = ka / wse, kax = ka - kay * wse, kby = kb / wse, kbx = kb - kby * wse;
-        const TC* base = vplane + (size_t)dt * 16 * plane;
-        return vt_pair<ALIGN4>(base + (size_t)kay * Wp2 + kax, base + (size_t)kby * Wp2 + kbx);
+        const TS* base = vplane + (size_t)dt * 16 * plane;
+        if constexpr (sizeof(Frag<TC>) == 32 && sizeof(TS) == 4 && !std::is_same<TC, float>::value)
+            return fl_split(vt_pair<ALIGN4>(base + (size_t)kay * Wp2 + kax, base + (size_t)kby * Wp2 + kbx));
+        else
+            return vt_pair<ALIGN4>(base + (size_t)kay * Wp2 + kax, base + (size_t)kby * Wp2 + kbx);
     }
 };
 
@@ -131,10 +158,11 @@ __global__ __launch_bounds__(256) void sr_attn_flash_kernel(FlashArgs a) {
     const Src src(a, bwin, head, lane);
     const int KB = a.ktp / 4;
 
-    const TC* q = reinterpret_cast<const TC*>(a.q) + ((size_t)bwin * a.heads + head) * a.ntok * 32;
+    typedef typename FlStore<TC>::type TS;
+    const TS* q = reinterpret_cast<const TS*>(a.q) + ((size_t)bwin * a.heads + head) * a.ntok * 32;
     Frag<TC> qf[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) qf[t] = *reinterpret_cast<const Frag<TC>*>(q + (size_t)((qb * QT + t) * 16 + lr) * 32 + lg * 8);
+    for (int t = 0; t < QT; ++t) qf[t] = load_group<TC, TS>(q + (size_t)((qb * QT + t) * 16 + lr) * 32 + lg * 8);
 
     // bias tile (t, j) of key block kb: [head][qb*QT + t][kb*4 + j]; this wave fetches tiles wave*QT .. wave*QT + QT - 1 of the slab
     const f32x4* bsrc = reinterpret_cast<const f32x4*>(a.bias_frag) + ((size_t)(head * qtt + qb * QT) * a.ktp) * 64 + lane;
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(256) void sr_attn_flash_kernel(FlashArgs a) {
     }
 
     if (live) {
-        TC* out = reinterpret_cast<TC*>(a.out);
+        TS* out = reinterpret_cast<TS*>(a.out);
         const int ldo = a.heads * 32;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(256) void sr_attn_flash_kernel(FlashArgs a) {
             l = wave_sum_xor(l, 32);
             const float inv = 1.0f / l;
             const int qi = (qb * QT + t) * 16 + lr;
-            TC* dst = out + ((size_t)bwin * a.ntok + qi) * ldo + head * 32 + lg * 4;
+            TS* dst = out + ((size_t)bwin * a.ntok + qi) * ldo + head * 32 + lg * 4;
             store4(dst, o[0][t] * inv);
             store4(dst + 16, o[1][t] * inv);
         }
@@ -281,6 +309,10 @@ int sr_oca_attention_flash(const SrOcaAttn& o, hipStream_t st) {
     if (o.dtype == SR_BF16) {
         if (align4) return launch<bf16, OcaKeys<bf16, true>, 4>(a, st, "sr_oca_attention");
         return launch<bf16, OcaKeys<bf16, false>, 4>(a, st, "sr_oca_attention");
+    }
+    if (o.dtype == SR_BF16X3) {  // fp32 tensors, split-operand MFMAs (ABI v11)
+        if (align4) return launch<bf3, OcaKeys<bf3, true>, 4>(a, st, "sr_oca_attention");
+        return launch<bf3, OcaKeys<bf3, false>, 4>(a, st, "sr_oca_attention");
     }
     if (align4) return launch<float, OcaKeys<float, true>, 4>(a, st, "sr_oca_attention");
     return launch<float, OcaKeys<float, false>, 4>(a, st, "sr_oca_attention");

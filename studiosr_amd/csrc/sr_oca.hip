@@ -174,6 +174,10 @@ extern "C" int sr_oca_attention(const SrOcaAttn* p, void* stream) {
     SR_REQUIRE(a.hd_p == 32 && a.ws > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.pad >= 0 && a.border >= a.pad && a.border % 4 == 0 && (a.ws + 2 * a.pad) % 4 == 0 && (a.pad % 2) == 0,
                "sr_oca_attention: bad geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.dtype == SR_BF16X3) {  // ABI v11: fp32 tensors, split-operand MFMAs -- the flash form only
+        SR_REQUIRE(sr_oca_attention_flash_supported(a), "sr_oca_attention: SR_BF16X3 needs the flash form (bias_frag, nk_frag)");
+        return sr_oca_attention_flash(a, st);
+    }
     if (sr_oca_attention_lds_supported(a)) return sr_oca_attention_lds(a, st);  // K / V^T / the bias table in LDS once per (window, head)
     if (sr_oca_attention_flash_supported(a)) return sr_oca_attention_flash(a, st);
     return a.dtype == SR_BF16 ? dispatch_oca<bf16>(a, st) : dispatch_oca<float>(a, st);

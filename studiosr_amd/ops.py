@@ -195,6 +195,12 @@ def hab_mid(attn: dict, cab: dict) -> None:
 
 
 def oca_attention(**kw) -> None:
+    from .runtime import knob, x3_active
+
+    # precision "fp32x3": split-operand instantiation of the flash form (ABI v11), as window_attention
+    if (kw.get("dtype") == L.SR_F32 and x3_active() and kw.get("bias_frag") and kw.get("nk_frag", 0) % 64 == 0 and kw.get("nk_frag", 0) > 0 and kw.get("hd_p") == 32
+            and (kw.get("ws", 0) ** 2) % 64 == 0 and knob("SR_ATTN_X3", "1") != "0"):
+        kw["dtype"] = L.SR_BF16X3
     a = L.SrOcaAttn()
     for k, v in kw.items():
         setattr(a, k, v)

@@ -1067,6 +1067,38 @@ def test_overlapping_cross_attention_lds_form_against_the_flash_form_and_torch()
     assert float((new - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+def test_overlapping_cross_attention_split_operand_form_against_exact_fp32():
+    """ABI v11: sr_oca_attention with dtype SR_BF16X3 (precision "fp32x3": fp32 q / zero-bordered k / v^T planes / out, split-operand bf16 MFMAs) against the exact-fp32
+    instantiation of the same flash kernel (hat.py:239-283; 576 keys of the 24 x 24 neighbourhood, wrapping negative bias indices)."""
+    from studiosr_amd.models.hat import rpi_oca
+    from studiosr_amd.runtime import x3_mode
+
+    torch.manual_seed(48)
+    B, H, W, heads, hd_p, ws, pad, e = 2, 32, 48, 6, 32, 16, 4, 4
+    wse, ntok, nk = ws + 2 * pad, ws * ws, (ws + 2 * pad) ** 2
+    nb = B * (H // ws) * (W // ws)
+    q = torch.randn(nb, heads, ntok, hd_p, device=DEV) * 0.4
+    kimg = torch.zeros(B, H + 2 * e, W + 2 * e, heads, hd_p, device=DEV)
+    kimg[:, e:-e, e:-e] = torch.randn(B, H, W, heads, hd_p, device=DEV)
+    vpl = torch.zeros(B, heads, hd_p, H + 2 * e, W + 2 * e, device=DEV)
+    vpl[..., e:-e, e:-e] = torch.randn(B, heads, hd_p, H, W, device=DEV)
+    table = torch.randn((ws + wse - 1) ** 2, heads, device=DEV)
+    bias = packing.gather_bias(table, rpi_oca(ws, 0.5), ntok, nk)
+    bias_frag = packing.bias_fragments(bias)
+
+    def run(x3):
+        o = torch.full((nb * ntok, heads * hd_p), float("nan"), device=DEV)
+        with x3_mode(x3):
+            ops.oca_attention(q=q.data_ptr(), k=kimg.data_ptr(), vt=vpl.data_ptr(), bias=bias.data_ptr(), out=o.data_ptr(), B=B, H=H, W=W, heads=heads, hd_p=hd_p, ws=ws,
+                              pad=pad, border=e, nk_pad=nk, dtype=L.SR_F32, bias_frag=bias_frag.data_ptr(), nk_frag=nk, bias_rel=None)
+        torch.cuda.synchronize()
+        return o
+
+    new, old = run(True), run(False)
+    assert not torch.isnan(new).any()
+    assert float((new - old).abs().max()) <= 2e-5 * float(old.abs().max()), float((new - old).abs().max()) / float(old.abs().max())
+
+
 def test_hat_graph_replay_with_half_batches_equals_the_eager_forward():
     """Inside a HIP-graph capture a HAT batch of >= 8 runs as two half batches on two streams (models/hat.py forward, SR_HAT_PARTS): same kernels on the same
     per-image data, so the replayed output is bit-identical to the eager one-sequence forward, image by image."""
