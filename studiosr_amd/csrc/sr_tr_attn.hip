@@ -38,6 +38,9 @@ struct Geo {
     int nwx, nwy, win_per_img;
 };
 
+#ifndef SR_OCAQ_ATOMIC_FOLD
+#define SR_OCAQ_ATOMIC_FOLD 0  // 1: the overlapping cross attention's table fold as 144 index-map LDS atomics per wave (before round 5: +40 us per launch)
+#endif
 // ---- pass Q.  KT = key tiles; Nq = 16 * QT_ALL query rows per (window, head)
 // LDSK (round 4, the 576-key neighbourhoods of the overlapping cross attention): the four waves of a workgroup work on the same (head, window) at the same
 // time, so K and V (as operand fragments) and K^T (in the accumulator-as-operand key order) of the window are staged in LDS once per window walk step
@@ -251,6 +254,52 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
                 if (lr >= 1) atomicAdd(&tab[row + lr - 16], neg);
             }
         }
+    } else if constexpr (LDSK && !SR_OCAQ_ATOMIC_FOLD) {
+        // Overlapping cross attention (hat.py:494-517): table entry j = (ky - qy + 15) * 39 + (kx - qx + 15) with (ky, kx) the key's position in the 24 x 24 neighbourhood;
+        // row j - 880, negative rows wrap.  The index-map fold below is 144 ds_add_f32 per wave with up to four lanes per address -- LDS float atomics run lane by lane:
+        // 40 us of this 145-us launch (a build without them).  Here, as for the 16 x 16 self-attention windows above: rotating the sixteen query columns by the key's
+        // column inside the tile puts (kx - qx) on the lane column (no wrap: kx0 - lr, wrapped: + 16), the sums over r and the lane groups follow, and 16 lanes add two
+        // DISTINCT entries per tile.  A tile is 16 consecutive keys of a 24-key row: tiles with kt % 3 == 1 straddle two rows (lane groups 0, 1 | 2, 3).
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            float pos = 0.f, neg = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * lg + r;
+                const float w = __shfl(dbacc[kt][r], (lane & 48) | ((lr + c) & 15), 64);
+                const bool p = lr + c <= 15;
+                pos += p ? w : 0.f;
+                neg += p ? 0.f : w;
+            }
+            pos = wave_sum_xor(pos, 16);
+            neg = wave_sum_xor(neg, 16);
+            const int ky = (16 * kt) / 24;
+            int kyr, kx0;
+            bool writer;
+            if (kt % 3 == 1) {  // keys 16 .. 23 of row ky (lane groups 0, 1) | keys 0 .. 7 of row ky + 1 (lane groups 2, 3)
+                kyr = lg < 2 ? ky : ky + 1;
+                kx0 = lg < 2 ? 16 : -8;
+                writer = (lg & 1) == 0;
+            } else {
+                pos = wave_sum_xor(pos, 32);
+                neg = wave_sum_xor(neg, 32);
+                kyr = ky;
+                kx0 = kt % 3 == 0 ? 0 : 8;
+                writer = lg == 0;
+            }
+            if (writer) {
+                const int dxp = kx0 - lr, dxn = dxp + 16;  // kx - qx of the two sums
+                const int row = (kyr - qt + 15) * 39 + 15 - 880;
+                if (dxp >= -15 && dxp <= 23) {
+                    const int t = row + dxp;
+                    atomicAdd(&tab[t < 0 ? t + a.T : t], pos);
+                }
+                if (dxn >= -15 && dxn <= 23) {
+                    const int t = row + dxn;
+                    atomicAdd(&tab[t < 0 ? t + a.T : t], neg);
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -271,8 +320,12 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
                         for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
                     }
             } else {
+#ifndef SR_Q_NOFOLD
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(&tab[tt[r] < 0 ? tt[r] + a.T : tt[r]], dbacc[kt][r]);
+#else
+                if (tt[0] == -123456) tab[0] = dbacc[kt][0] + dbacc[kt][1] + dbacc[kt][2] + dbacc[kt][3];
+#endif
             }
         }
     }
