@@ -514,6 +514,7 @@ int sr_tr_finalize(const float* arena, const long long* src, const int* stride, 
 /* (ABI v9) the same sums with the items in arena order: grad[dst[i]] = scale[i] * sum_{s < ns[i]} arena[src[i] + s * stride[i]] (the host sorts the items by src: coalesced
  * partial reads whatever the parameter order is; ns[i] = 0 writes a zero) */
 int sr_tr_finalize_to(const float* arena, const long long* src, const int* dst, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream);
+int sr_tr_finalize_to8(const float* arena, const long long* src, const int* dst, const int* stride, const int* ns, const float* scale, float* grad, long long n, void* stream); /* ABI v11: eight lanes per item (SrTrFinalize.lanes) */
 
 typedef struct SrTrWgradJob {
     /* dW[slice][tap][n][k] = sum over the slice's tokens t of A[t][n] * B[t'][k]: the weight gradient of nn.Linear (taps 1, t' = t;
@@ -660,7 +661,10 @@ typedef struct SrTrGelu { const void* x; const void* dg; void* g; void* dx; long
 int sr_tr_gelu_args(const SrTrGelu* a, void* stream);
 typedef struct SrTrAdd { const float* a; const void* b; float* out; long long n; int b_dtype; } SrTrAdd;
 int sr_tr_add_args(const SrTrAdd* a, void* stream);
-typedef struct SrTrFinalize { const float* arena; const long long* src; const int* dst; const int* stride; const int* ns; const float* scale; float* grad; long long n; } SrTrFinalize;
+typedef struct SrTrFinalize { const float* arena; const long long* src; const int* dst; const int* stride; const int* ns; const float* scale; float* grad; long long n;
+                              int lanes;  /* ABI v11: 0 / 1 = one thread per item; 8 = eight adjacent lanes share an item (slices j, j + 8, ...; their sums meet in a fixed xor tree): items
+                                           * with MANY slices -- LayerNorm / bias-table partials, one per workgroup: 256 of them are 64 dependent rounds for one thread */
+                            } SrTrFinalize;
 int sr_tr_finalize_to_args(const SrTrFinalize* a, void* stream);
 typedef struct SrTrUnshuffle { const void* src; void* dst; int B, H, W, cps, r; } SrTrUnshuffle;
 int sr_tr_unshuffle_args(const SrTrUnshuffle* a, void* stream);

@@ -235,7 +235,7 @@ class SrTrAdd(C.Structure):
 
 
 class SrTrFinalize(C.Structure):
-    _fields_ = [("arena", _vp), ("src", _vp), ("dst", _vp), ("stride", _vp), ("ns", _vp), ("scale", _vp), ("grad", _vp), ("n", _ll)]
+    _fields_ = [("arena", _vp), ("src", _vp), ("dst", _vp), ("stride", _vp), ("ns", _vp), ("scale", _vp), ("grad", _vp), ("n", _ll), ("lanes", _i)]
 
 
 class SrTrUnshuffle(C.Structure):
@@ -320,6 +320,7 @@ SYMBOLS = {
     "sr_tr_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "sr_tr_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sr_tr_finalize_to": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "sr_tr_finalize_to8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sr_tr_wgrad": (_i, [C.POINTER(SrTrWgradJob), _i, _vp]),
     "sr_tr_wgrad_out_floats": (_ll, [C.POINTER(SrTrWgradJob)]),
     "sr_tr_attn_bwd": (_i, [C.POINTER(SrTrAttnBwd), _vp]),

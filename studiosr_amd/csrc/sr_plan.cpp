@@ -107,6 +107,8 @@ extern "C" int sr_tr_add_args(const SrTrAdd* a, void* stream) {
 }
 extern "C" int sr_tr_finalize_to_args(const SrTrFinalize* a, void* stream) {
     SR_REQUIRE(a, "sr_tr_finalize_to_args: null pointer");
+    SR_REQUIRE(a->lanes == 0 || a->lanes == 1 || a->lanes == 8, "sr_tr_finalize_to_args: lanes must be 0, 1 or 8");
+    if (a->lanes == 8) return sr_tr_finalize_to8(a->arena, a->src, a->dst, a->stride, a->ns, a->scale, a->grad, a->n, stream);
     return sr_tr_finalize_to(a->arena, a->src, a->dst, a->stride, a->ns, a->scale, a->grad, a->n, stream);
 }
 extern "C" int sr_tr_unshuffle_args(const SrTrUnshuffle* a, void* stream) {

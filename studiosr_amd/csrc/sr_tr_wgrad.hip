@@ -87,6 +87,35 @@ __global__ __launch_bounds__(256) void sr_tr_finalize_to_kernel(const float* __r
     grad[dst[i]] = acc * scale[i];
 }
 
+// Items with many slices (LayerNorm gamma / beta and bias-table partials: one per workgroup of the producing launch, 64 - 256 of them): eight adjacent lanes share an
+// item -- lane j adds slices j, j + 8, ... (four in flight), then a fixed xor tree -- instead of one thread walking 256 dependent strided loads while the rest of
+// the launch has long finished (the finalize launches were 95 us of which the four-slices-in-flight loop over 256 partials is ~64 rounds of L2 latency).
+__global__ __launch_bounds__(256) void sr_tr_finalize_to8_kernel(const float* __restrict__ arena, const long long* __restrict__ src, const int* __restrict__ dst,
+                                                                const int* __restrict__ stride, const int* __restrict__ ns, const float* __restrict__ scale,
+                                                                float* __restrict__ grad, long long n) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = gid >> 3;
+    const int sub = (int)(gid & 7);
+    const bool live = i < n;
+    const long long ii = live ? i : n - 1;  // (whole waves take part in the shuffles)
+    const int st = stride[ii], cnt = live ? ns[ii] : 0;
+    const float* p = arena + src[ii];
+    float acc = 0.0f;
+    int s = sub;
+    for (; s + 24 < cnt; s += 32) {
+        const float v0 = p[(long long)s * st], v1 = p[(long long)(s + 8) * st], v2 = p[(long long)(s + 16) * st], v3 = p[(long long)(s + 24) * st];
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+    }
+    for (; s < cnt; s += 8) acc += p[(long long)s * st];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (live && sub == 0) grad[dst[i]] = acc * scale[i];
+}
+
 // ----------------------------------------------------------------------------- wgrad
 constexpr int WG_TN = 64, WG_TK = 64, WG_STEP = 32;
 constexpr int WG_LD = 160;                       // bytes per LDS tile row (64 bf16 + 32 B): see the header comment
@@ -612,6 +641,15 @@ extern "C" int sr_tr_finalize_to(const float* arena, const long long* src, const
     if (n == 0) return SR_OK;
     hipLaunchKernelGGL(sr_tr_finalize_to_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), arena, src, dst, stride, ns, scale, grad, n);
     SR_CHECK_LAUNCH("sr_tr_finalize_to");
+    return SR_OK;
+}
+
+extern "C" int sr_tr_finalize_to8(const float* arena, const long long* src, const int* dst, const int* stride, const int* ns, const float* scale, float* grad, long long n,
+                                  void* stream) {
+    SR_REQUIRE(arena && src && dst && stride && ns && scale && grad && n >= 0, "sr_tr_finalize_to8: bad arguments");
+    if (n == 0) return SR_OK;
+    hipLaunchKernelGGL(sr_tr_finalize_to8_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), arena, src, dst, stride, ns, scale, grad, n);
+    SR_CHECK_LAUNCH("sr_tr_finalize_to8");
     return SR_OK;
 }
 

@@ -38,6 +38,7 @@ C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
 CONV_WG_SIDE = os.environ.get("SR_TR_CONV_WG_SIDE", "1") != "0"  # A/B knob: the CAB convs' weight-gradient launch on the backward's side stream
+FINALIZE_LONG = int(os.environ.get("SR_TR_FINALIZE_LONG", "64"))  # tuning knob: items with at least this many slices are finalized by eight lanes each (0: never)
 BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
 _SIDE = {}
 
@@ -294,17 +295,23 @@ class FinalMap:
         src, ns = self.src[idx].copy(), self.ns[idx].copy()
         ns[src < 0] = 0
         src[src < 0] = 0
+        # Items with many slices (LayerNorm / bias-table partials: one per workgroup of the producing launch) go to a launch of their own where eight lanes share an
+        # item (SrTrFinalize.lanes, ABI v11): one thread per item would walk up to 256 dependent strided loads long after the rest of the launch has finished.
+        stride, scale = self.stride[idx].copy(), self.scale[idx].copy()
+        long_ = ns >= FINALIZE_LONG if FINALIZE_LONG > 0 else np.zeros(ns.shape, dtype=bool)
+        self.sets = []
+        for sel, lanes in ((~long_, 1), (long_, 8)):
+            if not sel.any():
+                continue
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sel])).to(device)  # noqa: E731
+            self.sets.append((int(sel.sum()), lanes, t(src), t(idx.astype(np.int32)), t(stride), t(ns), t(scale)))
         self.n_items = int(idx.size)
-        self.d_src = torch.from_numpy(src).to(device)
-        self.d_dst = torch.from_numpy(idx.astype(np.int32)).to(device)
-        self.d_stride = torch.from_numpy(self.stride[idx].copy()).to(device)
-        self.d_ns = torch.from_numpy(ns).to(device)
-        self.d_scale = torch.from_numpy(self.scale[idx].copy()).to(device)
         self.part = torch.zeros(max(self.size, 64), dtype=torch.float32, device=device)
 
     def run(self, G: Tensor) -> None:
-        _call(L.lib().sr_tr_finalize_to_args, L.SrTrFinalize, "sr_tr_finalize_to", arena=self.part.data_ptr(), src=self.d_src.data_ptr(), dst=self.d_dst.data_ptr(),
-              stride=self.d_stride.data_ptr(), ns=self.d_ns.data_ptr(), scale=self.d_scale.data_ptr(), grad=G.data_ptr() + 4 * self.p0, n=self.n_items)
+        for n, lanes, src, dst, stride, ns, scale in self.sets:
+            _call(L.lib().sr_tr_finalize_to_args, L.SrTrFinalize, "sr_tr_finalize_to", arena=self.part.data_ptr(), src=src.data_ptr(), dst=dst.data_ptr(),
+                  stride=stride.data_ptr(), ns=ns.data_ptr(), scale=scale.data_ptr(), grad=G.data_ptr() + 4 * self.p0, n=n, lanes=lanes)
 
 
 # --------------------------------------------------------------------------- index-form packers (cf. studiosr_amd/packing.py)

@@ -55,6 +55,7 @@ KNOBS = {
     "SR_TR_MIDPRE": ("1", "select", "the CAB's conv1 pre-activation kept by the forward (0: recomputed in the backward)"),
     "SR_TR_GROUPS": ("10", "tune", "window groups of the OCAB's pass Q (default 256 // (6 heads x 4))"),
     "SR_WG_WIDE": ("1", "select", "library: nn.Linear weight gradients on 192 x 96 tiles (sr_tr_wgrad_wide_kernel; 0: the 64 x 64 tiles; both tested against torch)"),
+    "SR_TR_FINALIZE_LONG": ("64", "tune", "gradient partial sums with at least this many slices are reduced by eight lanes per element (0: one thread per element)"),
     "SR_WG_KS": ("16", "tune", "token slices of the weight-gradient GEMMs"),
     "SR_WG_HALO": ("1", "select", "3x3 weight gradients on 2-D patches with one staged halo for all nine taps"),
     "SR_WG_HALO_STEPS": ("16", "tune", "patches per slice of the halo form"),

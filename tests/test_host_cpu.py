@@ -380,6 +380,8 @@ def test_finalize_items_in_arena_order_are_the_same_sums():
     fm.put(pidx, a + (np.arange(180) % 9) * 20 + np.arange(180) // 9, 180, 3, scale=0.5)
     b = fm.alloc(100 * 4)     # a "linear" job: 4 slices of 100
     fm.put(40 + 200 + np.arange(100), b + np.arange(100), 100, 4)
+    c = fm.alloc(7 * 64)      # "LayerNorm partials": 64 slices (one per workgroup) of 7 -- items of the eight-lanes-per-element launch
+    fm.put(40 + 300 + np.arange(7), c + np.arange(7), 7, 64)
     fm.src[350:360] = -2      # another map's elements
     fm.finish("cpu")
     part = rng.standard_normal(fm.size).astype(np.float32)
@@ -393,14 +395,32 @@ def test_finalize_items_in_arena_order_are_the_same_sums():
                 acc = np.float32(acc + part[fm.src[p] + s * fm.stride[p]])
         want[p] = acc * fm.scale[p]
     got = np.full(n, np.nan, dtype=np.float32)
-    src, dst, st, ns, sc = (t.numpy() for t in (fm.d_src, fm.d_dst, fm.d_stride, fm.d_ns, fm.d_scale))
-    assert fm.n_items == n - 10 and np.all(np.diff(src) >= 0) and len(set(dst.tolist())) == fm.n_items
-    for i in range(fm.n_items):
-        acc = np.float32(0)
-        for s in range(ns[i]):
-            acc = np.float32(acc + part[src[i] + s * st[i]])
-        got[dst[i]] = acc * sc[i]
-    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    seen = []
+    assert sorted(lanes for _, lanes, *_ in fm.sets) == [1, 8] and sum(cnt for cnt, *_ in fm.sets) == fm.n_items == n - 10
+    for cnt, lanes, *arrs in fm.sets:
+        src, dst, st, ns, sc = (t.numpy() for t in arrs)
+        assert len(src) == cnt and np.all(np.diff(src) >= 0)
+        assert np.all(ns >= 64) if lanes == 8 else np.all(ns < 64)
+        seen += dst.tolist()
+        for i in range(cnt):
+            if lanes == 8:  # lane j adds slices j, j + 8, ...; the eight sums meet in an xor tree (1, 2, 4)
+                lane = [np.float32(0)] * 8
+                for s in range(ns[i]):
+                    lane[s % 8] = np.float32(lane[s % 8] + part[src[i] + s * st[i]])
+                for m in (1, 2, 4):
+                    lane = [np.float32(lane[j] + lane[j ^ m]) for j in range(8)]
+                acc = lane[0]
+            else:
+                acc = np.float32(0)
+                for s in range(ns[i]):
+                    acc = np.float32(acc + part[src[i] + s * st[i]])
+            got[dst[i]] = acc * sc[i]
+    assert len(set(seen)) == fm.n_items
+    long_p = 300 + np.arange(7)  # (indices relative to p0)
+    short = np.ones(n, dtype=bool)
+    short[long_p] = False
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[short & ~np.isnan(got)], want[short & ~np.isnan(want)])
+    np.testing.assert_allclose(got[long_p], want[long_p], rtol=1e-5)  # (another summation order)
     assert np.all(got[180:200] == 0) and np.isnan(got[350:360]).all()
 
 
