@@ -439,6 +439,144 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
 }
 
 
+// ---- pass KV of the overlapping cross attention (256 queries x 576 keys per (window, head), SrTrAttnBwd.oca_rel) with the QUERY side in LDS (round 5).  The generic pass above is
+// one wave per (window, head, two key tiles): every wave pulls the window's q / dO / q^T / dO^T fragments (64 KB) and its bias rows from L2 -- 660 MB per launch, 120 us at the
+// ~5.5 TB/s the L2 -> CU path gives the other latency-chain kernels too.  Here a workgroup owns a (window, head): the four query-side arrays are staged once in fragment order
+// (64 KB), the head's relative-position table (39 x 39, recovered from the gathered bias as in pass Q) and lse / delta sit beside them (72 KB: two workgroups per CU), and each
+// wave walks three groups of three key tiles.  Same products and the same summation order per output as the generic pass.
+constexpr int KVO_QT = 16, KVO_KT = 36, KVO_KPW = 3;
+constexpr int KVO_LDS = 4 * KVO_QT * 1024 + 6144 + 2 * 256 * 4;
+__global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_oca_kernel(SrTrAttnBwd a) {
+    constexpr int QT = KVO_QT, NQ = QT * 16, NK = KVO_KT * 16, KPW = KVO_KPW;
+    extern __shared__ __attribute__((aligned(16))) char smem_kv[];
+    const Frag<bf16>* QL = reinterpret_cast<const Frag<bf16>*>(smem_kv);  // [q tile][lane]: row 16 qt + lr, features 8 lg ..
+    const Frag<bf16>* DOL = QL + QT * 64;                                 // dO likewise
+    const Frag<bf16>* QTL = DOL + QT * 64;                                // [d tile][32-query step][lane]: feature row 16 dt + lr, queries 32 qs + 4 lg .. | + 16
+    const Frag<bf16>* DOTL = QTL + QT * 64;
+    float* REL = reinterpret_cast<float*>(smem_kv + 4 * QT * 1024);       // the head's table [39 * 39]
+    float* LSE = REL + 1536;
+    float* DEL = LSE + NQ;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const size_t bh = blockIdx.x;
+    const int head = (int)(bh % a.heads), bwin = (int)(bh / a.heads);
+    const bf16* q = reinterpret_cast<const bf16*>(a.q) + bh * NQ * 32;
+    const bf16* qT = reinterpret_cast<const bf16*>(a.qT) + bh * NQ * 32;
+    const bf16* dOT = reinterpret_cast<const bf16*>(a.dOT) + bh * NQ * 32;
+    // ---- staging (once per workgroup)
+    {
+        constexpr int PER = QT * 64 / 256;  // 16-byte pieces per array and thread
+        Frag<bf16> r[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) r[i] = *reinterpret_cast<const Frag<bf16>*>(q + (size_t)(i * 256 + threadIdx.x) * 8);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 256 + threadIdx.x, tok = c >> 2, g = c & 3;
+            *reinterpret_cast<Frag<bf16>*>(smem_kv + ((tok >> 4) * 64 + g * 16 + (tok & 15)) * 16) = r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 256 + threadIdx.x, tok = c >> 2, g = c & 3;
+            r[i] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + ((size_t)bwin * NQ + tok) * a.ldo + head * 32 + g * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * 256 + threadIdx.x, tok = c >> 2, g = c & 3;
+            *reinterpret_cast<Frag<bf16>*>(smem_kv + (QT * 64 + (tok >> 4) * 64 + g * 16 + (tok & 15)) * 16) = r[i];
+        }
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+            const bf16* srcT = arr == 0 ? qT : dOT;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) r[i] = *reinterpret_cast<const Frag<bf16>*>(srcT + (size_t)(i * 256 + threadIdx.x) * 8);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = i * 256 + threadIdx.x;
+                const int d = c / (NQ / 8), k0 = (c - d * (NQ / 8)) * 8;  // queries k0 .. k0 + 7 of feature row d: two groups of 4
+                const int stp = k0 >> 5, e_hi = (k0 >> 4) & 1, g0 = (k0 >> 2) & 3;
+                char* cell = smem_kv + ((2 + arr) * QT * 64 + ((d >> 4) * (QT / 2) + stp) * 64 + g0 * 16 + (d & 15)) * 16 + e_hi * 8;
+                const bf16x8 v8 = r[i].v;
+                *reinterpret_cast<bf16x4*>(cell) = __builtin_shufflevector(v8, v8, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(cell + 16 * 16) = __builtin_shufflevector(v8, v8, 4, 5, 6, 7);
+            }
+        }
+        const float* bh_ = a.bias + (size_t)head * NQ * NK;
+        for (int j = threadIdx.x; j < 39 * 39; j += 256) {  // any (q, k) pair with the row / column differences of entry j (as pass Q)
+            const int dyp = j / 39, dxp = j - dyp * 39;
+            const int qy = dyp >= 15 ? 0 : 15 - dyp, ky = dyp >= 15 ? dyp - 15 : 0, qx = dxp >= 15 ? 0 : 15 - dxp, kx = dxp >= 15 ? dxp - 15 : 0;
+            REL[j] = bh_[(size_t)(qy * 16 + qx) * NK + ky * 24 + kx];
+        }
+        LSE[threadIdx.x] = a.lse[bh * NQ + threadIdx.x];
+        DEL[threadIdx.x] = a.delta[bh * NQ + threadIdx.x];
+    }
+    __syncthreads();
+
+    for (int kg = wave; kg < KVO_KT / KPW; kg += 4) {
+        Frag<bf16> kf[KPW], vf[KPW];
+        int jbase[KPW];
+        f32x4 dk[KPW][2], dv[KPW][2];
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            const int ki = (kg * KPW + u) * 16 + lr;
+            kf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.k) + (bh * NK + ki) * 32 + lg * 8);
+            vf[u] = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.v) + (bh * NK + ki) * 32 + lg * 8);
+            const int ky = ki / 24, kx = ki - ky * 24;
+            jbase[u] = (ky + 15) * 39 + kx - 4 * lg + 15;  // entry of (query row 0, query column 4 lg): query row qt subtracts 39 qt, register r subtracts r
+            dk[u][0] = dk[u][1] = dv[u][0] = dv[u][1] = (f32x4)(0.0f);
+        }
+#pragma unroll 2
+        for (int qs = 0; qs < QT / 2; ++qs) {
+            f32x4 p[KPW][2], ds[KPW][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qt = 2 * qs + h;
+                const Frag<bf16> qf = QL[qt * 64 + lane], dof = DOL[qt * 64 + lane];
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(LSE + qt * 16 + lg * 4), d4 = *reinterpret_cast<const f32x4*>(DEL + qt * 16 + lg * 4);
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) {
+                    const float* tr = REL + jbase[u] - 39 * qt;
+                    f32x4 b4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b4[r] = tr[-r];
+                    const f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf.v, kf[u].v, b4, 0, 0, 0);  // S[query 16 qt + 4 lg + r][key lr] + bias
+                    const f32x4 dp = mma_z(dof, vf[u]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p[u][h][r] = __expf(sv[r] - l4[r]);
+                        ds[u][h][r] = p[u][h][r] * (dp[r] - d4[r]);
+                    }
+                }
+            }
+            Frag<bf16> dotf[2], qtf[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dotf[dt] = DOTL[(dt * (QT / 2) + qs) * 64 + lane];
+                qtf[dt] = QTL[(dt * (QT / 2) + qs) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < KPW; ++u) {
+                const Frag<bf16> pf = pack_p(p[u][0], p[u][1]), dsf = pack_p(ds[u][0], ds[u][1]);  // row = key lr, k = queries 32 qs + 4 lg + r | + 16
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    mma(dotf[dt], pf, dv[u][dt]);  // C[d = 16 dt + 4 lg + r][key lr]
+                    mma(qtf[dt], dsf, dk[u][dt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            const int ki = (kg * KPW + u) * 16 + lr;
+            bf16* dkp = reinterpret_cast<bf16*>(a.dk) + (bh * NK + ki) * 32 + lg * 4;
+            bf16* dvp = reinterpret_cast<bf16*>(a.dv) + (bh * NK + ki) * 32 + lg * 4;
+            store4(dkp, dk[u][0]);
+            store4(dkp + 16, dk[u][1]);
+            store4(dvp, dv[u][0]);
+            store4(dvp + 16, dv[u][1]);
+        }
+    }
+}
+
 // ---- 8 x 8 windows (SwinIR, swinir.py:83-102), ONE pass: a wave owns a whole (window, head) -- 64 queries x 64 keys = sixteen logit tiles in 64 registers -- so nothing
 // travels between passes (no lse / delta round trip) and every operand is fetched once, in two rounds issued up front (the two register passes above, written for
 // 256 / 576 keys, leave a 64-key window as a chain of ~7 dependent L2 round trips: 35 + 17 us per SwinIR block at 4 x 64 x 64).  Orientation 1 (keys on registers,
@@ -905,6 +1043,15 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
 #ifndef SR_KV_KPW
 #define SR_KV_KPW 2
 #endif
+    static const bool kv_lds = !(getenv("SR_TR_OCA_KV_LDS") && atoi(getenv("SR_TR_OCA_KV_LDS")) == 0);  // A/B knob
+    if (kv_lds && a.Nk == 576 && a.Nq == 256 && a.oca_rel && a.T == 39 * 39 && a.shift == 0) {
+        static SrDeviceOnce once_kv;
+        const hipError_t e = sr_once_per_device(once_kv, [&] { return sr_allow_lds(sr_tr_attn_bwd_kv_oca_kernel, KVO_LDS); });
+        SR_REQUIRE(e == hipSuccess, "sr_tr_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(sr_tr_attn_bwd_kv_oca_kernel, dim3(a.n_bwin * a.heads), dim3(256), KVO_LDS, st, b);
+        SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv, query side in LDS)");
+        return SR_OK;
+    }
     hipLaunchKernelGGL((sr_tr_attn_bwd_kv_kernel<16, SR_KV_KPW>), dim3((a.n_bwin * a.heads * (a.Nk / 16 / SR_KV_KPW) + 3) / 4), dim3(256), 0, st, b);
     SR_CHECK_LAUNCH("sr_tr_attn_bwd (kv)");
     return SR_OK;

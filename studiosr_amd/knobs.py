@@ -51,6 +51,7 @@ KNOBS = {
     "SR_TR_CONV_WG_SIDE": ("1", "select", "the CAB convs' weight-gradient launch on the backward's side stream beside sr_tr_qkv_bwd and the nn.Linear weight gradients"),
     "SR_TR_BWD_DUAL": ("1", "select", "CAB branch of a HAB's backward on a side stream"),
     "SR_TR_ATTN_LDS": ("1", "select", "window-attention backward as one LDS-form launch (0: two register passes; both tested against torch)"),
+    "SR_TR_OCA_KV_LDS": ("1", "select", "library: OCAB pass KV with the query side and the bias table in LDS (0: the generic register pass; compared by the fused tests)"),
     "SR_TR_OCA_LDS": ("1", "select", "OCAB pass Q in LDS form"),
     "SR_TR_MIDPRE": ("1", "select", "the CAB's conv1 pre-activation kept by the forward (0: recomputed in the backward)"),
     "SR_TR_GROUPS": ("10", "tune", "window groups of the OCAB's pass Q (default 256 // (6 heads x 4))"),
