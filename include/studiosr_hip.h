@@ -552,6 +552,8 @@ typedef struct SrTrAttnBwd {
     int oca_rel;           /* 1 (ABI v8; Nk = 576): bias[q][k] is a function of (ky - qy, kx - qx) only and rpi the overlapping-cross-attention index
                             * (ky - qy - 7) * 39 + (kx - qx - 7) with wrapping negatives (hat.py:494-517): pass Q then keeps the head's table in LDS beside the window's
                             * K / V / K^T fragments and folds the gradient through the index arithmetic instead of reading bias rows and rpi from memory */
+    int lse_given;         /* 1 (ABI v11; with oca_rel): lse holds the FORWARD's log-sum-exp (SrTrAttnFwd.lse) and is only read: pass Q then forms P = exp(S - lse) tile by tile
+                            * (two workgroups per CU instead of one wave per SIMD) and still writes delta */
 } SrTrAttnBwd;
 int sr_tr_attn_bwd(const SrTrAttnBwd* a, void* stream);
 

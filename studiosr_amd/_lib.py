@@ -166,7 +166,7 @@ class SrTrAttnBwd(C.Structure):
         ("q", _vp), ("qT", _vp), ("k", _vp), ("kT", _vp), ("v", _vp), ("o", _vp), ("dO", _vp), ("dOT", _vp), ("bias", _vp), ("biasT", _vp),
         ("dq", _vp), ("dk", _vp), ("dv", _vp), ("lse", _vp), ("delta", _vp), ("dtab_part", _vp), ("rpi", _vp),
         ("n_bwin", _i), ("heads", _i), ("hd_p", _i), ("Nq", _i), ("Nk", _i), ("ldo", _i), ("groups", _i), ("T", _i), ("Tpad", _i), ("toeplitz16", _i), ("H", _i), ("W", _i), ("ws", _i), ("shift", _i),
-        ("oca_rel", _i),
+        ("oca_rel", _i), ("lse_given", _i),
     ]
 
 

@@ -38,6 +38,59 @@ struct Geo {
     int nwx, nwy, win_per_img;
 };
 
+// Bias-table gradient of the overlapping cross attention (hat.py:494-517), folded from the S^T-layout accumulators dbacc[kt] (key 16 kt + 4 lg + r, query 16 qt + lr) of one wave
+// into the workgroup's LDS table `tab`:
+// Overlapping cross attention (hat.py:494-517): table entry j = (ky - qy + 15) * 39 + (kx - qx + 15) with (ky, kx) the key's position in the 24 x 24 neighbourhood;
+// row j - 880, negative rows wrap.  The index-map fold below is 144 ds_add_f32 per wave with up to four lanes per address -- LDS float atomics run lane by lane:
+// 40 us of this 145-us launch (a build without them).  Here, as for the 16 x 16 self-attention windows above: rotating the sixteen query columns by the key's
+// column inside the tile puts (kx - qx) on the lane column (no wrap: kx0 - lr, wrapped: + 16), the sums over r and the lane groups follow, and 16 lanes add two
+// DISTINCT entries per tile.  A tile is 16 consecutive keys of a 24-key row: tiles with kt % 3 == 1 straddle two rows (lane groups 0, 1 | 2, 3).
+template <int KT, int KT0 = 0>  // dbacc[i] = key tile KT0 + i
+SR_DEV void oca_table_fold(const f32x4 (&dbacc)[KT], float* tab, const int qt, const int lane, const int T) {
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int kti = 0; kti < KT; ++kti) {
+        const int kt = KT0 + kti;
+        float pos = 0.f, neg = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * lg + r;
+            const float w = __shfl(dbacc[kti][r], (lane & 48) | ((lr + c) & 15), 64);
+            const bool p = lr + c <= 15;
+            pos += p ? w : 0.f;
+            neg += p ? 0.f : w;
+        }
+        pos = wave_sum_xor(pos, 16);
+        neg = wave_sum_xor(neg, 16);
+        const int ky = (16 * kt) / 24;
+        int kyr, kx0;
+        bool writer;
+        if (kt % 3 == 1) {  // keys 16 .. 23 of row ky (lane groups 0, 1) | keys 0 .. 7 of row ky + 1 (lane groups 2, 3)
+            kyr = lg < 2 ? ky : ky + 1;
+            kx0 = lg < 2 ? 16 : -8;
+            writer = (lg & 1) == 0;
+        } else {
+            pos = wave_sum_xor(pos, 32);
+            neg = wave_sum_xor(neg, 32);
+            kyr = ky;
+            kx0 = kt % 3 == 0 ? 0 : 8;
+            writer = lg == 0;
+        }
+        if (writer) {
+            const int dxp = kx0 - lr, dxn = dxp + 16;  // kx - qx of the two sums
+            const int row = (kyr - qt + 15) * 39 + 15 - 880;
+            if (dxp >= -15 && dxp <= 23) {
+                const int t = row + dxp;
+                atomicAdd(&tab[t < 0 ? t + T : t], pos);
+            }
+            if (dxn >= -15 && dxn <= 23) {
+                const int t = row + dxn;
+                atomicAdd(&tab[t < 0 ? t + T : t], neg);
+            }
+        }
+    }
+}
+
 #ifndef SR_OCAQ_ATOMIC_FOLD
 #define SR_OCAQ_ATOMIC_FOLD 0  // 1: the overlapping cross attention's table fold as 144 index-map LDS atomics per wave (before round 5: +40 us per launch)
 #endif
@@ -255,51 +308,7 @@ __global__ __launch_bounds__(256, KT > 16 ? 1 : 2) void sr_tr_attn_bwd_q_kernel(
             }
         }
     } else if constexpr (LDSK && !SR_OCAQ_ATOMIC_FOLD) {
-        // Overlapping cross attention (hat.py:494-517): table entry j = (ky - qy + 15) * 39 + (kx - qx + 15) with (ky, kx) the key's position in the 24 x 24 neighbourhood;
-        // row j - 880, negative rows wrap.  The index-map fold below is 144 ds_add_f32 per wave with up to four lanes per address -- LDS float atomics run lane by lane:
-        // 40 us of this 145-us launch (a build without them).  Here, as for the 16 x 16 self-attention windows above: rotating the sixteen query columns by the key's
-        // column inside the tile puts (kx - qx) on the lane column (no wrap: kx0 - lr, wrapped: + 16), the sums over r and the lane groups follow, and 16 lanes add two
-        // DISTINCT entries per tile.  A tile is 16 consecutive keys of a 24-key row: tiles with kt % 3 == 1 straddle two rows (lane groups 0, 1 | 2, 3).
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            float pos = 0.f, neg = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 4 * lg + r;
-                const float w = __shfl(dbacc[kt][r], (lane & 48) | ((lr + c) & 15), 64);
-                const bool p = lr + c <= 15;
-                pos += p ? w : 0.f;
-                neg += p ? 0.f : w;
-            }
-            pos = wave_sum_xor(pos, 16);
-            neg = wave_sum_xor(neg, 16);
-            const int ky = (16 * kt) / 24;
-            int kyr, kx0;
-            bool writer;
-            if (kt % 3 == 1) {  // keys 16 .. 23 of row ky (lane groups 0, 1) | keys 0 .. 7 of row ky + 1 (lane groups 2, 3)
-                kyr = lg < 2 ? ky : ky + 1;
-                kx0 = lg < 2 ? 16 : -8;
-                writer = (lg & 1) == 0;
-            } else {
-                pos = wave_sum_xor(pos, 32);
-                neg = wave_sum_xor(neg, 32);
-                kyr = ky;
-                kx0 = kt % 3 == 0 ? 0 : 8;
-                writer = lg == 0;
-            }
-            if (writer) {
-                const int dxp = kx0 - lr, dxn = dxp + 16;  // kx - qx of the two sums
-                const int row = (kyr - qt + 15) * 39 + 15 - 880;
-                if (dxp >= -15 && dxp <= 23) {
-                    const int t = row + dxp;
-                    atomicAdd(&tab[t < 0 ? t + a.T : t], pos);
-                }
-                if (dxn >= -15 && dxn <= 23) {
-                    const int t = row + dxn;
-                    atomicAdd(&tab[t < 0 ? t + a.T : t], neg);
-                }
-            }
-        }
+        oca_table_fold<KT>(dbacc, tab, qt, lane, a.T);
     } else {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -438,6 +447,152 @@ __global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_kv_kernel(SrTrAttnBwd a
     }
 }
 
+
+// ---- pass Q of the overlapping cross attention with the FORWARD's log-sum-exp (SrTrAttnBwd.lse_given, round 5, ABI v11).  The pass above recomputes the softmax: all 36 logit
+// tiles of a query tile live at once beside the 36 gradient tiles of the table (288 registers: one wave per SIMD) and K / V / K^T of the whole neighbourhood staged per window
+// (114 KB: one workgroup per CU) -- 145 us per launch for 11 GFLOP.  With lse known, P = exp(S - lse) tile by tile: a pair of key tiles is live at a time (the dQ MFMA consumes
+// them), the neighbourhood is staged in two halves of 18 key tiles (60 KB: TWO workgroups per CU at two waves per SIMD), dQ accumulates in registers across the halves.
+// delta = rowsum(dO o O) is still produced here (for pass KV); lse is read, not written.
+constexpr int QO_KT = 36, QO_HALF = 18;
+constexpr int QO_LDS = 3 * QO_HALF * 1024 + 6144;
+__global__ __launch_bounds__(256, 2) void sr_tr_attn_bwd_q_oca_kernel(SrTrAttnBwd a) {
+    constexpr int KT = QO_KT, HALF = QO_HALF, NK = KT * 16, NQ = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_qo[];  // K | V | K^T fragments of HALF key tiles, then the head's table
+    const Frag<bf16>* KL = reinterpret_cast<const Frag<bf16>*>(smem_qo);
+    const Frag<bf16>* VL = KL + HALF * 64;
+    const Frag<bf16>* KTL = VL + HALF * 64;
+    float* REL = reinterpret_cast<float*>(smem_qo + 3 * HALF * 1024);
+    __shared__ float tab[1536];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wave;
+    const int qt = item & 15;
+    const int gh = item >> 4;
+    const int grp = gh % a.groups, head = gh / a.groups;  // head-major: the 4 waves of a workgroup share (head, group)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wpg = (a.n_bwin + a.groups - 1) / a.groups;
+    const int qi = qt * 16 + lr;
+    // rel index of this lane's logits of tile kt = (ky - qt + 15) * 39 + (kx0 - lr + 15) + r, (ky, kx0) = row / column of key 16 kt + 4 lg (see the pass above)
+    const int off_k[3] = {4 * lg, lg < 2 ? 16 + 4 * lg : 39 + 4 * lg - 8, 8 + 4 * lg};
+    const int rel0 = (15 - qt) * 39 + 15 - lr;
+    {
+        const float* bh_ = a.bias + (size_t)head * NQ * NK;
+        for (int j = threadIdx.x; j < 39 * 39; j += 256) {
+            const int dyp = j / 39, dxp = j - dyp * 39;
+            const int qy = dyp >= 15 ? 0 : 15 - dyp, ky = dyp >= 15 ? dyp - 15 : 0, qx = dxp >= 15 ? 0 : 15 - dxp, kx = dxp >= 15 ? dxp - 15 : 0;
+            REL[j] = bh_[(size_t)(qy * 16 + qx) * NK + ky * 24 + kx];
+        }
+        for (int i = threadIdx.x; i < 1536; i += 256) tab[i] = 0.f;
+    }
+    // The two halves of the neighbourhood are the OUTER loop (the table gradient of 18 key tiles = 72 registers lives across the window walk; all 36 would spill at two
+    // workgroups per CU): a window's dQ is completed by the second half on top of the first half's (stored as bf16 in between: dq is a bf16 tensor anyway).
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        f32x4 dbacc[HALF];
+#pragma unroll
+        for (int kt = 0; kt < HALF; ++kt) dbacc[kt] = (f32x4)(0.0f);
+        for (int wi = 0; wi < wpg; ++wi) {
+            const int bwin = grp * wpg + wi;
+            if (bwin >= a.n_bwin) break;  // (uniform over the workgroup)
+            const size_t bh = (size_t)bwin * a.heads + head;
+            const bf16* k = reinterpret_cast<const bf16*>(a.k) + bh * NK * 32 + (size_t)hf * HALF * 16 * 32;
+            const bf16* v = reinterpret_cast<const bf16*>(a.v) + bh * NK * 32 + (size_t)hf * HALF * 16 * 32;
+            const bf16* kT = reinterpret_cast<const bf16*>(a.kT) + bh * NK * 32 + hf * HALF * 16;
+            const Frag<bf16> qf = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.q) + (bh * NQ + qi) * 32 + lg * 8);
+            const size_t orow = ((size_t)bwin * NQ + qi) * a.ldo + head * 32 + lg * 8;
+            const Frag<bf16> dof = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.dO) + orow);
+            const Frag<bf16> of = *reinterpret_cast<const Frag<bf16>*>(reinterpret_cast<const bf16*>(a.o) + orow);
+            const float lse_q = a.lse[bh * NQ + qi];
+            float dl = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) dl += (float)dof.v[jj] * (float)of.v[jj];
+            dl = wave_sum_xor(dl, 16);
+            dl = wave_sum_xor(dl, 32);
+            bf16* dqp = reinterpret_cast<bf16*>(a.dq) + (bh * NQ + qi) * 32 + lg * 4;
+            f32x4 dq[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+            if (hf == 0) {
+                if (lg == 0) a.delta[bh * NQ + qi] = dl;
+            } else {
+                const bf16x4 p0 = *reinterpret_cast<const bf16x4*>(dqp), p1 = *reinterpret_cast<const bf16x4*>(dqp + 16);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    dq[0][rr] = (float)p0[rr];
+                    dq[1][rr] = (float)p1[rr];
+                }
+            }
+            constexpr int PIECES = HALF * 64, PER = (PIECES + 255) / 256;  // 16-byte pieces per array (1152), per thread (4.5)
+            __syncthreads();  // the previous fragments (and, the first time, the table fill) are through for every wave
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                Frag<bf16> r[PER];
+#pragma unroll
+                for (int arr = 0; arr < 2; ++arr) {
+                    const bf16* src = arr == 0 ? k : v;
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int c = i * 256 + threadIdx.x;
+                        if (c < PIECES) r[i] = *reinterpret_cast<const Frag<bf16>*>(src + (size_t)c * 8);
+                    }
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int c = i * 256 + threadIdx.x, key = c >> 2, g = c & 3;
+                        if (c < PIECES) *reinterpret_cast<Frag<bf16>*>(smem_qo + (arr * HALF * 64 + (key >> 4) * 64 + g * 16 + (key & 15)) * 16) = r[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int c = i * 256 + threadIdx.x;
+                    const int d = c / (HALF * 2), k0 = (c - d * (HALF * 2)) * 8;  // keys k0 .. k0 + 7 (inside this half) of feature row d
+                    if (c < PIECES) r[i] = *reinterpret_cast<const Frag<bf16>*>(kT + (size_t)d * NK + k0);
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int c = i * 256 + threadIdx.x;
+                    const int d = c / (HALF * 2), k0 = (c - d * (HALF * 2)) * 8;
+                    const int stp = k0 >> 5, e_hi = (k0 >> 4) & 1, g0 = (k0 >> 2) & 3;
+                    if (c < PIECES) {
+                        char* cell = smem_qo + (2 * HALF * 64 + ((d >> 4) * (HALF / 2) + stp) * 64 + g0 * 16 + (d & 15)) * 16 + e_hi * 8;
+                        const bf16x8 v8 = r[i].v;
+                        *reinterpret_cast<bf16x4*>(cell) = __builtin_shufflevector(v8, v8, 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(cell + 16 * 16) = __builtin_shufflevector(v8, v8, 4, 5, 6, 7);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < HALF / 2; ++ks) {
+                f32x4 dsp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int ktl = 2 * ks + e, kt = hf * HALF + ktl;
+                    const float* tr = REL + rel0 + ((16 * kt) / 24) * 39 + off_k[kt % 3];
+                    f32x4 b4;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) b4[rr] = tr[rr];
+                    const f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KL[ktl * 64 + lane].v, qf.v, b4, 0, 0, 0);  // S^T[key 16 kt + 4 lg + r][query lr] + bias
+                    const f32x4 dp = mma_z(VL[ktl * 64 + lane], dof);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) dsp[e][rr] = __expf(sv[rr] - lse_q) * (dp[rr] - dl);
+                    dbacc[ktl] += dsp[e];
+                }
+                const Frag<bf16> pf = pack_p(dsp[0], dsp[1]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) mma(KTL[(dt * (HALF / 2) + ks) * 64 + lane], pf, dq[dt]);  // C[d = 16 dt + 4 lg + r][query lr]
+                if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from hoisting every fragment read of the half at once)
+            }
+            store4(dqp, dq[0]);
+            store4(dqp + 16, dq[1]);
+        }
+        __syncthreads();  // (hf == 0: also orders the table's zero fill before the first adds)
+        if (hf == 0)
+            oca_table_fold<HALF, 0>(dbacc, tab, qt, lane, a.T);
+        else
+            oca_table_fold<HALF, HALF>(dbacc, tab, qt, lane, a.T);
+    }
+    __syncthreads();
+    float* dst = a.dtab_part + (size_t)blockIdx.x * a.Tpad;
+    for (int i = threadIdx.x; i < a.T; i += 256) dst[i] = tab[i];
+}
 
 // ---- pass KV of the overlapping cross attention (256 queries x 576 keys per (window, head), SrTrAttnBwd.oca_rel) with the QUERY side in LDS (round 5).  The generic pass above is
 // one wave per (window, head, two key tiles): every wave pulls the window's q / dO / q^T / dO^T fragments (64 KB) and its bias rows from L2 -- 660 MB per launch, 120 us at the
@@ -1030,7 +1185,12 @@ extern "C" int sr_tr_attn_bwd(const SrTrAttnBwd* p, void* stream) {
             hipLaunchKernelGGL((sr_tr_attn_bwd_q_kernel<16, 0>), dim3((items_q + 3) / 4), dim3(256), 0, st, b);
     } else {
         static const bool ldsk = !(getenv("SR_TR_OCA_LDS") && atoi(getenv("SR_TR_OCA_LDS")) == 0);  // A/B knob
-        if (ldsk && a.oca_rel && a.T == 39 * 39 && a.ws == 16) {
+        if (ldsk && a.oca_rel && a.T == 39 * 39 && a.lse_given && a.shift == 0 && a.Tpad >= 1521) {  // the forward's lse: tile-by-tile softmax, two workgroups per CU
+            static SrDeviceOnce once_qo;
+            const hipError_t e = sr_once_per_device(once_qo, [&] { return sr_allow_lds(sr_tr_attn_bwd_q_oca_kernel, QO_LDS); });
+            SR_REQUIRE(e == hipSuccess, "sr_tr_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(sr_tr_attn_bwd_q_oca_kernel, dim3((items_q + 3) / 4), dim3(256), QO_LDS, st, b);
+        } else if (ldsk && a.oca_rel && a.T == 39 * 39 && a.ws == 16) {
             constexpr int lds = 3 * 36 * 1024 + 6144;
             static SrDeviceOnce once;
             const hipError_t e = sr_once_per_device(once, [&] { return sr_allow_lds(sr_tr_attn_bwd_q_kernel<36, 0, true>, lds); });

@@ -39,6 +39,7 @@ ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
 CONV_WG_SIDE = os.environ.get("SR_TR_CONV_WG_SIDE", "1") != "0"  # A/B knob: the CAB convs' weight-gradient launch on the backward's side stream
 FINALIZE_LONG = int(os.environ.get("SR_TR_FINALIZE_LONG", "64"))  # tuning knob: items with at least this many slices are finalized by eight lanes each (0: never)
+OCA_LSE = os.environ.get("SR_TR_OCA_LSE", "1") != "0"  # A/B knob: the OCAB's forward keeps its log-sum-exp; the backward's pass Q then runs tile by tile at two workgroups per CU
 BWD_DUAL = os.environ.get("SR_TR_BWD_DUAL", "1") != "0"  # A/B knob: the CAB branch of a HAB's backward on a side stream beside the attention backward
 _SIDE = {}
 
@@ -604,6 +605,7 @@ class BlockPlan:
         if self.oca:
             n = T // 256 * HEADS * 576 * 32
             self.k, self.kT, self.v = e(n), e(n), e(n)  # the unfolded neighbourhoods
+            self.lse_fwd = e(T * HEADS, dt=f32) if (self.o_bias_rel is not None and OCA_LSE) else None
         else:
             self.k, self.kT, self.v, self.vT = (e(T * CP) for _ in range(4))
             self.n1 = None
@@ -631,7 +633,8 @@ class BlockPlan:
             L.check(lib.sr_tr_oca_fold(C.byref(a), 1, _st()), "sr_tr_oca_fold")
             _call(lib.sr_tr_attn_fwd, L.SrTrAttnFwd, "sr_tr_attn_fwd", q=self.q.data_ptr(), k=self.k.data_ptr(), vT=sc.vwinT.data_ptr(), bias=fa[self.o_bias:].data_ptr(),
                   out=self.o.data_ptr(), n_bwin=nbw, heads=HEADS, hd_p=HDP, Nq=256, Nk=576, ldo=CP,
-                  bias_rel=None if self.o_bias_rel is None else fa[self.o_bias_rel:].data_ptr())
+                  bias_rel=None if self.o_bias_rel is None else fa[self.o_bias_rel:].data_ptr(),
+                  lse=None if self.lse_fwd is None else self.lse_fwd.data_ptr())  # (the LDS form keeps every query row's log-sum-exp for the backward's pass Q)
         else:
             _call(lib.sr_tr_qkv_fwd, L.SrTrQkvFwd, "sr_tr_qkv_fwd", x=cur.data_ptr(), gamma=fa[self.o_g1:].data_ptr(), beta=fa[self.o_b1:].data_ptr(),
                   wstream=wa[self.o_qkvf:].data_ptr(), q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
@@ -694,9 +697,10 @@ class BlockPlan:
             with torch.cuda.stream(side):
                 jobs_cab = self._cab_backward(st, B, H, W, T, lib, wa, fa, sc, pp, op)
         dkp, dvp = (sc.dkwin, sc.dvwin) if self.oca else (sc.dk, sc.dv)
+        lse_given = self.oca and getattr(self, "lse_fwd", None) is not None
         _call(lib.sr_tr_attn_bwd, L.SrTrAttnBwd, "sr_tr_attn_bwd", q=self.q.data_ptr(), qT=self.qT.data_ptr(), k=self.k.data_ptr(), kT=self.kT.data_ptr(), v=self.v.data_ptr(),
               o=self.o.data_ptr(), dO=sc.dOw.data_ptr(), dOT=sc.dOT.data_ptr(), bias=fa[self.o_bias:].data_ptr(), biasT=fa[self.o_biasT:].data_ptr(), dq=sc.dq.data_ptr(),
-              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=sc.lse.data_ptr(), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // self.nq,
+              dk=dkp.data_ptr(), dv=dvp.data_ptr(), lse=(self.lse_fwd if lse_given else sc.lse).data_ptr(), lse_given=int(lse_given), delta=sc.delta.data_ptr(), dtab_part=pp(self.f_tab), rpi=self.rpi_dev.data_ptr(), n_bwin=T // self.nq,
               heads=HEADS, hd_p=HDP, Nq=self.nq, Nk=self.nk, ldo=CP, groups=self.groups, T=self.table.shape[0], Tpad=self.tpad, toeplitz16=int(not self.oca and self.std_rpi), H=H, W=W,
               ws=self.ws, shift=self.shift,
               oca_rel=int(self.oca and self.o_bias_rel is not None))
@@ -1180,7 +1184,7 @@ class HatPlan:
         nbw = B * H * W // 256
         # window groups of the OCAB's pass Q (one 4-wave workgroup per (group, head, 64 queries), one workgroup per CU): the largest divisor of the window count
         # that keeps the launch within one residency round of the 256 CUs (HAT x4 step at groups 8 / 16 / 32 / 64: 20.07 / 20.46 / 20.61 / 21.58 ms; SR_TR_GROUPS: A/B knob)
-        groups = max(1, min(nbw, int(os.environ.get("SR_TR_GROUPS", str(max(1, 256 // (HEADS * 4)))))))
+        groups = max(1, min(nbw, int(os.environ.get("SR_TR_GROUPS", str(max(1, (512 if OCA_LSE else 256) // (HEADS * 4)))))))
         while nbw % groups:
             groups -= 1
         self.scratch = Scratch(B, H, W, dev, groups, oca=self.with_oca)

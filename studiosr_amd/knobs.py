@@ -51,10 +51,11 @@ KNOBS = {
     "SR_TR_CONV_WG_SIDE": ("1", "select", "the CAB convs' weight-gradient launch on the backward's side stream beside sr_tr_qkv_bwd and the nn.Linear weight gradients"),
     "SR_TR_BWD_DUAL": ("1", "select", "CAB branch of a HAB's backward on a side stream"),
     "SR_TR_ATTN_LDS": ("1", "select", "window-attention backward as one LDS-form launch (0: two register passes; both tested against torch)"),
+    "SR_TR_OCA_LSE": ("1", "select", "the OCAB's forward keeps its log-sum-exp and the backward's pass Q runs tile by tile at two workgroups per CU (0: pass Q recomputes the softmax)"),
     "SR_TR_OCA_KV_LDS": ("1", "select", "library: OCAB pass KV with the query side and the bias table in LDS (0: the generic register pass; compared by the fused tests)"),
     "SR_TR_OCA_LDS": ("1", "select", "OCAB pass Q in LDS form"),
     "SR_TR_MIDPRE": ("1", "select", "the CAB's conv1 pre-activation kept by the forward (0: recomputed in the backward)"),
-    "SR_TR_GROUPS": ("10", "tune", "window groups of the OCAB's pass Q (default 256 // (6 heads x 4))"),
+    "SR_TR_GROUPS": ("21", "tune", "window groups of the OCAB's pass Q (default 512 // (6 heads x 4), rounded down to a divisor of the window count; 256 // 24 with SR_TR_OCA_LSE=0)"),
     "SR_WG_WIDE": ("1", "select", "library: nn.Linear weight gradients on 192 x 96 tiles (sr_tr_wgrad_wide_kernel; 0: the 64 x 64 tiles; both tested against torch)"),
     "SR_TR_FINALIZE_LONG": ("64", "tune", "gradient partial sums with at least this many slices are reduced by eight lanes per element (0: one thread per element)"),
     "SR_WG_KS": ("16", "tune", "token slices of the weight-gradient GEMMs"),
