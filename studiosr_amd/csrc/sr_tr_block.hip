@@ -15,7 +15,10 @@
 
 namespace {
 
-constexpr int TR_DIST = 2;
+#ifndef SR_TR_DIST
+#define SR_TR_DIST 4  // weight slots in flight ahead of the MFMAs: 2 / 3 / 4 / 6 = HAT step 15.86 / 15.49 / 15.57 / 15.53 ms, SwinIR 8.36 / 8.12 / 8.05 / 8.10 (one workgroup per CU: 512 registers, every L2 round trip exposed)
+#endif
+constexpr int TR_DIST = SR_TR_DIST;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 struct TrGeo {
