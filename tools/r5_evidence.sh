@@ -5,6 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 bash tools/profile_bench.sh r05 > gpurun_out/r05_profile_bench.log 2>&1 || echo "profile_bench failed"
 cd "$ROOT"
+# (studiosr_amd/lib/variants/wgtrace.so must be current: rebuild it with tools/exp3.sh wgtrace -DSR_WGTRACE after ANY change under csrc/ -- it links the other objects as they are)
 SR_LIB_PATH="$ROOT/studiosr_amd/lib/variants/wgtrace.so" timeout -k 10 200 python tools/wgtrace_blk3.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/r05_block_kernel_clock.txt
 timeout -k 10 300 python tools/model_bench.py EDSR SwinIR RCAN HAT SwinIR-light HAT:16 HAT:1 RCAN:8 EDSR:8 SwinIR:16 SwinIR:32 2>/dev/null > gpurun_out/r05_model_bench.jsonl
 MB_PREC=fp32x3 timeout -k 10 300 python tools/model_bench.py EDSR SwinIR RCAN RCAN:8 HAT HAT:16 HAT:1 SwinIR-light 2>/dev/null >> gpurun_out/r05_model_bench.jsonl
