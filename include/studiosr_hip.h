@@ -300,6 +300,13 @@ typedef struct SrCab {
                            * weight gradient, so that it does not run conv1 again (trainer.py:104 loss.backward() through hat.py:41-49) */
     int tile_rows;        /* (ABI v9) output rows per workgroup tile (14 columns): 0 or 6, or 8 in sr_hab_mid (large launches: fewer workgroups, less halo recomputation);
                            * pool_partial then has sr_cab_pool_tiles_rows(H, W, tile_rows) slots per image */
+    /* Backward form (ABI v11, sr_cab_fused, bf16; trainer.py:104 loss.backward() through hat.py:41-49): the CAB's data gradient is the same shape of launch with the transposed
+     * weights -- x = dy [.,Cin_p], w1p = conv2's flipped / transposed weights (Cin_p -> Cmid_p), w2p = conv1's (Cmid_p -> Cout_p), b1 = b2 = zeros -- and the pointwise step
+     * mid = conv(x) * GELU'(bwd_pre) instead of GELU(conv(x) + b1).  bwd_pre = the forward's mid_pre; side outputs for the weight gradients, NHWC [B,H,W,Cmid_p] bf16:
+     * bwd_dmid = mid, bwd_g = GELU(bwd_pre).  Replaces sr_conv3x3 -> sr_tr_gelu -> sr_conv3x3. */
+    const void* bwd_pre;
+    void* bwd_dmid;
+    void* bwd_g;
 } SrCab;
 int sr_cab_supported(int Cin_p, int Cmid_p, int Cout_p, int dtype);
 int sr_cab_pool_tiles(int H, int W);

@@ -64,7 +64,7 @@ class SrCab(C.Structure):  # (mid_pre: ABI v8)
     _fields_ = [
         ("x", _vp), ("w1p", _vp), ("b1", _vp), ("w2p", _vp), ("b2", _vp), ("y", _vp), ("pool_partial", _vp),
         ("B", _i), ("H", _i), ("W", _i), ("Cin_p", _i), ("Cmid_p", _i), ("Cout_p", _i), ("dtype", _i),
-        ("mid_pre", _vp), ("tile_rows", _i),
+        ("mid_pre", _vp), ("tile_rows", _i), ("bwd_pre", _vp), ("bwd_dmid", _vp), ("bwd_g", _vp),
     ]
 
 

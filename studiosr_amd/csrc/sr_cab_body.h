@@ -185,8 +185,26 @@ SR_DEV void cab_block(const SrCab& c, const int block_id, char* smem) {
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(c.mid_pre) + ((size_t)(b * c.H + gy) * c.W + gx) * CM + (wn * 2 + n) * 16 + ag * 4) = pre;
                 }
                 bf16x4 o;
+                if (c.bwd_pre) {  // backward form: mid = conv(dy) * GELU'(pre); side outputs dmid and GELU(pre) at the tile's own pixels
+                    const size_t pix = ((size_t)(b * c.H + (inside ? gy : 0)) * c.W + (inside ? gx : 0)) * CM + (wn * 2 + n) * 16 + ag * 4;
+                    const bf16x4 pre4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(c.bwd_pre) + pix);
+                    bf16x4 g4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? gelu_fast(v[r]) : 0.0f);
+                    for (int r = 0; r < 4; ++r) {
+                        float Phi, phi;
+                        const float pr = (float)pre4[r];
+                        gauss(pr, Phi, phi);
+                        o[r] = (bf16)(inside ? v[r] * (Phi + pr * phi) : 0.0f);
+                        g4[r] = (bf16)(pr * Phi);
+                    }
+                    if (inside && iy >= 1 && iy <= TOH && ar >= 1 && ar <= TOW) {
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(c.bwd_dmid) + pix) = o;
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(c.bwd_g) + pix) = g4;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)(inside ? gelu_fast(v[r]) : 0.0f);
+                }
                 char* dst = reinterpret_cast<char*>(Amid + kg * MID_ROWS + 1 + iy * TIW + ar) + (ag & 1) * 8;
                 *reinterpret_cast<bf16x4*>(dst) = o;
             }
@@ -291,6 +309,7 @@ static inline int cab_check(const SrCab* p, const char* who) {
     SR_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.Cin_p == CI && c.Cmid_p == CM && c.Cout_p == CO && (c.dtype == SR_BF16 || c.dtype == SR_BF16X3),
                "%s: bad CAB geometry (192 -> 64 -> 192 padded channels; bf16, or SR_BF16X3 on fp32 tensors)", who);
     SR_REQUIRE(c.x != c.y, "%s: y must not alias x (halo reads)", who);
+    SR_REQUIRE(!c.bwd_pre || (c.bwd_dmid && c.bwd_g && !c.mid_pre && c.dtype == SR_BF16), "%s: the backward form needs bwd_dmid and bwd_g, bf16, and no mid_pre", who);
     SR_REQUIRE((long)(((c.W + TOW - 1) / TOW) * ((c.H + TOH - 1) / TOH)) * c.B < (1l << 31), "%s: too many tiles", who);
     return SR_OK;
 }

@@ -255,6 +255,21 @@ SR_DEV float gelu_fast(float x) {
     return h + fabsf(h) * e;  // 0.5*x*(1 + sign(x)*erf(|x|/sqrt2))
 }
 
+// Phi(x) and phi(x) of the standard normal with erf from Abramowitz-Stegun 7.1.26 (as gelu_fast): gelu = x Phi, gelu' = Phi + x phi
+SR_DEV void gauss(float x, float& Phi, float& phi) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float ex = __expf(-z * z);
+    const float e = 1.0f - p * t * ex;
+    Phi = x >= 0.f ? 0.5f + 0.5f * e : 0.5f - 0.5f * e;
+    phi = ex * 0.3989422804014327f;
+}
+
 // tanh-form GELU written as x * sigmoid(2u): 5 VALU + v_exp + v_rcp.  |error| <= 4.8e-4 against the exact erf
 // form, i.e. ~8x below the bf16 rounding of the value it produces; used ONLY where the result is stored as bf16.
 SR_DEV float gelu_bf16(float x) {

@@ -37,21 +37,6 @@ static TrGeo make_geo(int H, int W, int ws) {
     return g;
 }
 
-// Phi(x) and phi(x) of the standard normal with erf from Abramowitz-Stegun 7.1.26 (as gelu_fast): gelu = x Phi, gelu' = Phi + x phi
-SR_DEV void gauss(float x, float& Phi, float& phi) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float ex = __expf(-z * z);
-    const float e = 1.0f - p * t * ex;
-    Phi = x >= 0.f ? 0.5f + 0.5f * e : 0.5f - 0.5f * e;
-    phi = ex * 0.3989422804014327f;
-}
-
 struct Pos {
     int w, lane, ar, ag;
 };

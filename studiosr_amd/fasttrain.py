@@ -37,6 +37,7 @@ CP, HP, HEADS, HD, HDP, CR = 192, 384, 6, 30, 32, 6
 C_REAL, HID = 180, 360
 ATTN_BWD_LDS = os.environ.get("SR_TR_ATTN_LDS", "1") != "0"  # A/B knob: window-attention backward as one LDS-form launch (read by the library too)
 ATTN_LDS = os.environ.get("SR_ATTN_LDS", "1") != "0"  # A/B knob: window attention forward with K / V^T / distinct bias tiles in LDS
+CAB_BWD_FUSED = os.environ.get("SR_TR_CAB_BWD_FUSED", "1") != "0"  # A/B knob: the CAB's data gradient (conv, GELU', conv) as one sr_cab_fused launch in its backward form
 CONV_WG_SIDE = os.environ.get("SR_TR_CONV_WG_SIDE", "1") != "0"  # A/B knob: the CAB convs' weight-gradient launch on the backward's side stream
 FINALIZE_LONG = int(os.environ.get("SR_TR_FINALIZE_LONG", "64"))  # tuning knob: items with at least this many slices are finalized by eight lanes each (0: never)
 OCA_LSE = os.environ.get("SR_TR_OCA_LSE", "1") != "0"  # A/B knob: the OCAB's forward keeps its log-sum-exp; the backward's pass Q then runs tile by tile at two workgroups per CU
@@ -751,9 +752,16 @@ class BlockPlan:
         _call(lib.sr_tr_ca_bwd, L.SrTrCaBwd, "sr_tr_ca_bwd", dgate_part=sc.dgate_part.data_ptr(), pool_partial=self.pool.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(),
               w2=w2.data_ptr(), b2=b2.data_ptr(), dy=op.dyc.data_ptr(), dparam_part=pp(self.f_ca), B=B, H=H, W=W, C=C_REAL, Cp=CP, Cr=w1.shape[0], n_tiles=self.n_tiles,
               parts=H * W // 64, ld=CP, dparam_stride=self.ca_stride, y_scale=self.conv_scale)
-        _conv(op.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
-        _call(lib.sr_tr_gelu_args, L.SrTrGelu, "sr_tr_gelu", x=mid_pre.data_ptr(), dg=sc.dmid_g.data_ptr(), g=op.mid_g.data_ptr(), dx=op.dmid.data_ptr(), n=T * 64)
-        _conv(op.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
+        if CAB_BWD_FUSED and ops.cab_supported(CP, 64, CP, L.SR_BF16):
+            # conv2's data gradient, GELU', conv1's data gradient as ONE launch: the backward form of sr_cab_fused (SrCab.bwd_pre, ABI v11) -- the same two convs with the
+            # flipped / transposed weights around a pointwise step; 49 us of three launches on the longer branch of a HAB's backward -> one
+            ops.cab_fused(x=op.dyc.data_ptr(), w1p=wa[self.o_c2t:].data_ptr(), b1=sc.zeros.data_ptr(), w2p=wa[self.o_c1t:].data_ptr(), b2=sc.zeros.data_ptr(),
+                          y=sc.dn1c.data_ptr(), pool_partial=None, B=B, H=H, W=W, Cin_p=CP, Cmid_p=64, Cout_p=CP, dtype=L.SR_BF16, tile_rows=0,
+                          bwd_pre=mid_pre.data_ptr(), bwd_dmid=op.dmid.data_ptr(), bwd_g=op.mid_g.data_ptr())
+        else:
+            _conv(op.dyc, wa[self.o_c2t:], None, sc.dmid_g, B, H, W, CP, 64)
+            _call(lib.sr_tr_gelu_args, L.SrTrGelu, "sr_tr_gelu", x=mid_pre.data_ptr(), dg=sc.dmid_g.data_ptr(), g=op.mid_g.data_ptr(), dx=op.dmid.data_ptr(), n=T * 64)
+            _conv(op.dmid, wa[self.o_c1t:], None, sc.dn1c, B, H, W, 64, CP)
         return [
             dict(A=op.dmid.data_ptr(), B=self.n1.data_ptr(), out=pp(self.f_c1), lda=64, ldb=CP, Np=64, Kp=CP, T=T, taps=9, H=H, W=W, ones_col=-1, ks=self.ks_conv),
             dict(A=op.dyc.data_ptr(), B=op.mid_g.data_ptr(), out=pp(self.f_c2), lda=CP, ldb=64, Np=CP, Kp=64, T=T, taps=9, H=H, W=W, ones_col=60, ks=self.ks_conv),
@@ -773,6 +781,7 @@ class Scratch:
         self.dOT, self.dq, self.dk, self.dv = (e(T * CP) for _ in range(4))
         self.dqkvw = e(T, 3 * CP)
         self.dgate_part = e(T // 64, CP, dt=f32)
+        self.zeros = torch.zeros(CP, dtype=f32, device=dev)  # (bias operands of the CAB's fused data-gradient launch)
         self.lse, self.delta = e(T * HEADS, dt=f32), e(T * HEADS, dt=f32)
         self.groups = groups
         self.mid_pre, self.mid_g, self.dmid_g, self.dmid = (e(T, 64) for _ in range(4))

@@ -48,6 +48,7 @@ KNOBS = {
     "SR_FAST_NODES": ("1", "select", "the step as a chain of autograd nodes, one per RHAG (0: one node; compared in the DDP overlap test)"),
     "SR_TR_PLAN": ("1", "select", "launch sequences recorded once and replayed by sr_plan_run (0: enqueued from Python every step)"),
     "SR_TR_WG_SIDE": ("0", "select", "weight-gradient launches on a stream of their own with doubled operand sets (measured +-0)"),
+    "SR_TR_CAB_BWD_FUSED": ("1", "select", "the CAB's data gradient (conv, GELU', conv) as one sr_cab_fused launch in its backward form (0: three launches; compared by the fused tests)"),
     "SR_TR_CONV_WG_SIDE": ("1", "select", "the CAB convs' weight-gradient launch on the backward's side stream beside sr_tr_qkv_bwd and the nn.Linear weight gradients"),
     "SR_TR_BWD_DUAL": ("1", "select", "CAB branch of a HAB's backward on a side stream"),
     "SR_TR_ATTN_LDS": ("1", "select", "window-attention backward as one LDS-form launch (0: two register passes; both tested against torch)"),
